@@ -1,0 +1,753 @@
+// dtsim_api.hip -- C-ABI entry points of libdtsim.so (include/dtsim.h).
+// Host-side only: handle management, table packing/upload, stream-ordered launches.
+// There is deliberately NO CPU fallback: without a HIP device dtsim_create fails with
+// DTSIM_E_NOGPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dtsim_dev.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail(DTSIM_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_;
+};
+
+}  // namespace
+
+struct dtsim {
+  dtsim_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int N = 0;
+  // SoA slab
+  void* slab = nullptr;
+  size_t slab_bytes = 0;
+  SimArrays A{};
+  // maps
+  bool have_maps = false, have_reset = false;
+  MapSet M{};
+  uint64_t* d_blobs = nullptr;
+  DynInit* d_dyn = nullptr;
+  std::vector<int> map_n_dyn, map_n_obj;
+  // reset / pool staging
+  dtsim_init_state* d_states = nullptr;
+  uint8_t* d_mask = nullptr;
+  dtsim_init_state* d_pool = nullptr;
+  int n_pool = 0;
+  // actions staging
+  void* d_actions = nullptr;
+  size_t actions_cap = 0;
+  // query staging
+  int32_t* d_qenv = nullptr;
+  double* d_qpose = nullptr;
+  dtsim_probe* d_qout = nullptr;
+  int q_cap = 0;
+  // render
+  uint8_t* frames_own = nullptr;
+  uint8_t* frames = nullptr;
+  size_t frames_bytes = 0;
+  float* d_lut = nullptr;
+  bool have_lut = false;
+  uint32_t* d_texels = nullptr;
+  TexDev* d_tex = nullptr;
+  int n_tex = 0;
+  std::vector<TexDev> h_tex;
+  MeshDev* d_meshes = nullptr;
+  TriDev* d_tris = nullptr;
+  int n_meshes = 0;
+  std::vector<MeshDev> h_meshes;
+  RenderMapDev* d_rmaps = nullptr;
+  uint32_t* d_rtiles = nullptr;
+  ObjInstDev* d_robjs = nullptr;
+  void* d_envcam = nullptr;
+  ProfSlot prof[DTSIM_KERNEL__COUNT];
+};
+
+namespace {
+
+template <typename T>
+T* carve(char*& p, size_t count) {
+  T* r = reinterpret_cast<T*>(p);
+  size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+  p += bytes;
+  return r;
+}
+
+size_t layout_arrays(SimArrays& A, int N, char* base) {
+  char* p = base;
+  const size_t n = (size_t)N;
+  A.N = N;
+  A.pos_x = carve<double>(p, n); A.pos_z = carve<double>(p, n); A.angle = carve<double>(p, n);
+  A.q_x = carve<double>(p, n); A.q_y = carve<double>(p, n); A.q_c = carve<double>(p, n); A.q_s = carve<double>(p, n);
+  A.vel_u = carve<double>(p, n); A.vel_w = carve<double>(p, n);
+  A.ring = carve<double>(p, n * DTSIM_MAX_DELAY * 2);
+  A.war = carve<double>(p, n); A.wal = carve<double>(p, n); A.wheel_dist = carve<double>(p, n);
+  A.timestamp = carve<double>(p, n); A.speed = carve<double>(p, n); A.reward = carve<double>(p, n);
+  A.lane = carve<double>(p, n * 4); A.prox = carve<double>(p, n); A.wheels = carve<double>(p, n * 2);
+  A.ob_cx = carve<double>(p, n * DTSIM_MAX_DYNAMIC); A.ob_cz = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_sx = carve<double>(p, n * DTSIM_MAX_DYNAMIC); A.ob_sz = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_corners = carve<double>(p, n * DTSIM_MAX_DYNAMIC * 8);
+  A.ob_vel = carve<double>(p, n * DTSIM_MAX_DYNAMIC); A.ob_wait = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_time = carve<double>(p, n * DTSIM_MAX_DYNAMIC); A.ob_angle = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_wiggle = carve<double>(p, n * DTSIM_MAX_DYNAMIC); A.ob_yrot = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.cam = carve<float>(p, n * 6); A.colors = carve<float>(p, n * 16);
+  A.ring_head = carve<int32_t>(p, n); A.step_count = carve<int32_t>(p, n);
+  A.tile_i = carve<int32_t>(p, n); A.tile_j = carve<int32_t>(p, n);
+  A.map_id = carve<int32_t>(p, n); A.episode = carve<int32_t>(p, n);
+  A.done = carve<uint8_t>(p, n); A.done_code = carve<uint8_t>(p, n); A.in_lane = carve<uint8_t>(p, n);
+  A.ob_active = carve<uint8_t>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_visible = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
+  return (size_t)(p - base);
+}
+
+StepParams step_params(const dtsim* h, int n_steps) {
+  StepParams P{};
+  P.n_steps = n_steps;
+  P.frame_skip = h->cfg.frame_skip;
+  P.max_steps = h->cfg.max_steps;
+  P.delay_steps = h->cfg.delay_steps;
+  P.action_mode = h->cfg.action_mode;
+  P.actions_f64 = (h->cfg.flags & DTSIM_F_ACTIONS_F64) ? 1 : 0;
+  P.auto_reset = ((h->cfg.flags & DTSIM_F_AUTO_RESET) && h->n_pool > 0) ? 1 : 0;
+  P.n_pool = h->n_pool;
+  P.delta_time = h->cfg.delta_time;
+  P.robot_speed = h->cfg.robot_speed;
+  P.gain = h->cfg.gain; P.trim = h->cfg.trim; P.radius = h->cfg.radius; P.k = h->cfg.k; P.limit = h->cfg.limit;
+  return P;
+}
+
+struct ProfScope {
+  dtsim* h; int k; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ProfScope(dtsim* h_, int k_) : h(h_), k(k_), on((h_->cfg.flags & DTSIM_F_PROFILE) != 0) {
+    if (!on) return;
+    ProfSlot& s = h->prof[k];
+    if (!s.free_.empty()) { a = s.free_.back().first; b = s.free_.back().second; s.free_.pop_back(); }
+    else { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, h->stream);
+    h->prof[k].pending.emplace_back(a, b);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int dtsim_abi_version(void) { return DTSIM_ABI_VERSION; }
+const char* dtsim_last_error(void) { return g_err.c_str(); }
+
+int dtsim_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(DTSIM_E_NOGPU, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
+  if (!cfg || !out) return fail(DTSIM_E_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(dtsim_config))
+    return fail(DTSIM_E_INVALID, "dtsim_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(dtsim_config));
+  if (cfg->num_envs <= 0) return fail(DTSIM_E_INVALID, "num_envs must be > 0");
+  if (cfg->delay_steps < 0 || cfg->delay_steps > DTSIM_MAX_DELAY)
+    return fail(DTSIM_E_LIMIT, "delay_steps %d outside [0,%d]", cfg->delay_steps, DTSIM_MAX_DELAY);
+  if (cfg->frame_skip < 1 || cfg->delta_time <= 0) return fail(DTSIM_E_INVALID, "bad frame_skip/delta_time");
+  if (cfg->cam_width <= 0 || cfg->cam_height <= 0) return fail(DTSIM_E_INVALID, "bad camera size");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(DTSIM_E_NOGPU, "no HIP device visible: libdtsim has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(DTSIM_E_INVALID, "device %d out of range", cfg->device);
+  HIPCHK(hipSetDevice(cfg->device));
+  dtsim* h = new dtsim();
+  h->cfg = *cfg;
+  h->N = cfg->num_envs;
+  if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(DTSIM_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    h->own_stream = true;
+  }
+  SimArrays tmp{};
+  h->slab_bytes = layout_arrays(tmp, h->N, reinterpret_cast<char*>(4096));
+  hipError_t e = hipMalloc(&h->slab, h->slab_bytes);
+  if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(state %zu B): %s", h->slab_bytes, hipGetErrorString(e)); }
+  (void)hipMemsetAsync(h->slab, 0, h->slab_bytes, h->stream);
+  layout_arrays(h->A, h->N, (char*)h->slab);
+  // map_id = -1 everywhere so the first reset creates the world objects
+  (void)hipMemsetAsync(h->A.map_id, 0xFF, sizeof(int32_t) * (size_t)h->N, h->stream);
+  e = hipMalloc(&h->d_states, sizeof(dtsim_init_state) * (size_t)h->N);
+  if (e == hipSuccess) e = hipMalloc(&h->d_mask, (size_t)h->N);
+  if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(reset staging): %s", hipGetErrorString(e)); }
+  if (cfg->flags & DTSIM_F_RENDER) {
+    h->frames_bytes = (size_t)h->N * cfg->cam_height * cfg->cam_width * 3;
+    e = hipMalloc(&h->frames_own, h->frames_bytes);
+    if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(frames %zu B): %s", h->frames_bytes, hipGetErrorString(e)); }
+    h->frames = h->frames_own;
+    e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
+    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * 128);
+    if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
+    if (!(cfg->flags & DTSIM_F_DISTORTION)) {
+      // identity LUT: output pixel == rectilinear pixel
+      int rc = dtsim_set_distortion_lut(h, nullptr, nullptr);
+      if (rc != DTSIM_OK) { dtsim_destroy(h); return rc; }
+    }
+  }
+  *out = h;
+  return DTSIM_OK;
+}
+
+void dtsim_destroy(dtsim_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& s : h->prof) {
+    for (auto& p : s.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto& p : s.free_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  }
+  void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
+                  h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const dtsim_mesh* meshes,
+                     int n_meshes) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (n_textures < 0 || n_textures > DTSIM_MAX_TEXTURES) return fail(DTSIM_E_LIMIT, "n_textures %d > %d", n_textures, DTSIM_MAX_TEXTURES);
+  if (n_meshes < 0 || n_meshes > DTSIM_MAX_MESHES) return fail(DTSIM_E_LIMIT, "n_meshes %d > %d", n_meshes, DTSIM_MAX_MESHES);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // textures: padded (h+1) x (w+1) storage so that GL_REPEAT bilinear fetches never wrap
+  std::vector<uint32_t> pool;
+  h->h_tex.clear();
+  for (int t = 0; t < n_textures; ++t) {
+    const dtsim_texture& tx = textures[t];
+    if (tx.width <= 0 || tx.height <= 0 || (tx.width & (tx.width - 1)) || (tx.height & (tx.height - 1)) || !tx.rgba)
+      return fail(DTSIM_E_INVALID, "texture %d: size must be a power of two", t);
+    TexDev d{tx.width, tx.height, (int32_t)pool.size(), 0};
+    const int pw = tx.width + 1;
+    pool.resize(pool.size() + (size_t)pw * (tx.height + 1));
+    uint32_t* dst = pool.data() + d.off;
+    for (int y = 0; y <= tx.height; ++y)
+      for (int x = 0; x <= tx.width; ++x) {
+        const uint8_t* s = tx.rgba + ((size_t)(y % tx.height) * tx.width + (x % tx.width)) * 4;
+        dst[(size_t)y * pw + x] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+      }
+    h->h_tex.push_back(d);
+  }
+  if (h->d_texels) { (void)hipFree(h->d_texels); h->d_texels = nullptr; }
+  if (h->d_tex) { (void)hipFree(h->d_tex); h->d_tex = nullptr; }
+  h->n_tex = n_textures;
+  if (n_textures > 0) {
+    HIPCHK(hipMalloc(&h->d_texels, pool.size() * 4));
+    HIPCHK(hipMemcpy(h->d_texels, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_tex, sizeof(TexDev) * n_textures));
+    HIPCHK(hipMemcpy(h->d_tex, h->h_tex.data(), sizeof(TexDev) * n_textures, hipMemcpyHostToDevice));
+  }
+  std::vector<TriDev> tris;
+  h->h_meshes.clear();
+  for (int m = 0; m < n_meshes; ++m) {
+    const dtsim_mesh& ms = meshes[m];
+    if (ms.n_tris < 0 || (ms.n_tris > 0 && (!ms.verts || !ms.normals || !ms.colors)))
+      return fail(DTSIM_E_INVALID, "mesh %d: null arrays", m);
+    MeshDev d{ms.n_tris, (int32_t)tris.size()};
+    for (int t = 0; t < ms.n_tris; ++t) {
+      TriDev td;
+      memcpy(td.v, ms.verts + (size_t)t * 9, 36);
+      memcpy(td.n, ms.normals + (size_t)t * 9, 36);
+      memcpy(td.c, ms.colors + (size_t)t * 9, 36);
+      tris.push_back(td);
+    }
+    h->h_meshes.push_back(d);
+  }
+  if (h->d_meshes) { (void)hipFree(h->d_meshes); h->d_meshes = nullptr; }
+  if (h->d_tris) { (void)hipFree(h->d_tris); h->d_tris = nullptr; }
+  h->n_meshes = n_meshes;
+  if (n_meshes > 0) {
+    HIPCHK(hipMalloc(&h->d_meshes, sizeof(MeshDev) * n_meshes));
+    HIPCHK(hipMemcpy(h->d_meshes, h->h_meshes.data(), sizeof(MeshDev) * n_meshes, hipMemcpyHostToDevice));
+    if (!tris.empty()) {
+      HIPCHK(hipMalloc(&h->d_tris, sizeof(TriDev) * tris.size()));
+      HIPCHK(hipMemcpy(h->d_tris, tris.data(), sizeof(TriDev) * tris.size(), hipMemcpyHostToDevice));
+    }
+  }
+  return DTSIM_OK;
+}
+
+int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
+  if (!h || !maps) return fail(DTSIM_E_INVALID, "null argument");
+  if (n_maps <= 0 || n_maps > DTSIM_MAX_MAPS) return fail(DTSIM_E_LIMIT, "n_maps %d outside [1,%d]", n_maps, DTSIM_MAX_MAPS);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<uint64_t> blobs;
+  std::vector<DynInit> dyn((size_t)n_maps * DTSIM_MAX_DYNAMIC);
+  memset(dyn.data(), 0, dyn.size() * sizeof(DynInit));
+  std::vector<RenderMapDev> rmaps(n_maps);
+  std::vector<uint32_t> rtiles;
+  std::vector<ObjInstDev> robjs;
+  MapSet M{};
+  M.n_maps = n_maps;
+  h->map_n_dyn.assign(n_maps, 0);
+  h->map_n_obj.assign(n_maps, 0);
+  for (int mi = 0; mi < n_maps; ++mi) {
+    const dtsim_map& mp = maps[mi];
+    const int nt = mp.grid_w * mp.grid_h;
+    if (mp.grid_w <= 0 || mp.grid_h <= 0 || nt > DTSIM_MAX_TILES) return fail(DTSIM_E_LIMIT, "map %d: %d tiles > %d", mi, nt, DTSIM_MAX_TILES);
+    if (mp.n_curves < 0 || mp.n_curves > DTSIM_MAX_CURVES) return fail(DTSIM_E_LIMIT, "map %d: n_curves %d", mi, mp.n_curves);
+    if (mp.n_objects < 0 || mp.n_objects > DTSIM_MAX_OBJECTS) return fail(DTSIM_E_LIMIT, "map %d: n_objects %d > %d", mi, mp.n_objects, DTSIM_MAX_OBJECTS);
+    if (!mp.tile_kind || !mp.tile_angle || !mp.tile_tex || !mp.tile_curve_off || !mp.tile_curve_cnt || !(mp.tile_size > 0))
+      return fail(DTSIM_E_INVALID, "map %d: null tile arrays / tile_size", mi);
+    if (mp.n_curves > 0 && (!mp.curves || !mp.curve_heads)) return fail(DTSIM_E_INVALID, "map %d: null curves", mi);
+    if (mp.n_objects > 0 && !mp.objects) return fail(DTSIM_E_INVALID, "map %d: null objects", mi);
+    int n_static = 0, n_dyn = 0;
+    for (int o = 0; o < mp.n_objects; ++o) {
+      if (mp.objects[o].dynamic) ++n_dyn;
+      else if (mp.objects[o].collidable) ++n_static;
+    }
+    if (n_static > DTSIM_MAX_STATIC) return fail(DTSIM_E_LIMIT, "map %d: %d static collidables > %d", mi, n_static, DTSIM_MAX_STATIC);
+    if (n_dyn > DTSIM_MAX_DYNAMIC) return fail(DTSIM_E_LIMIT, "map %d: %d dynamic objects > %d", mi, n_dyn, DTSIM_MAX_DYNAMIC);
+    MapHdr hd{};
+    hd.grid_w = mp.grid_w; hd.grid_h = mp.grid_h; hd.n_curves = mp.n_curves; hd.n_static = n_static;
+    hd.n_dyn = n_dyn; hd.n_obj = mp.n_objects; hd.tile_size = mp.tile_size;
+    int w = MAPHDR_WORDS;
+    hd.off_tiles = w; w += nt;
+    hd.off_curves = w; w += 8 * mp.n_curves;
+    hd.off_heads = w; w += 2 * mp.n_curves;
+    hd.off_static = w; w += STATIC_WORDS * n_static;
+    hd.off_objs = w; w += OBJ_WORDS * mp.n_objects;
+    hd.total_words = w;
+    const size_t base = blobs.size();
+    M.blob_off[mi] = (int32_t)base;
+    blobs.resize(base + w);
+    uint64_t* b = blobs.data() + base;
+    memcpy(b, &hd, sizeof hd);
+    for (int t = 0; t < nt; ++t) {
+      TileRec tr{};
+      tr.kind = mp.tile_kind[t]; tr.angle = mp.tile_angle[t];
+      tr.drivable = (tr.kind >= DTSIM_TILE_STRAIGHT && tr.kind <= DTSIM_TILE_4WAY) ? 1 : 0;
+      tr.curve_cnt = mp.tile_curve_cnt[t]; tr.curve_off = mp.tile_curve_off[t]; tr.tex = mp.tile_tex[t];
+      if (tr.drivable && (tr.curve_off < 0 || tr.curve_off + tr.curve_cnt > mp.n_curves || tr.curve_cnt == 0))
+        return fail(DTSIM_E_INVALID, "map %d tile %d: drivable tile without curves", mi, t);
+      if (tr.tex >= h->n_tex) return fail(DTSIM_E_INVALID, "map %d tile %d: texture %d not loaded", mi, t, tr.tex);
+      memcpy(&b[hd.off_tiles + t], &tr, 8);
+    }
+    if (mp.n_curves) {
+      memcpy(&b[hd.off_curves], mp.curves, sizeof(double) * 8 * mp.n_curves);
+      memcpy(&b[hd.off_heads], mp.curve_heads, sizeof(double) * 2 * mp.n_curves);
+    }
+    double* st = reinterpret_cast<double*>(&b[hd.off_static]);
+    double* ob = reinterpret_cast<double*>(&b[hd.off_objs]);
+    int si = 0, di = 0;
+    RenderMapDev& rm = rmaps[mi];
+    rm.grid_w = mp.grid_w; rm.grid_h = mp.grid_h; rm.n_obj = mp.n_objects; rm.pad = 0;
+    rm.tile_size = (float)mp.tile_size; rm.inv_tile_size = (float)(1.0 / mp.tile_size);
+    rm.tile_off = (int32_t)rtiles.size(); rm.obj_off = (int32_t)robjs.size();
+    for (int t = 0; t < nt; ++t) {
+      const bool present = mp.tile_kind[t] != DTSIM_TILE_EMPTY;
+      const int tex = mp.tile_tex[t] < 0 ? 0xFF : mp.tile_tex[t];
+      rtiles.push_back((uint32_t)tex | ((uint32_t)(mp.tile_angle[t] & 3) << 8) | ((present ? 1u : 0u) << 15) |
+                       ((mp.tile_tex[t] >= 0 ? 1u : 0u) << 14));
+    }
+    for (int o = 0; o < mp.n_objects; ++o) {
+      const dtsim_object& ob_ = mp.objects[o];
+      if (ob_.mesh_id >= h->n_meshes) return fail(DTSIM_E_INVALID, "map %d object %d: mesh %d not loaded", mi, o, ob_.mesh_id);
+      int slot = -1;
+      if (ob_.dynamic) {
+        slot = di++;
+        DynInit& d = dyn[(size_t)mi * DTSIM_MAX_DYNAMIC + slot];
+        d.cx = ob_.pos[0]; d.cz = ob_.pos[2];
+        memcpy(d.corners, ob_.corners, sizeof d.corners);
+        memcpy(d.norm, ob_.norm, sizeof d.norm);
+        d.heading_x = std::cos(ob_.angle); d.heading_z = -std::sin(ob_.angle);  // collision.py:223-230
+        d.angle = ob_.angle; d.safety_radius = ob_.safety_radius;
+        d.walk_distance = ob_.walk_distance; d.vel = ob_.vel; d.wait_time = ob_.wait_time; d.wiggle = ob_.wiggle;
+        d.obj_index = o;
+      } else if (ob_.collidable) {
+        double* r = st + STATIC_WORDS * si++;
+        memcpy(r, ob_.corners, 8 * sizeof(double));
+        memcpy(r + 8, ob_.norm, 4 * sizeof(double));
+        r[12] = ob_.pos[0]; r[13] = ob_.pos[2]; r[14] = ob_.safety_radius;
+      }
+      ob[o * OBJ_WORDS + 0] = ob_.pos[0]; ob[o * OBJ_WORDS + 1] = ob_.pos[2];
+      ob[o * OBJ_WORDS + 2] = ob_.spawn_clear; ob[o * OBJ_WORDS + 3] = (double)slot;
+      ObjInstDev oi{};
+      oi.x = (float)ob_.pos[0]; oi.y = (float)ob_.pos[1]; oi.z = (float)ob_.pos[2];
+      oi.scale = (float)ob_.scale; oi.yrot_deg = (float)(ob_.angle * (180.0 / 3.141592653589793));
+      oi.mesh_id = ob_.mesh_id; oi.dyn_slot = slot;
+      robjs.push_back(oi);
+    }
+    h->map_n_dyn[mi] = n_dyn; h->map_n_obj[mi] = mp.n_objects;
+  }
+  M.total_words = (int32_t)blobs.size();
+  if ((size_t)M.total_words * 8 > 60000)
+    return fail(DTSIM_E_LIMIT, "map tables %zu B exceed the 60 KB LDS staging budget", (size_t)M.total_words * 8);
+  void* olds[] = {h->d_blobs, h->d_dyn, h->d_rmaps, h->d_rtiles, h->d_robjs};
+  for (void* p : olds) if (p) (void)hipFree(p);
+  h->d_blobs = nullptr; h->d_dyn = nullptr; h->d_rmaps = nullptr; h->d_rtiles = nullptr; h->d_robjs = nullptr;
+  HIPCHK(hipMalloc(&h->d_blobs, blobs.size() * 8));
+  HIPCHK(hipMemcpy(h->d_blobs, blobs.data(), blobs.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->d_dyn, dyn.size() * sizeof(DynInit)));
+  HIPCHK(hipMemcpy(h->d_dyn, dyn.data(), dyn.size() * sizeof(DynInit), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->d_rmaps, rmaps.size() * sizeof(RenderMapDev)));
+  HIPCHK(hipMemcpy(h->d_rmaps, rmaps.data(), rmaps.size() * sizeof(RenderMapDev), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->d_rtiles, std::max<size_t>(rtiles.size(), 1) * 4));
+  if (!rtiles.empty()) HIPCHK(hipMemcpy(h->d_rtiles, rtiles.data(), rtiles.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->d_robjs, std::max<size_t>(robjs.size(), 1) * sizeof(ObjInstDev)));
+  if (!robjs.empty()) HIPCHK(hipMemcpy(h->d_robjs, robjs.data(), robjs.size() * sizeof(ObjInstDev), hipMemcpyHostToDevice));
+  M.blobs = h->d_blobs;
+  M.dyn = h->d_dyn;
+  h->M = M;
+  h->have_maps = true;
+  // worlds must be re-created against the new maps
+  HIPCHK(hipMemsetAsync(h->A.map_id, 0xFF, sizeof(int32_t) * (size_t)h->N, h->stream));
+  h->have_reset = false;
+  return DTSIM_OK;
+}
+
+int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (!h->d_lut) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  if ((rmapx == nullptr) != (rmapy == nullptr)) return fail(DTSIM_E_INVALID, "rmapx/rmapy must both be given");
+  if (rmapx && !(h->cfg.flags & DTSIM_F_DISTORTION)) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_DISTORTION");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int W = h->cfg.cam_width, H = h->cfg.cam_height;
+  std::vector<float> lut((size_t)W * H * 4);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) {
+      long sx = c, sy = r;
+      if (rmapx) {
+        // cv2.remap(INTER_NEAREST): cvRound = round-half-to-even of the float map
+        // (distortion.py:118-124); outside the source image => BORDER_CONSTANT 0.
+        sx = std::lrint((double)rmapx[(size_t)r * W + c]);
+        sy = std::lrint((double)rmapy[(size_t)r * W + c]);
+      }
+      float* o = &lut[((size_t)r * W + c) * 4];
+      const bool ok = sx >= 0 && sx < W && sy >= 0 && sy < H;
+      // NDC of the centre of rectilinear pixel (sy, sx); row 0 = image top (simulator.py:1949)
+      o[0] = ok ? (float)((2.0 * (sx + 0.5)) / W - 1.0) : 0.f;
+      o[1] = ok ? (float)(1.0 - (2.0 * (sy + 0.5)) / H) : 0.f;
+      o[2] = ok ? 1.f : 0.f;
+      o[3] = 0.f;
+    }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
+  h->have_lut = true;
+  return DTSIM_OK;
+}
+
+static int check_states(const dtsim* h, const dtsim_init_state* st, int n, const uint8_t* mask) {
+  for (int e = 0; e < n; ++e) {
+    if (mask && !mask[e]) continue;
+    if (st[e].map_id < 0 || st[e].map_id >= h->M.n_maps) return fail(DTSIM_E_INVALID, "state %d: map_id %d out of range", e, st[e].map_id);
+  }
+  return DTSIM_OK;
+}
+
+int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states) {
+  if (!h || !states) return fail(DTSIM_E_INVALID, "null argument");
+  if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_reset before dtsim_set_maps");
+  if (!mask && false) {}
+  int rc = check_states(h, states, h->N, mask);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(h->d_states, states, sizeof(dtsim_init_state) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  if (mask) HIPCHK(hipMemcpyAsync(h->d_mask, mask, (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, DTSIM_KERNEL_RESET);
+    dt_launch_reset(h->stream, h->A, h->M, step_params(h, 0), mask ? h->d_mask : nullptr, h->d_states);
+  }
+  HIPCHK(hipGetLastError());
+  // the host buffers may be reused by the caller as soon as we return
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!mask) h->have_reset = true;
+  else h->have_reset = true;
+  return DTSIM_OK;
+}
+
+int dtsim_set_spawn_pool(dtsim_t* h, const dtsim_init_state* pool, int n_pool) {
+  if (!h || !pool || n_pool <= 0) return fail(DTSIM_E_INVALID, "bad pool");
+  if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_set_spawn_pool before dtsim_set_maps");
+  int rc = check_states(h, pool, n_pool, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->d_pool) { (void)hipFree(h->d_pool); h->d_pool = nullptr; }
+  HIPCHK(hipMalloc(&h->d_pool, sizeof(dtsim_init_state) * (size_t)n_pool));
+  HIPCHK(hipMemcpy(h->d_pool, pool, sizeof(dtsim_init_state) * (size_t)n_pool, hipMemcpyHostToDevice));
+  h->n_pool = n_pool;
+  return DTSIM_OK;
+}
+
+int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_device) {
+  if (!h || !actions || n_steps <= 0) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_step before dtsim_set_maps/dtsim_reset");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t esz = (h->cfg.flags & DTSIM_F_ACTIONS_F64) ? 8 : 4;
+  const size_t bytes = (size_t)n_steps * h->N * 2 * esz;
+  const void* dptr = actions;
+  if (!actions_on_device) {
+    if (bytes > h->actions_cap) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (h->d_actions) (void)hipFree(h->d_actions);
+      h->d_actions = nullptr; h->actions_cap = 0;
+      HIPCHK(hipMalloc(&h->d_actions, bytes));
+      h->actions_cap = bytes;
+    }
+    // pageable host memory: hipMemcpyAsync stages synchronously, so the caller may
+    // reuse `actions` on return
+    HIPCHK(hipMemcpyAsync(h->d_actions, actions, bytes, hipMemcpyHostToDevice, h->stream));
+    dptr = h->d_actions;
+  }
+  {
+    ProfScope ps(h, DTSIM_KERNEL_STEP);
+    dt_launch_step(h->stream, h->A, h->M, step_params(h, n_steps), dptr, h->d_pool);
+  }
+  HIPCHK(hipGetLastError());
+  return DTSIM_OK;
+}
+
+int dtsim_render(dtsim_t* h) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_render before dtsim_set_maps/dtsim_reset");
+  if (!h->have_lut) return fail(DTSIM_E_STATE, "DTSIM_F_DISTORTION set but dtsim_set_distortion_lut was not called");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  RenderParams R{};
+  R.N = h->N; R.W = h->cfg.cam_width; R.H = h->cfg.cam_height;
+  R.distortion = (h->cfg.flags & DTSIM_F_DISTORTION) ? 1 : 0;
+  R.domain_rand = (h->cfg.flags & DTSIM_F_DOMAIN_RAND) ? 1 : 0;
+  R.n_maps = h->M.n_maps;
+  R.frames = h->frames; R.lut = h->d_lut; R.texels = h->d_texels; R.tex = h->d_tex;
+  R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
+  R.envcam = h->d_envcam;
+  {
+    ProfScope ps(h, DTSIM_KERNEL_RENDER);
+    dt_launch_render(h->stream, h->A, R);
+  }
+  HIPCHK(hipGetLastError());
+  return DTSIM_OK;
+}
+
+void* dtsim_frames_devptr(dtsim_t* h) { return h ? h->frames : nullptr; }
+size_t dtsim_frames_bytes(const dtsim_t* h) { return h ? h->frames_bytes : 0; }
+
+int dtsim_bind_frames(dtsim_t* h, void* devptr) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (!h->frames_own) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  h->frames = devptr ? (uint8_t*)devptr : h->frames_own;
+  return DTSIM_OK;
+}
+
+int dtsim_query(dtsim_t* h, int n, const int32_t* env_idx, const double* poses, double safety_factor,
+                dtsim_probe* out) {
+  if (!h || n <= 0 || !env_idx || !poses || !out) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_query before dtsim_set_maps/dtsim_reset");
+  for (int i = 0; i < n; ++i)
+    if (env_idx[i] < 0 || env_idx[i] >= h->N) return fail(DTSIM_E_INVALID, "env_idx[%d]=%d out of range", i, env_idx[i]);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (n > h->q_cap) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_qenv) (void)hipFree(h->d_qenv);
+    if (h->d_qpose) (void)hipFree(h->d_qpose);
+    if (h->d_qout) (void)hipFree(h->d_qout);
+    h->d_qenv = nullptr; h->d_qpose = nullptr; h->d_qout = nullptr; h->q_cap = 0;
+    const int cap = n < 256 ? 256 : n;
+    HIPCHK(hipMalloc(&h->d_qenv, sizeof(int32_t) * cap));
+    HIPCHK(hipMalloc(&h->d_qpose, sizeof(double) * 3 * cap));
+    HIPCHK(hipMalloc(&h->d_qout, sizeof(dtsim_probe) * cap));
+    h->q_cap = cap;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_qenv, env_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_qpose, poses, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, DTSIM_KERNEL_QUERY);
+    dt_launch_query(h->stream, h->A, h->M, step_params(h, 0), n, h->d_qenv, h->d_qpose, safety_factor, h->d_qout);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, h->d_qout, sizeof(dtsim_probe) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DTSIM_OK;
+}
+
+// ---- field access -------------------------------------------------------------
+namespace {
+struct FieldDesc { void* base; size_t elem; int comps; size_t comp_stride_elems; bool planar; };
+
+// planar == true: device layout is [comps][N]; the public layout is [N][comps].
+bool field_desc(dtsim* h, int field, FieldDesc& d) {
+  const SimArrays& A = h->A;
+  const size_t N = (size_t)h->N;
+  switch (field) {
+    case DTSIM_FIELD_ANGLE: d = {A.angle, 8, 1, N, true}; return true;
+    case DTSIM_FIELD_REWARD: d = {A.reward, 8, 1, N, true}; return true;
+    case DTSIM_FIELD_DONE: d = {A.done, 1, 1, N, true}; return true;
+    case DTSIM_FIELD_DONE_CODE: d = {A.done_code, 1, 1, N, true}; return true;
+    case DTSIM_FIELD_STEP_COUNT: d = {A.step_count, 4, 1, N, true}; return true;
+    case DTSIM_FIELD_LANE: d = {A.lane, 8, 4, N, true}; return true;
+    case DTSIM_FIELD_IN_LANE: d = {A.in_lane, 1, 1, N, true}; return true;
+    case DTSIM_FIELD_PROX: d = {A.prox, 8, 1, N, true}; return true;
+    case DTSIM_FIELD_SPEED: d = {A.speed, 8, 1, N, true}; return true;
+    case DTSIM_FIELD_TIMESTAMP: d = {A.timestamp, 8, 1, N, true}; return true;
+    case DTSIM_FIELD_WHEELS: d = {A.wheels, 8, 2, N, true}; return true;
+    case DTSIM_FIELD_MAP_ID: d = {A.map_id, 4, 1, N, true}; return true;
+    case DTSIM_FIELD_OBJ_ACTIVE: d = {A.ob_active, 1, DTSIM_MAX_DYNAMIC, N, true}; return true;
+    case DTSIM_FIELD_OBJ_YROT: d = {A.ob_yrot, 8, DTSIM_MAX_DYNAMIC, N, true}; return true;
+    case DTSIM_FIELD_OBJ_VISIBLE: d = {A.ob_visible, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
+    case DTSIM_FIELD_EPISODE: d = {A.episode, 4, 1, N, true}; return true;
+    default: return false;
+  }
+}
+
+size_t public_bytes(const dtsim* h, int field) {
+  const size_t N = (size_t)h->N;
+  switch (field) {
+    case DTSIM_FIELD_POS: return N * 3 * 8;
+    case DTSIM_FIELD_TILE: return N * 2 * 4;
+    case DTSIM_FIELD_OBJ_CENTER: return N * DTSIM_MAX_DYNAMIC * 2 * 8;
+    case DTSIM_FIELD_OBJ_PARAMS: return N * DTSIM_MAX_DYNAMIC * 3 * 8;
+    case DTSIM_FIELD_STATE_BLOB: return h->slab_bytes;
+    default: {
+      FieldDesc d;
+      if (!field_desc(const_cast<dtsim*>(h), field, d)) return 0;
+      return N * d.comps * d.elem;
+    }
+  }
+}
+
+// copy `ncomp` planar device arrays ([c][N], given per-component base pointers) into the
+// public [N][ncomp] layout (or back).
+int xfer_planar(dtsim* h, void* const* bases, int ncomp, size_t elem, void* host, bool to_host) {
+  const size_t N = (size_t)h->N;
+  std::vector<char> tmp(N * elem);
+  for (int c = 0; c < ncomp; ++c) {
+    if (to_host) {
+      if (bases[c] == nullptr) { memset(tmp.data(), 0, tmp.size()); }
+      else {
+        hipError_t e = hipMemcpy(tmp.data(), bases[c], N * elem, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(DTSIM_E_HIP, "hipMemcpy D2H: %s", hipGetErrorString(e));
+      }
+      for (size_t i = 0; i < N; ++i) memcpy((char*)host + (i * ncomp + c) * elem, tmp.data() + i * elem, elem);
+    } else {
+      if (bases[c] == nullptr) continue;
+      for (size_t i = 0; i < N; ++i) memcpy(tmp.data() + i * elem, (const char*)host + (i * ncomp + c) * elem, elem);
+      hipError_t e = hipMemcpy(bases[c], tmp.data(), N * elem, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(DTSIM_E_HIP, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    }
+  }
+  return DTSIM_OK;
+}
+
+int field_xfer(dtsim* h, int field, void* host, size_t bytes, bool to_host) {
+  if (!h || !host) return fail(DTSIM_E_INVALID, "null argument");
+  const size_t need = public_bytes(h, field);
+  if (need == 0) return fail(DTSIM_E_INVALID, "unknown field %d", field);
+  if (bytes != need) return fail(DTSIM_E_INVALID, "field %d: %zu bytes given, %zu expected", field, bytes, need);
+  hipError_t e0 = hipSetDevice(h->cfg.device);
+  if (e0 == hipSuccess) e0 = hipStreamSynchronize(h->stream);
+  if (e0 != hipSuccess) return fail(DTSIM_E_HIP, "sync: %s", hipGetErrorString(e0));
+  const SimArrays& A = h->A;
+  const size_t N = (size_t)h->N;
+  std::vector<void*> bases;
+  switch (field) {
+    case DTSIM_FIELD_STATE_BLOB: {
+      hipError_t e = to_host ? hipMemcpy(host, h->slab, need, hipMemcpyDeviceToHost)
+                             : hipMemcpy(h->slab, host, need, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(DTSIM_E_HIP, "hipMemcpy blob: %s", hipGetErrorString(e));
+      return DTSIM_OK;
+    }
+    case DTSIM_FIELD_POS: bases = {A.pos_x, nullptr, A.pos_z}; return xfer_planar(h, bases.data(), 3, 8, host, to_host);
+    case DTSIM_FIELD_TILE: bases = {A.tile_i, A.tile_j}; return xfer_planar(h, bases.data(), 2, 4, host, to_host);
+    case DTSIM_FIELD_OBJ_CENTER:
+      for (int d = 0; d < DTSIM_MAX_DYNAMIC; ++d) { bases.push_back(A.ob_cx + d * N); bases.push_back(A.ob_cz + d * N); }
+      return xfer_planar(h, bases.data(), DTSIM_MAX_DYNAMIC * 2, 8, host, to_host);
+    case DTSIM_FIELD_OBJ_PARAMS:
+      for (int d = 0; d < DTSIM_MAX_DYNAMIC; ++d) { bases.push_back(A.ob_vel + d * N); bases.push_back(A.ob_wait + d * N); bases.push_back(A.ob_wiggle + d * N); }
+      return xfer_planar(h, bases.data(), DTSIM_MAX_DYNAMIC * 3, 8, host, to_host);
+    default: {
+      FieldDesc d;
+      field_desc(h, field, d);
+      for (int c = 0; c < d.comps; ++c) bases.push_back((char*)d.base + c * d.comp_stride_elems * d.elem);
+      return xfer_planar(h, bases.data(), d.comps, d.elem, host, to_host);
+    }
+  }
+}
+}  // namespace
+
+int dtsim_read(dtsim_t* h, int field, void* dst, size_t bytes) { return field_xfer(h, field, dst, bytes, true); }
+int dtsim_write(dtsim_t* h, int field, const void* src, size_t bytes) {
+  return field_xfer(h, field, const_cast<void*>(src), bytes, false);
+}
+
+void* dtsim_field_devptr(dtsim_t* h, int field) {
+  if (!h) return nullptr;
+  if (field == DTSIM_FIELD_STATE_BLOB) return h->slab;
+  if (field == DTSIM_FIELD_POS) return h->A.pos_x;  // planar: x plane; z plane = pos_z
+  FieldDesc d;
+  if (!field_desc(h, field, d)) return nullptr;
+  return d.base;
+}
+
+size_t dtsim_field_bytes(const dtsim_t* h, int field) { return h ? public_bytes(h, field) : 0; }
+size_t dtsim_state_bytes(const dtsim_t* h) { return h ? h->slab_bytes : 0; }
+
+int dtsim_sync(dtsim_t* h) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DTSIM_OK;
+}
+
+void* dtsim_stream(dtsim_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int dtsim_profile_read(dtsim_t* h, int kernel, int* n_launches, double* total_ms) {
+  if (!h || kernel < 0 || kernel >= DTSIM_KERNEL__COUNT || !n_launches || !total_ms) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!(h->cfg.flags & DTSIM_F_PROFILE)) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_PROFILE");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  ProfSlot& s = h->prof[kernel];
+  double tot = 0;
+  for (auto& p : s.pending) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms;
+    s.free_.push_back(p);
+  }
+  *n_launches = (int)s.pending.size();
+  *total_ms = tot;
+  s.pending.clear();
+  return DTSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// Internal device-side layout of libdtsim (not part of the C-ABI).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   * per-env state is struct-of-arrays, one array per scalar, index = env, all carved
+//     from ONE slab so a checkpoint is a single memcpy (DTSIM_FIELD_STATE_BLOB);
+//     thread e of the step kernel touches element e of each array => every load/store
+//     of a wavefront is one fully coalesced 512-byte (f64) transaction.
+//   * per-map tables are one packed blob of 8-byte words per map, copied into LDS by
+//     each workgroup of the step kernel (tiles, Bezier control points, static OBBs).
+//   * frames are [N][H][W][3] uint8.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dtsim.h"
+
+// ---- constants of the reference (simulator.py:99-177), evaluated exactly as
+// Python evaluates them (IEEE double, same operation order) -------------------
+#define DT_CAMERA_FORWARD_DIST 0.066
+#define DT_ROBOT_WIDTH (0.13 + 0.02)
+#define DT_ROBOT_LENGTH 0.18
+#define DT_CENTER_SHIFT (DT_CAMERA_FORWARD_DIST - (DT_ROBOT_LENGTH / 2))
+#define DT_SAFETY_RAD_MULT 1.8
+#define DT_AGENT_SAFETY_RAD ((DT_ROBOT_LENGTH / 2) * DT_SAFETY_RAD_MULT) /* max(L,W)=L */
+#define DT_REWARD_INVALID_POSE (-1000.0)
+
+// ---- packed map blob --------------------------------------------------------
+struct MapHdr {            // 8-byte words; offsets are in words from the blob start
+  int32_t grid_w, grid_h;
+  int32_t n_curves, n_static;
+  int32_t n_dyn, n_obj;
+  int32_t off_tiles, off_curves;   // tiles: 1 word each; curves: 8 words each (P0x,P0z..P3x,P3z)
+  int32_t off_heads, off_static;   // heads: 2 words per curve; static: 15 words each
+  int32_t off_objs, total_words;   // objs: 4 words each (x, z, spawn_clear, dyn_slot(as double, -1 static))
+  double tile_size;
+};
+static_assert(sizeof(MapHdr) % 8 == 0, "MapHdr must be whole words");
+#define MAPHDR_WORDS (sizeof(MapHdr) / 8)
+
+struct TileRec {           // one 8-byte word
+  uint8_t kind, angle, drivable, curve_cnt;
+  int16_t curve_off, tex;
+};
+static_assert(sizeof(TileRec) == 8, "TileRec is one word");
+
+// static collidable record: corners[8] norms[4] center[2] radius[1]
+#define STATIC_WORDS 15
+#define OBJ_WORDS 4
+
+struct DynInit {           // per map, per dynamic slot: initial DuckieObj state
+  double cx, cz, corners[8], norm[4], heading_x, heading_z, angle, safety_radius;
+  double walk_distance, vel, wait_time, wiggle;
+  int32_t obj_index, pad;
+};
+
+// ---- per-env SoA ------------------------------------------------------------
+struct SimArrays {
+  int32_t N;
+  // pose + dynamics (duckietown_world state, restated)
+  double *pos_x, *pos_z, *angle;
+  double *q_x, *q_y, *q_c, *q_s, *vel_u, *vel_w;
+  double *ring;            // [DTSIM_MAX_DELAY][2][N]  delayed [left,right] duty
+  double *war, *wal;       // angular input gains (trim)
+  double *wheel_dist;
+  double *timestamp, *speed;
+  double *reward;
+  double *lane;            // [4][N]
+  double *prox;
+  double *wheels;          // [2][N]
+  // dynamic objects [slot][N]
+  double *ob_cx, *ob_cz, *ob_sx, *ob_sz;
+  double *ob_corners;      // [8][DTSIM_MAX_DYNAMIC][N]
+  double *ob_vel, *ob_wait, *ob_time, *ob_angle, *ob_wiggle, *ob_yrot;
+  // render / DR parameters (f32, consumed by the raster)
+  float *cam;              // [6][N] height, pitch(rad), fov_y(rad), noise x,y,z
+  float *colors;           // [16][N] horizon rgb, ground rgb, ambient rgb, diffuse rgb, light xyzw
+  int32_t *ring_head, *step_count, *tile_i, *tile_j, *map_id, *episode;
+  uint8_t *done, *done_code, *in_lane;
+  uint8_t *ob_active;      // [DTSIM_MAX_DYNAMIC][N]
+  uint8_t *ob_visible;     // [DTSIM_MAX_OBJECTS][N]
+};
+
+struct StepParams {
+  int32_t n_steps, frame_skip, max_steps, delay_steps;
+  int32_t action_mode, actions_f64, auto_reset, n_pool;
+  double delta_time, robot_speed;
+  double gain, trim, radius, k, limit;
+};
+
+// All maps, device side
+struct MapSet {
+  int32_t n_maps;
+  int32_t blob_off[DTSIM_MAX_MAPS];   // word offset of each map blob inside `blobs`
+  int32_t total_words;
+  const uint64_t* blobs;
+  const DynInit* dyn;                 // [n_maps][DTSIM_MAX_DYNAMIC]
+};
+
+// launchers implemented in physics.hip
+void dt_launch_step(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
+                    const void* actions, const dtsim_init_state* pool);
+void dt_launch_reset(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
+                     const uint8_t* mask, const dtsim_init_state* states);
+void dt_launch_query(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P, int n,
+                     const int32_t* env_idx, const double* poses, double safety_factor, dtsim_probe* out);
+
+// ---- raster -----------------------------------------------------------------
+struct TexDev { int32_t w, h, off, pad; };   // off: texel offset into the texel pool; storage is (h+1) x (w+1), padded for REPEAT
+struct MeshDev { int32_t n_tris, off; };     // off: triangle offset into the triangle pool
+struct TriDev { float v[3][3]; float n[3][3]; float c[3][3]; };
+
+struct RenderMapDev {       // per map, raster view of the grid + objects
+  int32_t grid_w, grid_h, n_obj, pad;
+  float tile_size, inv_tile_size;
+  int32_t tile_off;         // offset into tile table (uint32 per tile: tex | angle<<8 | present<<15)
+  int32_t obj_off;          // offset into object-instance table
+};
+
+struct ObjInstDev {         // static render instance (dynamic ones are patched per env)
+  float x, y, z, scale, yrot_deg;
+  int32_t mesh_id, dyn_slot, pad;
+};
+
+struct RenderParams {
+  int32_t N, W, H, distortion;
+  int32_t domain_rand, n_maps, pad0, pad1;
+  uint8_t* frames;
+  const float* lut;             // [H*W][4]: source-pixel NDC x, y (of the rectilinear pixel), valid flag, pad
+  const uint32_t* texels;       // RGBA8 pool
+  const TexDev* tex;
+  const RenderMapDev* maps;
+  const uint32_t* tiles;
+  const ObjInstDev* objs;
+  const MeshDev* meshes;
+  const TriDev* tris;
+  void* envcam;                 // [N] EnvCam scratch written by the setup kernel
+};
+
+void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

@@ -1,0 +1,568 @@
+// physics.hip -- the non-render half of Simulator.step as ONE fused HIP kernel for gfx950.
+//
+//   k_step : one thread per env; per launch n_steps x { [DuckietownEnv kinematics] ->
+//            frame_skip x update_physics -> _compute_done_reward }.
+//            Reference: envs/duckietown_env.py:36-72, simulator.py:1551-1584, 1669-1705,
+//            2076-2088, collision.py, graphics.py:286-333, objects.py:384-431.
+//   k_reset: Simulator.reset()'s state hand-over (simulator.py:740-755).
+//   k_query: the reference's geometry queries at arbitrary poses (used by the host
+//            reset sampler and by the drop-in Simulator's query methods).
+//
+// Numerics: float64 throughout, compiled with -ffp-contract=off so that every product
+// and sum is rounded separately, in the reference's operation order (numpy elementwise
+// ufuncs do not fuse).  done/collision flags and tile indices are therefore bit-exact
+// against the oracle except on measure-zero ties (DESIGN.md "Parity").
+//
+// Memory: per-env state is SoA => all wave accesses are coalesced 512-B transactions.
+// Map tables (<= a few KB per map) are staged once per workgroup into LDS.
+// Roofline: HBM-bound by construction: algorithmic bytes per env-step =
+// read+write of the SoA state; at N=4096 the working set is L2-resident and the kernel
+// is latency-bound, so n_steps are fused per launch.
+#include "dtsim_dev.h"
+
+#pragma clang fp contract(off)
+
+#define STEP_BLOCK 64
+
+namespace {
+
+struct MapView {
+  const MapHdr* h;
+  const TileRec* tiles;
+  const double* curves;
+  const double* heads;
+  const double* stat;
+  const double* objs;
+};
+
+__device__ inline MapView map_view(const uint64_t* blob) {
+  MapView v;
+  v.h = reinterpret_cast<const MapHdr*>(blob);
+  v.tiles = reinterpret_cast<const TileRec*>(blob + v.h->off_tiles);
+  v.curves = reinterpret_cast<const double*>(blob + v.h->off_curves);
+  v.heads = reinterpret_cast<const double*>(blob + v.h->off_heads);
+  v.stat = reinterpret_cast<const double*>(blob + v.h->off_static);
+  v.objs = reinterpret_cast<const double*>(blob + v.h->off_objs);
+  return v;
+}
+
+// simulator.py:1134-1149 get_grid_coords + :1053-1063 _get_tile
+__device__ inline const TileRec* tile_at(const MapView& m, double x, double z, int& i, int& j) {
+  const double ts = m.h->tile_size;
+  const double fi = floor(x / ts), fj = floor(z / ts);
+  // keep int conversion defined for wild values
+  i = (fi < -1e9) ? -1000000000 : (fi > 1e9 ? 1000000000 : (int)fi);
+  j = (fj < -1e9) ? -1000000000 : (fj > 1e9 ? 1000000000 : (int)fj);
+  if (i < 0 || i >= m.h->grid_w || j < 0 || j >= m.h->grid_h) return nullptr;
+  const TileRec* t = &m.tiles[j * m.h->grid_w + i];
+  return t->kind == DTSIM_TILE_EMPTY ? nullptr : t;
+}
+
+// simulator.py:1411-1428
+__device__ inline bool drivable_pos(const MapView& m, double x, double z) {
+  int i, j;
+  const TileRec* t = tile_at(m, x, z, i, j);
+  return t != nullptr && t->drivable;
+}
+
+// collision.py:50-61 (closed intervals)
+__device__ inline bool overlaps(double min1, double max1, double min2, double max2) {
+  return (min1 <= min2 && min2 <= max1) || (min2 <= min1 && min1 <= max2);
+}
+
+// min/max over 4 corners of n . c   (collision.py:37-47 tensor_sat_test)
+__device__ inline void proj4(double nx, double nz, const double* c, double& mn, double& mx) {
+  double p0 = nx * c[0] + nz * c[1];
+  double p1 = nx * c[2] + nz * c[3];
+  double p2 = nx * c[4] + nz * c[5];
+  double p3 = nx * c[6] + nz * c[7];
+  mn = fmin(fmin(p0, p1), fmin(p2, p3));
+  mx = fmax(fmax(p0, p1), fmax(p2, p3));
+}
+
+// collision.py:129-186: SAT between the agent box (corners ac, axes an) and one OBB.
+__device__ inline bool sat_pair(const double* ac, const double* an, const double* oc, const double* on) {
+  double a0, a1, b0, b1;
+  proj4(an[0], an[1], ac, a0, a1);
+  proj4(an[0], an[1], oc, b0, b1);
+  if (!overlaps(a0, a1, b0, b1)) return false;
+  proj4(an[2], an[3], ac, a0, a1);
+  proj4(an[2], an[3], oc, b0, b1);
+  if (!overlaps(a0, a1, b0, b1)) return false;
+  proj4(on[0], on[1], ac, a0, a1);
+  proj4(on[0], on[1], oc, b0, b1);
+  if (!overlaps(a0, a1, b0, b1)) return false;
+  proj4(on[2], on[3], ac, a0, a1);
+  proj4(on[2], on[3], oc, b0, b1);
+  if (!overlaps(a0, a1, b0, b1)) return false;
+  return true;
+}
+
+// collision.py:9-34 agent_boundbox applied to _actual_center (simulator.py:2112-2116)
+__device__ inline void agent_corners(double px, double pz, double dx, double dz, double rx, double rz,
+                                     double* c /*[8]*/) {
+  const double tx = px + DT_CENTER_SHIFT * dx;
+  const double tz = pz + DT_CENTER_SHIFT * dz;
+  const double hw = 0.5 * DT_ROBOT_WIDTH, hl = 0.5 * DT_ROBOT_LENGTH;
+  c[0] = (tx - hw * rx) - hl * dx;  c[1] = (tz - hw * rz) - hl * dz;
+  c[2] = (tx + hw * rx) - hl * dx;  c[3] = (tz + hw * rz) - hl * dz;
+  c[4] = (tx + hw * rx) + hl * dx;  c[5] = (tz + hw * rz) + hl * dz;
+  c[6] = (tx - hw * rx) + hl * dx;  c[7] = (tz - hw * rz) + hl * dz;
+}
+
+// simulator.py:1473-1492 _collision.  Agent axes = (dir, right): the eigenvectors the
+// reference gets from generate_norm (collision.py:99-106) for the 0.15 x 0.18 box.
+__device__ inline bool collision(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
+                                 const double* ac, double dx, double dz, double rx, double rz) {
+  const double an[4] = {dx, dz, rx, rz};
+  const int ns = m.h->n_static;
+  for (int s = 0; s < ns; ++s) {
+    const double* r = m.stat + s * STATIC_WORDS;
+    if (sat_pair(ac, an, r, r + 8)) return true;
+  }
+  const int nd = m.h->n_dyn;
+  const int N = A.N;
+  for (int d = 0; d < nd; ++d) {
+    double oc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) oc[k] = A.ob_corners[(size_t)(k * DTSIM_MAX_DYNAMIC + d) * N + e];
+    if (sat_pair(ac, an, oc, dyn[d].norm)) return true;
+  }
+  return false;
+}
+
+// simulator.py:1494-1534 _valid_pose, including the second _actual_center inside
+// get_agent_corners (box centred at cur_pos - 0.048 dir).
+__device__ inline bool valid_pose(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
+                                  double px, double pz, double angle, double sf, bool* coll_out) {
+  const double ca = cos(angle), sa = sin(angle);
+  const double dx = ca, dz = -sa, rx = sa, rz = ca;
+  const double cx = px + DT_CENTER_SHIFT * dx, cz = pz + DT_CENTER_SHIFT * dz;
+  const double w = sf * 0.5 * DT_ROBOT_WIDTH, l = sf * 0.5 * DT_ROBOT_LENGTH;
+  const bool all_drivable = drivable_pos(m, cx, cz) && drivable_pos(m, cx - w * rx, cz - w * rz) &&
+                            drivable_pos(m, cx + w * rx, cz + w * rz) && drivable_pos(m, cx + l * dx, cz + l * dz);
+  double ac[8];
+  agent_corners(cx, cz, dx, dz, rx, rz, ac);
+  const bool coll = collision(m, A, dyn, e, ac, dx, dz, rx, rz);
+  if (coll_out) *coll_out = coll;
+  return (!coll) && all_drivable;
+}
+
+// simulator.py:1430-1459 proximity_penalty2 + collision.py:189-211 + objects.py:373-382
+__device__ inline double proximity(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
+                                   double px, double pz, double angle) {
+  const double cx = px + DT_CENTER_SHIFT * cos(angle), cz = pz + DT_CENTER_SHIFT * (-sin(angle));
+  const double r1 = DT_AGENT_SAFETY_RAD;
+  double total = 0.0;
+  const int ns = m.h->n_static;
+  if (ns > 0) {
+    bool gate = false;
+    double sum = 0.0;
+    for (int s = 0; s < ns; ++s) {
+      const double* r = m.stat + s * STATIC_WORDS;
+      const double ddx = r[12] - cx, ddz = r[13] - cz;
+      const double d = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+      const double r2 = r[14];
+      const double d2 = d * d, lo = (r1 - r2) * (r1 - r2), hi = (r1 + r2) * (r1 + r2);
+      gate = gate || (lo <= d2 && d2 <= hi) || (d < fabs(r1 - r2));
+      const double score = (d - r1) - r2;
+      if (score < 0) sum += score;
+    }
+    total = gate ? sum : 0.0;
+  }
+  const int nd = m.h->n_dyn;
+  const int N = A.N;
+  for (int d = 0; d < nd; ++d) {
+    const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
+    const double dist = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+    const double score = (dist - r1) - dyn[d].safety_radius;
+    total += fmin(0.0, score);
+  }
+  return total;
+}
+
+struct Lane {
+  bool in_lane;
+  int curve_idx;
+  double t, pt_x, pt_z, tan_x, tan_z, dist, dot_dir, angle_deg, angle_rad;
+};
+
+// graphics.py:286-297: Bernstein weights are exact doubles for t on the 1/512 grid.
+__device__ inline void bezier_point(const double* cp, double t, double& x, double& z) {
+  const double u = 1.0 - t;
+  const double b0 = u * u * u, b1 = 3 * t * (u * u), b2 = 3 * (t * t) * u, b3 = t * t * t;
+  x = ((b0 * cp[0] + b1 * cp[2]) + b2 * cp[4]) + b3 * cp[6];
+  z = ((b0 * cp[1] + b1 * cp[3]) + b2 * cp[5]) + b3 * cp[7];
+}
+
+// simulator.py:1337-1409 closest_curve_point + get_lane_pos2
+__device__ inline Lane lane_pos(const MapView& m, double px, double pz, double angle) {
+  Lane L;
+  L.in_lane = false; L.curve_idx = -1;
+  L.t = L.pt_x = L.pt_z = L.tan_x = L.tan_z = L.dist = L.dot_dir = L.angle_deg = L.angle_rad = 0.0;
+  int i, j;
+  const TileRec* tl = tile_at(m, px, pz, i, j);
+  if (tl == nullptr || !tl->drivable) return L;
+  const double dx = cos(angle), dz = -sin(angle);
+  // argmax_c  heading_c . dir  (headings pre-divided by the Frobenius norm on the host,
+  // simulator.py:1355-1362); first maximum wins like np.argmax.
+  int best = 0;
+  double bestv = 0.0;
+  for (int c = 0; c < tl->curve_cnt; ++c) {
+    const double* hd = m.heads + 2 * (tl->curve_off + c);
+    const double v = hd[0] * dx + hd[1] * dz;
+    if (c == 0 || v > bestv) { bestv = v; best = c; }
+  }
+  const double* cp = m.curves + 8 * (tl->curve_off + best);
+  // graphics.py:316-333 bezier_closest: 8-level endpoint-distance bisection, strict <
+  double tb = 0.0, tt = 1.0;
+  for (int n = 0; n < 8; ++n) {
+    const double mid = (tb + tt) * 0.5;
+    double bx, bz, ux, uz;
+    bezier_point(cp, tb, bx, bz);
+    bezier_point(cp, tt, ux, uz);
+    const double d_bot = sqrt(((bx - px) * (bx - px) + 0.0) + (bz - pz) * (bz - pz));
+    const double d_top = sqrt(((ux - px) * (ux - px) + 0.0) + (uz - pz) * (uz - pz));
+    if (d_bot < d_top) tt = mid; else tb = mid;
+  }
+  const double t = (tb + tt) * 0.5;
+  double ptx, ptz;
+  bezier_point(cp, t, ptx, ptz);
+  // graphics.py:300-313 bezier_tangent
+  const double u = 1.0 - t;
+  const double c0 = 3 * (u * u), c1 = 6 * u * t, c2 = 3 * (t * t);
+  double tx = (c0 * (cp[2] - cp[0]) + c1 * (cp[4] - cp[2])) + c2 * (cp[6] - cp[4]);
+  double tz = (c0 * (cp[3] - cp[1]) + c1 * (cp[5] - cp[3])) + c2 * (cp[7] - cp[5]);
+  const double nrm = sqrt((tx * tx + 0.0) + tz * tz);
+  tx /= nrm; tz /= nrm;
+  // simulator.py:1387-1409
+  double dot = (dx * tx + 0.0) + dz * tz;
+  dot = fmin(fmax(dot, -1.0), 1.0);
+  const double rvx = -tz, rvz = tx;  // cross(tangent, up)
+  const double dist = ((px - ptx) * rvx + 0.0) + (pz - ptz) * rvz;
+  double arad = acos(dot);
+  if (((dx * rvx + 0.0) + dz * rvz) < 0) arad *= -1;
+  L.in_lane = true; L.curve_idx = best; L.t = t;
+  L.pt_x = ptx; L.pt_z = ptz; L.tan_x = tx; L.tan_z = tz;
+  L.dist = dist; L.dot_dir = dot; L.angle_rad = arad;
+  L.angle_deg = arad * (180.0 / 3.141592653589793);  // np.rad2deg
+  return L;
+}
+
+// simulator.py:1654-1667
+__device__ inline double compute_reward(const Lane& L, double prox, double speed) {
+  if (!L.in_lane) return 40 * prox;
+  return ((1.0 * speed) * L.dot_dir + (-10 * fabs(L.dist))) + (40 * prox);
+}
+
+// objects.py:384-431 DuckieObj.step (non-DR finish_walk branch; DR parameters are
+// supplied per env through DTSIM_FIELD_OBJ_PARAMS because the reference draws them from
+// the unseeded global np.random, objects.py:349-350).
+__device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d, int e, double dt) {
+  const size_t N = A.N, ix = (size_t)d * N + e;
+  double time = A.ob_time[ix] + dt;
+  A.ob_time[ix] = time;
+  if (!A.ob_active[ix]) {
+    double w = A.ob_wait[ix] - dt;
+    A.ob_wait[ix] = w;
+    if (w <= 0) A.ob_active[ix] = 1;
+    return;
+  }
+  double vel = A.ob_vel[ix];
+  const double vax = di.heading_x * vel, vaz = di.heading_z * vel;
+  const double cx = A.ob_cx[ix] + vax, cz = A.ob_cz[ix] + vaz;
+  A.ob_cx[ix] = cx; A.ob_cz[ix] = cz;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    A.ob_corners[(size_t)((2 * k) * DTSIM_MAX_DYNAMIC + d) * N + e] += vax;
+    A.ob_corners[(size_t)((2 * k + 1) * DTSIM_MAX_DYNAMIC + d) * N + e] += vaz;
+  }
+  const double ddx = cx - A.ob_sx[ix], ddz = cz - A.ob_sz[ix];
+  const double distance = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+  double ang = A.ob_angle[ix];
+  if (distance > di.walk_distance) {  // finish_walk
+    A.ob_sx[ix] = cx; A.ob_sz[ix] = cz;
+    ang += 3.141592653589793;
+    A.ob_angle[ix] = ang;
+    A.ob_active[ix] = 0;
+    A.ob_vel[ix] = vel * -1;
+    A.ob_wait[ix] = 8;
+  }
+  const double angle_delta = A.ob_wiggle[ix] * sin(48 * time);
+  A.ob_yrot[ix] = (ang + angle_delta) * (180 / 3.141592653589793);
+}
+
+// duckietown_world DB18 model + SE(2) exponential, restated (PARITY UNPINNED;
+// call sites simulator.py:745-755, 2076-2088).  Mirrors oracle/sim.py DynamicsDB18.
+struct Dyn { double x, y, c, s, u, w; };
+
+__device__ inline void dyn_integrate(Dyn& q, double dt, double L_, double R_, double war, double wal) {
+  const double R = fmin(fmax(R_, -1.0), 1.0), L = fmin(fmax(L_, -1.0), 1.0);
+  const double u1 = 5.0, u2 = 0.0, u3 = 0.0, w1 = 4.0, w2 = 0.0, w3 = 0.0, uar = 1.5, ual = 1.5;
+  double u = q.u, w = q.w;
+  const double acc_u = ((-u1 * u - u2 * w) + u3 * w * w) + (uar * R + ual * L);
+  const double acc_w = ((-w1 * w - w2 * u) - w3 * u * w) + (war * R + (-wal) * L);
+  u = u + dt * acc_u;
+  w = w + dt * acc_w;
+  const double th = dt * w, vx = dt * u;
+  double cd, sd, tx, ty;
+  if (fabs(th) < 1e-12) { cd = 1.0; sd = th; tx = vx; ty = 0.0; }
+  else {
+    sd = sin(th); cd = cos(th);
+    const double Aa = sd / th, Bb = (1.0 - cd) / th;
+    tx = Aa * vx; ty = Bb * vx;
+  }
+  const double c0 = q.c, s0 = q.s;
+  q.x = (c0 * tx + (-s0) * ty) + q.x;
+  q.y = (s0 * tx + c0 * ty) + q.y;
+  q.c = c0 * cd + (-s0) * sd;
+  q.s = s0 * cd + c0 * sd;
+  q.u = u; q.w = w;
+}
+
+// Simulator.reset()'s hand-over of one env (simulator.py:740-755) from a host-drawn state.
+__device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, const dtsim_init_state& st,
+                                  int delay_steps) {
+  const size_t N = A.N;
+  const int new_map = st.map_id;
+  const MapHdr* mh = reinterpret_cast<const MapHdr*>(M.blobs + M.blob_off[new_map]);
+  A.pos_x[e] = st.pos[0]; A.pos_z[e] = st.pos[2]; A.angle[e] = st.angle;
+  // cartesian_from_weird simulator.py:1629-1638
+  A.q_x[e] = st.pos[0];
+  A.q_y[e] = mh->grid_h * mh->tile_size - st.pos[2];
+  A.q_c[e] = cos(st.angle); A.q_s[e] = sin(st.angle);
+  A.vel_u[e] = 0.0; A.vel_w[e] = 0.0;
+  for (int k = 0; k < DTSIM_MAX_DELAY * 2; ++k) A.ring[(size_t)k * N + e] = 0.0;
+  A.ring_head[e] = 0;
+  if (st.dynamics_trim_on) { A.war[e] = 15.0 * (1.0 + st.dynamics_trim); A.wal[e] = 15.0 * (1.0 - st.dynamics_trim); }
+  else { A.war[e] = 15.0; A.wal[e] = 15.0; }
+  A.wheel_dist[e] = st.wheel_dist;
+  A.step_count[e] = 0; A.timestamp[e] = 0.0; A.speed[e] = 0.0;
+  A.reward[e] = 0.0; A.done[e] = 0; A.done_code[e] = DTSIM_DONE_IN_PROGRESS;
+  A.wheels[e] = 0.0; A.wheels[N + e] = 0.0;
+  A.cam[0 * N + e] = (float)st.cam_height;
+  A.cam[1 * N + e] = (float)(st.cam_angle_deg * (3.141592653589793 / 180.0));
+  A.cam[2 * N + e] = (float)(st.cam_fov_y_deg * (3.141592653589793 / 180.0));
+  A.cam[3 * N + e] = (float)st.camera_noise[0];
+  A.cam[4 * N + e] = (float)st.camera_noise[1];
+  A.cam[5 * N + e] = (float)st.camera_noise[2];
+  for (int k = 0; k < 3; ++k) {
+    A.colors[(0 + k) * N + e] = (float)st.horizon_color[k];
+    A.colors[(3 + k) * N + e] = (float)st.ground_color[k];
+    A.colors[(6 + k) * N + e] = (float)st.light_ambient[k];
+    A.colors[(9 + k) * N + e] = (float)st.light_diffuse[k];
+  }
+  for (int k = 0; k < 4; ++k) A.colors[(12 + k) * N + e] = (float)st.light_pos[k];
+  // World objects are created at map load and persist across resets in the reference
+  // (simulator.py:349,865); (re)create them only when the env's map changes.
+  if (A.map_id[e] != new_map) {
+    const DynInit* dyn = M.dyn + (size_t)new_map * DTSIM_MAX_DYNAMIC;
+    for (int d = 0; d < mh->n_dyn; ++d) {
+      const size_t ix = (size_t)d * N + e;
+      A.ob_cx[ix] = dyn[d].cx; A.ob_cz[ix] = dyn[d].cz;
+      A.ob_sx[ix] = dyn[d].cx; A.ob_sz[ix] = dyn[d].cz;
+      for (int k = 0; k < 8; ++k) A.ob_corners[(size_t)(k * DTSIM_MAX_DYNAMIC + d) * N + e] = dyn[d].corners[k];
+      A.ob_vel[ix] = dyn[d].vel; A.ob_wait[ix] = dyn[d].wait_time; A.ob_time[ix] = 0.0;
+      A.ob_angle[ix] = dyn[d].angle; A.ob_wiggle[ix] = dyn[d].wiggle;
+      A.ob_yrot[ix] = dyn[d].angle * (180 / 3.141592653589793);
+      A.ob_active[ix] = 0;
+    }
+    for (int o = 0; o < DTSIM_MAX_OBJECTS; ++o) A.ob_visible[(size_t)o * N + e] = 1;
+    A.map_id[e] = new_map;
+  }
+  // info fields of the new pose are filled by the first step / by k_reset's tail
+  (void)delay_steps;
+}
+
+// Fill tile / lane / prox info for the current pose (what get_agent_info reports,
+// simulator.py:1586-1627).
+__device__ inline void fill_info(const SimArrays& A, const MapView& m, const DynInit* dyn, int e) {
+  const size_t N = A.N;
+  const double px = A.pos_x[e], pz = A.pos_z[e], ang = A.angle[e];
+  int i, j;
+  tile_at(m, px, pz, i, j);
+  A.tile_i[e] = i; A.tile_j[e] = j;
+  const Lane L = lane_pos(m, px, pz, ang);
+  A.in_lane[e] = L.in_lane;
+  A.lane[0 * N + e] = L.dist; A.lane[1 * N + e] = L.dot_dir;
+  A.lane[2 * N + e] = L.angle_deg; A.lane[3 * N + e] = L.angle_rad;
+  A.prox[e] = proximity(m, A, dyn, e, px, pz, ang);
+}
+
+// Stage every map blob into LDS (cooperative, 8-byte words).
+__device__ inline const uint64_t* stage_maps(const MapSet& M, uint64_t* lds) {
+  for (int k = threadIdx.x; k < M.total_words; k += blockDim.x) lds[k] = M.blobs[k];
+  __syncthreads();
+  return lds;
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, StepParams P, const void* actions,
+                                                     const dtsim_init_state* pool) {
+  extern __shared__ uint64_t lds[];
+  const uint64_t* blobs = stage_maps(M, lds);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = A.N;
+  if (e >= N) return;
+  const double dt = P.delta_time;
+
+  for (int s = 0; s < P.n_steps; ++s) {
+    // ---- auto reset (DTSIM_F_AUTO_RESET): the caller's reset() after a done=True
+    if (P.auto_reset && A.done[e]) {
+      const int ep = A.episode[e] + 1;
+      A.episode[e] = ep;
+      const long long slot = ((long long)e + (long long)ep * N) % P.n_pool;
+      apply_init(A, M, e, pool[slot], P.delay_steps);
+    }
+    const int mid = A.map_id[e];
+    const MapView m = map_view(blobs + M.blob_off[mid]);
+    const DynInit* dyn = M.dyn + (size_t)mid * DTSIM_MAX_DYNAMIC;
+
+    // ---- action (envs/duckietown_env.py:36-61, simulator.py:1670)
+    double a0, a1;
+    const size_t aoff = ((size_t)s * N + e) * 2;
+    if (P.actions_f64) { a0 = ((const double*)actions)[aoff]; a1 = ((const double*)actions)[aoff + 1]; }
+    else { a0 = (double)((const float*)actions)[aoff]; a1 = (double)((const float*)actions)[aoff + 1]; }
+    double left, right;
+    if (P.action_mode == DTSIM_ACTION_VEL_STEER) {
+      const double vel = a0, steer = a1, baseline = A.wheel_dist[e];
+      const double k_r_inv = (P.gain + P.trim) / P.k, k_l_inv = (P.gain - P.trim) / P.k;
+      const double omega_r = (vel + 0.5 * steer * baseline) / P.radius;
+      const double omega_l = (vel - 0.5 * steer * baseline) / P.radius;
+      const double u_r = omega_r * k_r_inv, u_l = omega_l * k_l_inv;
+      right = fmax(fmin(u_r, P.limit), -P.limit);
+      left = fmax(fmin(u_l, P.limit), -P.limit);
+    } else { left = a0; right = a1; }
+    left = fmin(fmax(left, -1.0), 1.0);   // np.clip(action, -1, 1) simulator.py:1670
+    right = fmin(fmax(right, -1.0), 1.0);
+    A.wheels[e] = left; A.wheels[(size_t)N + e] = right;
+
+    // ---- frame_skip x update_physics (simulator.py:1551-1584)
+    Dyn q = {A.q_x[e], A.q_y[e], A.q_c[e], A.q_s[e], A.vel_u[e], A.vel_w[e]};
+    double px = A.pos_x[e], pz = A.pos_z[e], ang = A.angle[e];
+    const double war = A.war[e], wal = A.wal[e];
+    int head = A.ring_head[e];
+    int sc = A.step_count[e];
+    double ts_ = A.timestamp[e], speed = A.speed[e];
+    const double Hts = m.h->grid_h * m.h->tile_size;
+    for (int f = 0; f < P.frame_skip; ++f) {
+      double l_use = left, r_use = right;
+      if (P.delay_steps > 0) {  // ApplyDelay: command issued delay_steps ago
+        l_use = A.ring[(size_t)(2 * head) * N + e];
+        r_use = A.ring[(size_t)(2 * head + 1) * N + e];
+        A.ring[(size_t)(2 * head) * N + e] = left;
+        A.ring[(size_t)(2 * head + 1) * N + e] = right;
+        head = (head + 1) % P.delay_steps;
+      }
+      dyn_integrate(q, dt, l_use, r_use, war, wal);
+      // weird_from_cartesian simulator.py:1640-1652
+      const double nx = q.x, nz = Hts - q.y;
+      const double ddx = nx - px, ddz = nz - pz;
+      px = nx; pz = nz; ang = atan2(q.s, q.c);
+      sc += 1; ts_ += dt;
+      speed = sqrt((ddx * ddx + 0.0) + ddz * ddz) / dt;
+      for (int d = 0; d < m.h->n_dyn; ++d) duckie_step(A, dyn[d], d, e, dt);
+    }
+    A.q_x[e] = q.x; A.q_y[e] = q.y; A.q_c[e] = q.c; A.q_s[e] = q.s; A.vel_u[e] = q.u; A.vel_w[e] = q.w;
+    A.pos_x[e] = px; A.pos_z[e] = pz; A.angle[e] = ang;
+    A.ring_head[e] = head; A.step_count[e] = sc; A.timestamp[e] = ts_; A.speed[e] = speed;
+
+    // ---- _compute_done_reward (simulator.py:1685-1705)
+    int ti, tj;
+    tile_at(m, px, pz, ti, tj);
+    A.tile_i[e] = ti; A.tile_j[e] = tj;
+    const Lane Ln = lane_pos(m, px, pz, ang);
+    const double prox = proximity(m, A, dyn, e, px, pz, ang);
+    A.in_lane[e] = Ln.in_lane;
+    A.lane[e] = Ln.dist; A.lane[(size_t)N + e] = Ln.dot_dir;
+    A.lane[(size_t)2 * N + e] = Ln.angle_deg; A.lane[(size_t)3 * N + e] = Ln.angle_rad;
+    A.prox[e] = prox;
+    double reward; uint8_t done, code;
+    if (!valid_pose(m, A, dyn, e, px, pz, ang, 1.0, nullptr)) {
+      reward = DT_REWARD_INVALID_POSE; done = 1; code = DTSIM_DONE_INVALID_POSE;
+    } else if (sc >= P.max_steps) {
+      reward = 0.0; done = 1; code = DTSIM_DONE_MAX_STEPS;
+    } else {
+      reward = compute_reward(Ln, prox, P.robot_speed); done = 0; code = DTSIM_DONE_IN_PROGRESS;
+    }
+    A.reward[e] = reward; A.done[e] = done; A.done_code[e] = code;
+  }
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, StepParams P, const uint8_t* mask,
+                                                      const dtsim_init_state* states) {
+  extern __shared__ uint64_t lds[];
+  const uint64_t* blobs = stage_maps(M, lds);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A.N) return;
+  if (mask != nullptr && !mask[e]) return;
+  apply_init(A, M, e, states[e], P.delay_steps);
+  const int mid = A.map_id[e];
+  fill_info(A, map_view(blobs + M.blob_off[mid]), M.dyn + (size_t)mid * DTSIM_MAX_DYNAMIC, e);
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void k_query(SimArrays A, MapSet M, StepParams P, int n,
+                                                      const int32_t* env_idx, const double* poses,
+                                                      double sf, dtsim_probe* out) {
+  extern __shared__ uint64_t lds[];
+  const uint64_t* blobs = stage_maps(M, lds);
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= n) return;
+  const int e = env_idx[qi];
+  const int mid = A.map_id[e];
+  const MapView m = map_view(blobs + M.blob_off[mid]);
+  const DynInit* dyn = M.dyn + (size_t)mid * DTSIM_MAX_DYNAMIC;
+  const double px = poses[3 * qi], pz = poses[3 * qi + 1], ang = poses[3 * qi + 2];
+  dtsim_probe r;
+  int i, j;
+  const TileRec* t = tile_at(m, px, pz, i, j);
+  r.tile_i = i; r.tile_j = j;
+  r.drivable = (t != nullptr && t->drivable);
+  const double ca = cos(ang), sa = sin(ang);
+  double ac[8];
+  agent_corners(px, pz, ca, -sa, sa, ca, ac);
+  r.collision = collision(m, A, dyn, e, ac, ca, -sa, sa, ca);
+  r.valid = valid_pose(m, A, dyn, e, px, pz, ang, sf, nullptr);
+  const Lane L = lane_pos(m, px, pz, ang);
+  r.in_lane = L.in_lane; r.curve_idx = L.curve_idx; r.t = L.t;
+  r.point[0] = L.pt_x; r.point[1] = L.pt_z; r.tangent[0] = L.tan_x; r.tangent[1] = L.tan_z;
+  r.dist = L.dist; r.dot_dir = L.dot_dir; r.angle_deg = L.angle_deg; r.angle_rad = L.angle_rad;
+  r.prox = proximity(m, A, dyn, e, px, pz, ang);
+  r.reward = compute_reward(L, r.prox, P.robot_speed);
+  // _inconvenient_spawn simulator.py:1461-1471 (uses obj.pos; for a DuckieObj that is its
+  // current centre, objects.py:408)
+  bool inc = false;
+  const int N = A.N;
+  for (int o = 0; o < m.h->n_obj; ++o) {
+    if (!A.ob_visible[(size_t)o * N + e]) continue;
+    const double* ob = m.objs + o * OBJ_WORDS;
+    double ox = ob[0], oz = ob[1];
+    const int slot = (int)ob[3];
+    if (slot >= 0) { ox = A.ob_cx[(size_t)slot * N + e]; oz = A.ob_cz[(size_t)slot * N + e]; }
+    const double ddx = ox - px, ddz = oz - pz;
+    inc = inc || (sqrt((ddx * ddx + 0.0) + ddz * ddz) < ob[2]);
+  }
+  r.inconvenient = inc;
+  r.pad[0] = r.pad[1] = r.pad[2] = 0;
+  out[qi] = r;
+}
+
+}  // namespace
+
+void dt_launch_step(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
+                    const void* actions, const dtsim_init_state* pool) {
+  const int grid = (A.N + STEP_BLOCK - 1) / STEP_BLOCK;
+  hipLaunchKernelGGL(k_step, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
+}
+
+void dt_launch_reset(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
+                     const uint8_t* mask, const dtsim_init_state* states) {
+  const int grid = (A.N + STEP_BLOCK - 1) / STEP_BLOCK;
+  hipLaunchKernelGGL(k_reset, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, mask, states);
+}
+
+void dt_launch_query(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P, int n,
+                     const int32_t* env_idx, const double* poses, double safety_factor, dtsim_probe* out) {
+  const int grid = (n + STEP_BLOCK - 1) / STEP_BLOCK;
+  hipLaunchKernelGGL(k_query, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, n, env_idx,
+                     poses, safety_factor, out);
+}

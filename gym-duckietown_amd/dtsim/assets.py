@@ -1,0 +1,252 @@
+"""Fixture assets: maps, procedural tile textures and a stand-in duckie mesh.
+
+The reference loads maps, textures and meshes from the third-party
+`duckietown_world` package (simulator.py:638,779; objmesh.py:37), none of which is
+available offline.  These deterministic stand-ins are the *inputs* shared
+by the HIP path and the test oracle; parity is defined on identical inputs.
+
+  * maps: `small_loop` (= the tile block of small_loop_only_duckies.yaml, no objects),
+    `small_loop_only_duckies`, `loop_only_duckies` (the two YAML files in the reference
+    root, restated as data), `loop_pedestrians` (= loop_only_duckies with static: False).
+  * textures: 256x256 RGBA8 per tile kind, lane markings laid out in the tile-local frame
+    the reference's Bezier curves use (simulator.py:1164-1225): road along local z for
+    `straight`, arc about the (u,v)=(0,1) corner for `curve_right`, (1,1) for `curve_left`.
+  * mesh: low-poly duckie, extents exactly x[-0.5,0.5] y[0,1] z[-0.34375,0.34375]
+    (dyadic => exact in float32, so OBB arithmetic is dtype-independent).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+
+TEX_SIZE = 256
+
+_G = "grass"
+_SMALL_LOOP_TILES = [
+    [_G, _G, _G, _G, _G],
+    [_G, "curve_right/N", "straight/E", "curve_right/E", _G],
+    [_G, "straight/S", _G, "straight/S", _G],
+    [_G, "curve_right/W", "straight/E", "curve_right/S", _G],
+    [_G, _G, _G, _G, _G],
+]
+_LOOP_TILES = [
+    [_G] * 8,
+    [_G, "curve_left/W", "straight/E", "straight/E", "straight/E", "straight/E", "curve_left/N", _G],
+    [_G, "straight/S", _G, _G, _G, _G, "straight/S", _G],
+    [_G, "straight/S", _G, _G, _G, _G, "straight/S", _G],
+    [_G, "straight/S", _G, _G, "curve_left/W", "straight/E", "curve_left/E", _G],
+    [_G, "curve_left/S", "straight/E", "straight/E", "curve_left/E", _G, _G, _G],
+    [_G] * 8,
+]
+
+
+def _duckies(spec, static=True):
+    return [dict(height=0.06, kind="duckie", optional=False, pos=list(p), rotate=r, static=static)
+            for p, r in spec]
+
+
+_SMALL_DUCKIES = [((2.5, 1.25), 30), ((1.75, 2.5), 60), ((2.5, 3.6), 120), ((3.4, 2.5), 170)]
+_LOOP_DUCKIES = [((4.75, 1.25), 60), ((3.25, 1.75), 210), ((1.25, 2.9), 300), ((1.75, 4.1), 270),
+                 ((3.25, 5.8), 60), ((2.75, 5.2), 240), ((6.2, 2.75), 310), ((6.8, 3.25), 50)]
+
+MAPS = {
+    "small_loop": dict(tiles=_SMALL_LOOP_TILES, objects=[], tile_size=0.585),
+    "small_loop_only_duckies": dict(tiles=_SMALL_LOOP_TILES, objects=_duckies(_SMALL_DUCKIES), tile_size=0.585),
+    "loop_only_duckies": dict(tiles=_LOOP_TILES, objects=_duckies(_LOOP_DUCKIES), tile_size=0.585),
+    "loop_pedestrians": dict(tiles=_LOOP_TILES, objects=_duckies(_LOOP_DUCKIES, static=False), tile_size=0.585),
+}
+
+
+def get_map(name: str) -> dict:
+    """Map data in the reference's MapFormat1 dict form (what yaml.load returns)."""
+    import os
+    if name in MAPS:
+        return copy.deepcopy(MAPS[name])
+    if os.path.isfile(name):
+        import yaml
+        with open(name) as f:
+            return yaml.safe_load(f)
+    raise KeyError(f"unknown map {name!r}; fixtures: {sorted(MAPS)} (or a path to a MapFormat1 YAML)")
+
+
+def map_basename(name: str) -> str:
+    import os
+    if os.path.isfile(name):  # simulator.py:771-775
+        return ".".join(os.path.basename(name).split(".")[:-1])
+    return name
+
+
+# ---------------------------------------------------------------- textures ----
+def _noise(rng, n, amp):
+    """Smooth-ish photo-like noise: coarse octaves upsampled + per-texel grain."""
+    out = np.zeros((n, n))
+    for cells, a in ((8, 0.5), (32, 0.3)):
+        g = rng.uniform(-1, 1, size=(cells, cells))
+        out += a * np.kron(g, np.ones((n // cells, n // cells)))
+    out += 0.2 * rng.uniform(-1, 1, size=(n, n))
+    return amp * out
+
+
+def _paint(base, mask, color):
+    for k in range(3):
+        base[..., k] = np.where(mask, color[k], base[..., k])
+
+
+def make_texture(kind: str, n: int = TEX_SIZE) -> np.ndarray:
+    """RGBA8 [n,n,4]; row 0 = TOP of the image file (v=1).  Use gl_rows() for upload."""
+    seed = sum(ord(ch) * (i + 1) for i, ch in enumerate(kind)) + 12345
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(1.0 - (np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n, indexing="ij")
+    img = np.zeros((n, n, 3))
+    nz = _noise(rng, n, 14.0)
+    WHITE, YELLOW, RED = (232, 232, 226), (238, 200, 36), (200, 40, 36)
+    if kind == "grass":
+        img[:] = (58, 132, 52)
+        img[..., 1] += nz * 1.8
+        img[..., 0] += nz
+        img[..., 2] += nz * 0.6
+    elif kind == "floor":
+        img[:] = (196, 188, 170)
+        img += nz[..., None] * 0.6
+    else:
+        img[:] = (62, 62, 66)
+        img += nz[..., None]
+        if kind == "straight":
+            _paint(img, (np.abs(u - 0.06) < 0.022) | (np.abs(u - 0.94) < 0.022), WHITE)
+            _paint(img, (np.abs(u - 0.5) < 0.012) & ((v * 6.0) % 1.0 < 0.55), YELLOW)
+        elif kind in ("curve_right", "curve_left"):
+            cu = 0.0 if kind == "curve_right" else 1.0
+            r = np.hypot(u - cu, v - 1.0)
+            ang = np.arctan2(np.abs(1.0 - v), np.abs(u - cu) + 1e-9)
+            _paint(img, (np.abs(r - 0.06) < 0.022) | (np.abs(r - 0.94) < 0.022), WHITE)
+            _paint(img, (np.abs(r - 0.5) < 0.012) & ((ang * 8.0 / math.pi * 2) % 1.0 < 0.55), YELLOW)
+        elif kind.startswith("3way") or kind == "4way":
+            corner = (np.minimum(u, 1 - u) < 0.08) & (np.minimum(v, 1 - v) < 0.08)
+            _paint(img, corner, WHITE)
+            stop = ((np.abs(v - 0.1) < 0.02) & (u > 0.5) & (u < 0.92)) | ((np.abs(v - 0.9) < 0.02) & (u < 0.5) & (u > 0.08))
+            _paint(img, stop, RED)
+        # asphalt / unknown: plain
+    rgba = np.empty((n, n, 4), dtype=np.uint8)
+    rgba[..., :3] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    rgba[..., 3] = 255
+    return rgba
+
+
+def gl_rows(tex: np.ndarray) -> np.ndarray:
+    """Row 0 = bottom of the image (v=0): the order pyglet/GL store textures in
+    (graphics.py:69-169) and the order dtsim_texture expects."""
+    return np.ascontiguousarray(tex[::-1])
+
+
+_TEX_CACHE: dict = {}
+
+
+def get_texture(kind: str) -> np.ndarray:
+    if kind not in _TEX_CACHE:
+        _TEX_CACHE[kind] = gl_rows(make_texture(kind))
+    return _TEX_CACHE[kind]
+
+
+# -------------------------------------------------------------------- mesh ----
+def _ellipsoid(center, radii, nu, nv, color):
+    cx, cy, cz = center
+    rx, ry, rz = radii
+    tris, nrms = [], []
+
+    def pt(i, j):
+        th = math.pi * i / nv              # polar from +y
+        ph = 2 * math.pi * j / nu
+        n = np.array([math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph)])
+        p = np.array([cx + rx * n[0], cy + ry * n[1], cz + rz * n[2]])
+        nn = np.array([n[0] / rx, n[1] / ry, n[2] / rz])
+        return p, nn / np.linalg.norm(nn)
+
+    for i in range(nv):
+        for j in range(nu):
+            a, b, c, d = pt(i, j), pt(i, j + 1), pt(i + 1, j + 1), pt(i + 1, j)
+            if i > 0:
+                tris.append((a[0], b[0], d[0])); nrms.append((a[1], b[1], d[1]))
+            if i < nv - 1:
+                tris.append((b[0], c[0], d[0])); nrms.append((b[1], c[1], d[1]))
+    cols = [np.tile(np.asarray(color, dtype=np.float64), (3, 1)) for _ in tris]
+    return tris, nrms, cols
+
+
+def _cone(base_c, tip, r, n, color):
+    bc, tip = np.asarray(base_c, float), np.asarray(tip, float)
+    ax = tip - bc
+    ax /= np.linalg.norm(ax)
+    u = np.cross(ax, [0, 1, 0]); u /= np.linalg.norm(u)
+    w = np.cross(ax, u)
+    tris, nrms, cols = [], [], []
+    for k in range(n):
+        a0, a1 = 2 * math.pi * k / n, 2 * math.pi * (k + 1) / n
+        p0 = bc + r * (math.cos(a0) * u + math.sin(a0) * w)
+        p1 = bc + r * (math.cos(a1) * u + math.sin(a1) * w)
+        nn = np.cross(p1 - p0, tip - p0)
+        nn /= np.linalg.norm(nn)
+        tris.append((p0, p1, tip)); nrms.append((nn, nn, nn))
+        cols.append(np.tile(np.asarray(color, float), (3, 1)))
+    return tris, nrms, cols
+
+
+class MeshData:
+    """What ObjMesh exposes to the hot path (objmesh.py:181-232): float32 triangle soup
+    [T,3,3] verts / normals / per-vertex Kd colours, and min_coords / max_coords."""
+
+    def __init__(self, verts, normals, colors):
+        self.verts = np.ascontiguousarray(verts, dtype=np.float32)
+        self.normals = np.ascontiguousarray(normals, dtype=np.float32)
+        self.colors = np.ascontiguousarray(colors, dtype=np.float32)
+        # objmesh.py:230-232
+        self.min_coords = self.verts.min(axis=0).min(axis=0)
+        self.max_coords = self.verts.max(axis=0).max(axis=0)
+
+    @property
+    def n_tris(self):
+        return self.verts.shape[0]
+
+
+def _finish(parts, lo, hi):
+    tris = np.array([t for p in parts for t in p[0]], dtype=np.float64)
+    nrms = np.array([t for p in parts for t in p[1]], dtype=np.float64)
+    cols = np.array([t for p in parts for t in p[2]], dtype=np.float64)
+    mn, mx = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    tris = (tris - mn) / (mx - mn) * (hi - lo) + lo          # exact target extents
+    tris = np.rint(tris * 1024.0) / 1024.0                    # dyadic grid: exact in float32
+    return MeshData(tris, nrms, cols)
+
+
+_MESH_CACHE: dict = {}
+
+
+def get_mesh(kind: str) -> MeshData:
+    """Stand-in meshes.  `duckie`: body + head + beak; anything else: a generic
+    non-square-footprint blob (square footprints make generate_norm's eigenvectors
+    arbitrary, collision.py:99-106 / SURVEY App. A)."""
+    key = "duckie" if kind == "duckie" else "*"
+    if key not in _MESH_CACHE:
+        if key == "duckie":
+            yellow, orange = (0.96, 0.80, 0.10), (0.93, 0.45, 0.08)
+            parts = [
+                _ellipsoid((0.0, 0.36, 0.0), (0.5, 0.36, 0.34375), 10, 6, yellow),
+                _ellipsoid((0.27, 0.78, 0.0), (0.21, 0.22, 0.2), 8, 5, yellow),
+                _cone((0.44, 0.76, 0.0), (0.5, 0.73, 0.0), 0.07, 5, orange),
+            ]
+            _MESH_CACHE[key] = _finish(parts, (-0.5, 0.0, -0.34375), (0.5, 1.0, 0.34375))
+        else:
+            parts = [_ellipsoid((0.0, 0.5, 0.0), (0.5, 0.5, 0.40625), 8, 5, (0.7, 0.7, 0.72))]
+            _MESH_CACHE[key] = _finish(parts, (-0.5, 0.0, -0.40625), (0.5, 1.0, 0.40625))
+    return _MESH_CACHE[key]
+
+
+def mesh_extents(kinds=("duckie",)) -> dict:
+    """kind -> (min_coords, max_coords) float32, plus '*' fallback."""
+    out = {"*": (get_mesh("*").min_coords, get_mesh("*").max_coords)}
+    for k in kinds:
+        m = get_mesh(k)
+        out[k] = (m.min_coords, m.max_coords)
+    return out

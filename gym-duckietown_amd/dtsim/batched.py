@@ -1,0 +1,369 @@
+"""BatchedSimulator: N Duckietown envs on one MI355X behind libdtsim.so.
+
+Vector counterpart of the reference's Simulator / DuckietownEnv (simulator.py:188,
+envs/duckietown_env.py:9): same constructor keywords, same reset/step semantics per
+env, batched over env index.  All per-step work happens in the HIP library; this class
+only owns host-side set-up (assets, map tables, reset RNG order) and marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _ffi, assets, maps, reset as R
+from . import distortion as dist_mod
+
+
+class DeviceArray:
+    """Zero-copy view of library-owned device memory (`__cuda_array_interface__`, v2):
+    `torch.as_tensor(arr, device="cuda")` wraps it without a copy."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class BatchedSimulator:
+    def __init__(self, map_name: Union[str, Sequence[str]] = "small_loop", num_envs: int = 1, *,
+                 max_steps: int = 1500, domain_rand: bool = True, frame_rate: float = 30, frame_skip: int = 1,
+                 camera_width: int = 640, camera_height: int = 480, robot_speed: float = 1.20,
+                 accept_start_angle_deg: float = 60, user_tile_start=None, seed: Optional[int] = None,
+                 distortion: bool = False, dynamics_rand: bool = False, camera_rand: bool = False,
+                 num_tris_distractors: int = 12, color_ground=(0.15, 0.15, 0.15), color_sky=R.BLUE_SKY,
+                 # DuckietownEnv (envs/duckietown_env.py:15)
+                 action_mode: str = "wheels", gain=1.0, trim=0.0, radius=0.0318, k=27.0, limit=1.0,
+                 # batched / device options
+                 render: bool = True, auto_reset: bool = False, delay_steps: int = 5, device: int = 0,
+                 stream: Optional[int] = None, profile: bool = False, actions_f64: bool = False,
+                 map_cycle: bool = False, transform_uses_width: bool = False, map_data: Optional[dict] = None,
+                 do_reset: bool = True):
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self._device = int(device)
+        self.num_envs = int(num_envs)
+        self.max_steps, self.domain_rand = max_steps, bool(domain_rand)
+        self.frame_rate, self.frame_skip = frame_rate, int(frame_skip)
+        self.delta_time = 1.0 / frame_rate
+        self.camera_width, self.camera_height = int(camera_width), int(camera_height)
+        self.robot_speed = robot_speed
+        self.accept_start_angle_deg = accept_start_angle_deg
+        self.user_tile_start = user_tile_start
+        self.distortion = bool(distortion)
+        self.dynamics_rand, self.camera_rand = bool(dynamics_rand), bool(camera_rand)
+        self.num_tris_distractors = num_tris_distractors
+        self.color_ground, self.color_sky = color_ground, list(color_sky)
+        self.action_mode = action_mode
+        self.render_enabled = bool(render)
+        self.auto_reset = bool(auto_reset)
+        self.actions_f64 = bool(actions_f64)
+        self.map_cycle = bool(map_cycle)
+        self.seed_value = seed
+
+        flags = 0
+        flags |= _ffi.F_RENDER if render else 0
+        flags |= _ffi.F_DISTORTION if (render and distortion) else 0
+        flags |= _ffi.F_DOMAIN_RAND if domain_rand else 0
+        flags |= _ffi.F_AUTO_RESET if auto_reset else 0
+        flags |= _ffi.F_ACTIONS_F64 if actions_f64 else 0
+        flags |= _ffi.F_PROFILE if profile else 0
+        cfg = _ffi.Config()
+        cfg.struct_size = C.sizeof(_ffi.Config)
+        cfg.flags, cfg.num_envs, cfg.device = flags, self.num_envs, int(device)
+        cfg.cam_width, cfg.cam_height = self.camera_width, self.camera_height
+        cfg.frame_skip, cfg.max_steps, cfg.delay_steps = self.frame_skip, int(max_steps), int(delay_steps)
+        cfg.action_mode = {"wheels": _ffi.ACTION_WHEELS, "vel_steer": _ffi.ACTION_VEL_STEER}[action_mode]
+        cfg.delta_time, cfg.robot_speed = self.delta_time, float(robot_speed)
+        cfg.gain, cfg.trim, cfg.radius, cfg.k, cfg.limit = float(gain), float(trim), float(radius), float(k), float(limit)
+        cfg.stream = C.c_void_p(stream) if stream else None
+        _ffi.check(self._lib, self._lib.dtsim_create(C.byref(cfg), C.byref(self._h)))
+
+        # ---- maps + assets (one-time host prep)
+        names = [map_name] if isinstance(map_name, str) else list(map_name)
+        datas = [map_data] if (map_data is not None) else [assets.get_map(n) for n in names]
+        self.map_names = [assets.map_basename(n) for n in names]
+        self.meshes: Dict[str, assets.MeshData] = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
+        mesh_order = ["duckie", "*"]
+        first = [maps.interpret_map(d, n, self.meshes, transform_uses_width) for d, n in zip(datas, self.map_names)]
+        tex_kinds: List[str] = []
+        for mt in first:
+            for kd in mt.texture_kinds:
+                if kd not in tex_kinds:
+                    tex_kinds.append(kd)
+        self.texture_kinds = tex_kinds
+        self.textures = [assets.get_texture(kd) for kd in tex_kinds]
+        tex_ids = {kd: i for i, kd in enumerate(tex_kinds)} if render else None
+        self.maps: List[maps.MapTables] = [
+            maps.interpret_map(d, n, self.meshes, transform_uses_width, texture_ids=tex_ids)
+            for d, n in zip(datas, self.map_names)]
+        if render:
+            tarr = (_ffi.Texture * len(self.textures))()
+            for i, t in enumerate(self.textures):
+                tarr[i].width, tarr[i].height = t.shape[1], t.shape[0]
+                tarr[i].rgba = t.ctypes.data_as(C.POINTER(C.c_uint8))
+            marr = (_ffi.Mesh * len(mesh_order))()
+            for i, mk in enumerate(mesh_order):
+                m = self.meshes[mk]
+                marr[i].n_tris = m.n_tris
+                marr[i].verts = m.verts.ctypes.data_as(C.POINTER(C.c_float))
+                marr[i].normals = m.normals.ctypes.data_as(C.POINTER(C.c_float))
+                marr[i].colors = m.colors.ctypes.data_as(C.POINTER(C.c_float))
+            _ffi.check(self._lib, self._lib.dtsim_set_assets(self._h, tarr, len(self.textures), marr, len(mesh_order)))
+        mesh_ids = {mk: i for i, mk in enumerate(mesh_order)} if render else {}
+        farr = (_ffi.Map * len(self.maps))()
+        for i, mt in enumerate(self.maps):
+            farr[i] = mt.to_ffi(mesh_ids)
+        _ffi.check(self._lib, self._lib.dtsim_set_maps(self._h, farr, len(self.maps)))
+        if render and distortion:
+            rmx, rmy = dist_mod.distortion_maps(self.camera_width, self.camera_height)
+            self.rmapx, self.rmapy = rmx, rmy
+            _ffi.check(self._lib, self._lib.dtsim_set_distortion_lut(
+                self._h, rmx.ctypes.data_as(C.POINTER(C.c_float)), rmy.ctypes.data_as(C.POINTER(C.c_float))))
+
+        # ---- per-env host reset state (RNG order lives on the host; reset.py)
+        self.env_state = [R.EnvResetState(None if seed is None else seed + e) for e in range(self.num_envs)]
+        self.env_map = np.zeros(self.num_envs, np.int32)
+        self.init_states = (_ffi.InitState * self.num_envs)()
+        self._have_reset = False
+        if do_reset:
+            self.reset()
+
+    # ------------------------------------------------------------------ reset --
+    def _map_for_reset(self, e: int) -> int:
+        if len(self.maps) == 1:
+            return 0
+        if not self.map_cycle:
+            return e % len(self.maps)          # fixed assignment
+        es = self.env_state[e]
+        es.map_slot = (es.map_slot + 1) % len(self.maps)   # envs/multimap_env.py:46 (first reset -> 1)
+        return es.map_slot
+
+    def sample_states(self, envs: Sequence[int]) -> None:
+        """Simulator.reset() for the given envs: fills self.init_states[e] (host draws in
+        the reference order; geometry on the device via dtsim_query)."""
+        envs = [int(e) for e in envs]
+        pend = {}
+        vis_all = None
+        for e in envs:
+            mi = self._map_for_reset(e)
+            mt = self.maps[mi]
+            st, tile, visible = R.draw_prefix(
+                self.env_state[e], mt, domain_rand=self.domain_rand, camera_rand=self.camera_rand,
+                dynamics_rand=self.dynamics_rand, color_sky=self.color_sky, color_ground=self.color_ground,
+                num_tris_distractors=self.num_tris_distractors, n_visible_draw=(), user_tile_start=self.user_tile_start)
+            st.map_id = mi
+            self.init_states[e] = st
+            self.env_state[e].spawn_attempts = 0
+            if mt.start_pose is not None:                       # simulator.py:679-688
+                i, j = tile
+                sp = mt.start_pose
+                st.pos[:] = [i * mt.tile_size + sp[0][0], 0.0, j * mt.tile_size + sp[0][2]]
+                st.angle = float(sp[1])
+                self.init_states[e] = st
+            else:
+                pend[e] = (mt, tile, visible)
+        if not pend:
+            return
+        # The device evaluates candidates against each env's *current* world; a map switch
+        # or a first reset must create that world first: provisional reset at a dummy pose.
+        need_world = [e for e in pend if (not self._have_reset) or self.env_map[e] != self.init_states[e].map_id]
+        if need_world:
+            mask = np.zeros(self.num_envs, np.uint8)
+            for e in need_world:
+                mask[e] = 1
+                self.init_states[e].pos[:] = [0.0, 0.0, 0.0]
+                self.init_states[e].angle = 0.0
+            self._reset_device(mask)
+        self._write_visibility({e: pend[e][2] for e in pend})
+        active = dict(pend)
+        while active:
+            q_env, q_pose, spans = [], [], {}
+            for e, (mt, tile, _) in active.items():
+                blk = R.attempt_block(self.env_state[e], tile, mt.tile_size)
+                spans[e] = (len(q_env), blk)
+                q_env.extend([e] * len(blk))
+                q_pose.append(blk)
+            probes = self.query(np.array(q_env, np.int32), np.concatenate(q_pose, axis=0), safety_factor=1.3)
+            nxt = {}
+            for e, (off, blk) in spans.items():
+                es = self.env_state[e]
+                k = len(blk)
+                M = self.accept_start_angle_deg
+                p = probes[off:off + k]
+                ok = (~p["inconvenient"].astype(bool)) & p["valid"].astype(bool) & p["in_lane"].astype(bool) \
+                    & (-M < p["angle_deg"]) & (p["angle_deg"] < M)
+                budget = R.MAX_SPAWN_ATTEMPTS - es.spawn_attempts
+                idx = np.flatnonzero(ok[:budget])
+                st = self.init_states[e]
+                if idx.size:
+                    a = int(idx[0])
+                    R.commit_attempts(es, a + 1)
+                    st.pos[:] = [float(blk[a, 0]), 0.0, float(blk[a, 1])]
+                    st.angle = float(blk[a, 2])
+                elif budget <= k:                              # simulator.py:732-736 fallback pose
+                    R.commit_attempts(es, budget)
+                    st.pos[:] = [1.0, 0.0, 1.0]
+                    st.angle = 1.0
+                else:
+                    R.commit_attempts(es, k)
+                    nxt[e] = active[e]
+                self.init_states[e] = st
+            active = nxt
+
+    def _write_visibility(self, vis: Dict[int, List[bool]]):
+        if all(all(v) for v in vis.values()) and not getattr(self, "_vis_dirty", False):
+            return
+        self._vis_dirty = True
+        arr = self.read(_ffi.FIELD_OBJ_VISIBLE)
+        for e, v in vis.items():
+            arr[e, :] = 1
+            arr[e, :len(v)] = np.asarray(v, np.uint8)
+        self.write(_ffi.FIELD_OBJ_VISIBLE, arr)
+
+    def _reset_device(self, mask: Optional[np.ndarray]):
+        mp = mask.ctypes.data_as(C.POINTER(C.c_uint8)) if mask is not None else None
+        _ffi.check(self._lib, self._lib.dtsim_reset(self._h, mp, self.init_states))
+        sel = range(self.num_envs) if mask is None else np.flatnonzero(mask)
+        for e in sel:
+            self.env_map[e] = self.init_states[e].map_id
+        self._have_reset = True
+
+    def reset(self, mask: Optional[np.ndarray] = None, states=None):
+        """Simulator.reset() for the masked envs (None = all).  `states`: optional
+        ctypes array / list of _ffi.InitState to use instead of sampling (parity mode)."""
+        if not self._have_reset:
+            mask = None                        # the first reset creates every env's world
+        sel = list(range(self.num_envs)) if mask is None else [int(e) for e in np.flatnonzero(mask)]
+        if states is not None:
+            for e in sel:
+                self.init_states[e] = states[e]
+        else:
+            self.sample_states(sel)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        self._reset_device(m)
+
+    def make_spawn_pool(self, n_pool: int):
+        """Pre-sample `n_pool` spawn states (env e%N's RNG stream) for DTSIM_F_AUTO_RESET."""
+        pool = (_ffi.InitState * n_pool)()
+        saved = [(_ffi.InitState.from_buffer_copy(self.init_states[e])) for e in range(self.num_envs)]
+        done = 0
+        while done < n_pool:
+            batch = min(self.num_envs, n_pool - done)
+            self.sample_states(range(batch))
+            for e in range(batch):
+                pool[done + e] = self.init_states[e]
+            done += batch
+        for e in range(self.num_envs):
+            self.init_states[e] = saved[e]
+        _ffi.check(self._lib, self._lib.dtsim_set_spawn_pool(self._h, pool, n_pool))
+        self._pool = pool
+        return pool
+
+    # ------------------------------------------------------------------- step --
+    def step(self, actions, n_steps: int = 1):
+        """actions: [n_steps, N, 2] or [N, 2] (float32, or float64 with actions_f64);
+        numpy array (host) or an object with __cuda_array_interface__ (device)."""
+        if hasattr(actions, "__cuda_array_interface__"):
+            ptr = actions.__cuda_array_interface__["data"][0]
+            _ffi.check(self._lib, self._lib.dtsim_step(self._h, C.c_void_p(ptr), int(n_steps), 1))
+            return
+        dt = np.float64 if self.actions_f64 else np.float32
+        a = np.ascontiguousarray(np.asarray(actions, dtype=dt))
+        if a.size != n_steps * self.num_envs * 2:
+            raise ValueError(f"actions has {a.size} elements, expected {n_steps}*{self.num_envs}*2")
+        _ffi.check(self._lib, self._lib.dtsim_step(self._h, a.ctypes.data_as(C.c_void_p), int(n_steps), 0))
+
+    def render(self):
+        _ffi.check(self._lib, self._lib.dtsim_render(self._h))
+
+    def frames_device(self) -> DeviceArray:
+        ptr = self._lib.dtsim_frames_devptr(self._h)
+        return DeviceArray(ptr, (self.num_envs, self.camera_height, self.camera_width, 3), "|u1", self)
+
+    def bind_frames(self, devptr: Optional[int]):
+        _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
+
+    def frames_host(self) -> np.ndarray:
+        """Synchronous copy of the frame batch to the host (tests / N=1 facade)."""
+        import torch
+        self.sync()
+        t = torch.as_tensor(self.frames_device(), device=f"cuda:{self.device_index}")
+        return t.cpu().numpy()
+
+    @property
+    def device_index(self) -> int:
+        return self._device
+
+    # ----------------------------------------------------------------- fields --
+    _FIELD_SHAPES = {
+        _ffi.FIELD_POS: ("f8", (3,)), _ffi.FIELD_ANGLE: ("f8", ()), _ffi.FIELD_REWARD: ("f8", ()),
+        _ffi.FIELD_DONE: ("u1", ()), _ffi.FIELD_DONE_CODE: ("u1", ()), _ffi.FIELD_STEP_COUNT: ("i4", ()),
+        _ffi.FIELD_TILE: ("i4", (2,)), _ffi.FIELD_LANE: ("f8", (4,)), _ffi.FIELD_IN_LANE: ("u1", ()),
+        _ffi.FIELD_PROX: ("f8", ()), _ffi.FIELD_SPEED: ("f8", ()), _ffi.FIELD_TIMESTAMP: ("f8", ()),
+        _ffi.FIELD_WHEELS: ("f8", (2,)), _ffi.FIELD_MAP_ID: ("i4", ()),
+        _ffi.FIELD_OBJ_CENTER: ("f8", (_ffi.MAX_DYNAMIC, 2)), _ffi.FIELD_OBJ_ACTIVE: ("u1", (_ffi.MAX_DYNAMIC,)),
+        _ffi.FIELD_OBJ_YROT: ("f8", (_ffi.MAX_DYNAMIC,)), _ffi.FIELD_OBJ_PARAMS: ("f8", (_ffi.MAX_DYNAMIC, 3)),
+        _ffi.FIELD_OBJ_VISIBLE: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_EPISODE: ("i4", ()),
+    }
+
+    def read(self, field: int) -> np.ndarray:
+        if field == _ffi.FIELD_STATE_BLOB:
+            out = np.empty(self._lib.dtsim_state_bytes(self._h), np.uint8)
+        else:
+            dt, shp = self._FIELD_SHAPES[field]
+            out = np.empty((self.num_envs,) + shp, dtype=dt)
+        _ffi.check(self._lib, self._lib.dtsim_read(self._h, field, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def write(self, field: int, arr: np.ndarray):
+        if field == _ffi.FIELD_STATE_BLOB:
+            a = np.ascontiguousarray(arr, np.uint8)
+        else:
+            dt, shp = self._FIELD_SHAPES[field]
+            a = np.ascontiguousarray(np.asarray(arr, dtype=dt).reshape((self.num_envs,) + shp))
+        _ffi.check(self._lib, self._lib.dtsim_write(self._h, field, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def query(self, env_idx, poses, safety_factor: float = 1.0) -> np.ndarray:
+        """Reference geometry queries at arbitrary poses [n,3] = (x, z, angle), evaluated
+        on the device; returns a structured array mirroring dtsim_probe."""
+        env_idx = np.ascontiguousarray(env_idx, np.int32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 3)
+        n = poses.shape[0]
+        out = np.zeros(n, dtype=_ffi.probe_dtype())
+        if n:
+            _ffi.check(self._lib, self._lib.dtsim_query(
+                self._h, n, env_idx.ctypes.data_as(C.POINTER(C.c_int32)), poses.ctypes.data_as(C.POINTER(C.c_double)),
+                float(safety_factor), C.cast(out.ctypes.data, C.POINTER(_ffi.Probe))))
+        return out
+
+    def sync(self):
+        _ffi.check(self._lib, self._lib.dtsim_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.dtsim_stream(self._h) or 0)
+
+    def profile_read(self, kernel: int):
+        n, ms = C.c_int(), C.c_double()
+        _ffi.check(self._lib, self._lib.dtsim_profile_read(self._h, kernel, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    @property
+    def state_bytes(self) -> int:
+        return int(self._lib.dtsim_state_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.dtsim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

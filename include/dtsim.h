@@ -1,0 +1,287 @@
+/*
+ * dtsim.h -- C-ABI of libdtsim.so, the MI355X-native batched Duckietown step path.
+ *
+ * The reference (duckietown/gym-duckietown v6.1.34) has no FFI boundary: its hot
+ * path is in-process Python (src/gym_duckietown/simulator.py).  This header is the
+ * boundary a maintainer would bind *below* the reference's gym.Env surface; every
+ * entry point cites the reference code it replaces (paths under /root/reference/).
+ * The ctypes binding is gym-duckietown_amd/dtsim/_ffi.py; INTEGRATION.md shows the
+ * stub the reference's simulator.py would add.
+ *
+ * Conventions
+ *   - plain C types, caller-owned inputs (the library copies), no torch types;
+ *   - every function returns 0 (DTSIM_OK) or a negative error code and never throws;
+ *     dtsim_last_error() returns a thread-local message for the last failure;
+ *   - one handle per device; a handle is not thread-safe, distinct handles are
+ *     independent; all work is stream-ordered on the handle's HIP stream;
+ *   - frames / SoA fields live in device memory owned by the library (or bound by
+ *     the caller with dtsim_bind_frames) and are exposed as raw device pointers.
+ *   - world frame = the reference's "weird" frame (simulator.py:1629-1652):
+ *     x right (tile column i), y up, z = tile row j; heading theta gives
+ *     dir = (cos t, 0, -sin t) (simulator.py:2056-2073).
+ */
+#ifndef DTSIM_H
+#define DTSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTSIM_ABI_VERSION 1
+
+/* error codes */
+#define DTSIM_OK 0
+#define DTSIM_E_INVALID (-1)   /* bad argument */
+#define DTSIM_E_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define DTSIM_E_NOGPU (-3)     /* no HIP device: the library has no CPU fallback */
+#define DTSIM_E_STATE (-4)     /* call sequence error (e.g. step before set_maps/reset) */
+#define DTSIM_E_LIMIT (-5)     /* a compile-time limit below was exceeded */
+
+/* limits (device tables are LDS-staged) */
+#define DTSIM_MAX_MAPS 8
+#define DTSIM_MAX_TILES 1024        /* grid_w * grid_h per map */
+#define DTSIM_MAX_CURVES 1024       /* per map */
+#define DTSIM_MAX_STATIC 32         /* collidable static objects per map */
+#define DTSIM_MAX_DYNAMIC 8         /* DuckieObj per map */
+#define DTSIM_MAX_OBJECTS 40        /* renderable objects per map */
+#define DTSIM_MAX_DELAY 8           /* dynamics command delay, in steps */
+#define DTSIM_MAX_TEXTURES 32
+#define DTSIM_MAX_MESHES 16
+
+/* dtsim_config.flags */
+#define DTSIM_F_RENDER 1u        /* allocate the [N,H,W,3] frame buffer */
+#define DTSIM_F_DISTORTION 2u    /* fisheye: needs dtsim_set_distortion_lut (distortion.py:85-125) */
+#define DTSIM_F_DOMAIN_RAND 4u   /* per-env camera/light/colour parameters are honoured (simulator.py:551-614) */
+#define DTSIM_F_AUTO_RESET 8u    /* envs whose done flag is set restart from the spawn pool at the next step */
+#define DTSIM_F_ACTIONS_F64 16u  /* dtsim_step actions are double[...] instead of float[...] */
+#define DTSIM_F_PROFILE 32u      /* bracket every kernel launch with HIP events (dtsim_profile_read) */
+
+/* dtsim_config.action_mode */
+#define DTSIM_ACTION_WHEELS 0    /* Simulator.step: [left, right] duty, clipped to [-1,1] (simulator.py:1669-1672) */
+#define DTSIM_ACTION_VEL_STEER 1 /* DuckietownEnv.step: (vel, steering) -> duty (envs/duckietown_env.py:36-61) */
+
+/* done codes (simulator.py:1685-1705 DoneRewardInfo.done_code) */
+#define DTSIM_DONE_IN_PROGRESS 0
+#define DTSIM_DONE_INVALID_POSE 1
+#define DTSIM_DONE_MAX_STEPS 2
+
+/* tile kinds (simulator.py:840-848 + the non-drivable kinds of the map format) */
+enum {
+  DTSIM_TILE_EMPTY = 0, /* "empty": no tile (simulator.py:820) */
+  DTSIM_TILE_STRAIGHT = 1,
+  DTSIM_TILE_CURVE_LEFT = 2,
+  DTSIM_TILE_CURVE_RIGHT = 3,
+  DTSIM_TILE_3WAY_LEFT = 4,
+  DTSIM_TILE_3WAY_RIGHT = 5,
+  DTSIM_TILE_4WAY = 6,
+  DTSIM_TILE_ASPHALT = 7,
+  DTSIM_TILE_GRASS = 8,
+  DTSIM_TILE_FLOOR = 9,
+  DTSIM_TILE_OTHER = 10
+};
+
+typedef struct dtsim dtsim_t;
+
+/* Constructor arguments of Simulator / DuckietownEnv that reach the hot path
+ * (simulator.py:207-232, envs/duckietown_env.py:15-34). */
+typedef struct dtsim_config {
+  uint32_t struct_size;  /* sizeof(dtsim_config), ABI check */
+  uint32_t flags;        /* DTSIM_F_* */
+  int32_t num_envs;
+  int32_t device;        /* HIP device ordinal */
+  int32_t cam_width;     /* camera_width  (default 640) */
+  int32_t cam_height;    /* camera_height (default 480) */
+  int32_t frame_skip;    /* simulator.py:1673 */
+  int32_t max_steps;     /* simulator.py:1694 */
+  int32_t delay_steps;   /* duckietown_world ApplyDelay(0.15 s) in steps; 5 at 30 Hz (PARITY UNPINNED) */
+  int32_t action_mode;   /* DTSIM_ACTION_* */
+  double delta_time;     /* 1 / frame_rate (simulator.py:300) */
+  double robot_speed;    /* constant used by the reward (simulator.py:1702) */
+  double gain, trim, radius, k, limit; /* DuckietownEnv kinematics (envs/duckietown_env.py:15) */
+  void* stream;          /* hipStream_t to launch on; NULL = library creates one */
+} dtsim_config;
+
+/* One world object as interpreted by Simulator.interpret_object (simulator.py:933-1038)
+ * and WorldObj.__init__ / DuckieObj.__init__ (objects.py:33-66, 339-365).  OBB corners
+ * and SAT axes are computed on the host exactly as the reference does
+ * (generate_corners collision.py:64-79, generate_norm collision.py:99-106). */
+typedef struct dtsim_object {
+  int32_t mesh_id;       /* index into dtsim_set_assets meshes, -1 = not rendered */
+  int32_t dynamic;       /* 0 static WorldObj, 1 DuckieObj pedestrian */
+  int32_t collidable;    /* static && kind != trafficlight (simulator.py:1027-1030) */
+  int32_t optional;
+  double pos[3];
+  double angle;          /* radians */
+  double scale;
+  double corners[8];     /* [4][2] (x,z) */
+  double norm[4];        /* [2][2] */
+  double safety_radius;
+  double spawn_clear;    /* max(max_coords)*0.5*scale + MIN_SPAWN_OBJ_DIST (simulator.py:1467) */
+  /* DuckieObj parameters (objects.py:339-365); ignored for static objects */
+  double walk_distance, vel, wait_time, wiggle;
+} dtsim_object;
+
+typedef struct dtsim_map {
+  int32_t grid_w, grid_h;          /* simulator.py:801-802 */
+  double tile_size;                /* road_tile_size */
+  const uint8_t* tile_kind;        /* [grid_h*grid_w] DTSIM_TILE_*, index j*grid_w+i */
+  const uint8_t* tile_angle;       /* [..] 0..3, index into [S,E,N,W] (simulator.py:823-830) */
+  const int16_t* tile_tex;         /* [..] texture id (dtsim_set_assets) or -1 */
+  const int16_t* tile_curve_off;   /* [..] first curve of the tile, -1 if not drivable */
+  const uint8_t* tile_curve_cnt;   /* [..] 2 / 6 / 12 (simulator.py:1151-1335) */
+  int32_t n_curves;
+  const double* curves;            /* [n_curves][4][2] Bezier control points (x,z) */
+  const double* curve_heads;       /* [n_curves][2] chord P3-P0 divided by the tile's Frobenius norm,
+                                      computed on the host with the reference's numpy expression
+                                      (simulator.py:1355-1356) */
+  int32_t n_objects;
+  const dtsim_object* objects;     /* [n_objects] in map order */
+} dtsim_map;
+
+/* RGBA8 texture, row 0 = v=0 (bottom row of the image, the GL/pyglet origin). */
+typedef struct dtsim_texture {
+  int32_t width, height;           /* powers of two */
+  const uint8_t* rgba;             /* [height][width][4] */
+} dtsim_texture;
+
+/* Triangle soup of one mesh after ObjMesh's recentring (objmesh.py:181-232). */
+typedef struct dtsim_mesh {
+  int32_t n_tris;
+  const float* verts;              /* [n_tris][3][3] */
+  const float* normals;            /* [n_tris][3][3] */
+  const float* colors;             /* [n_tris][3][3] per-vertex Kd */
+} dtsim_mesh;
+
+/* Everything Simulator.reset() decides for one env (simulator.py:528-763).  Drawn on
+ * the host in the reference's RNG order (dtsim/reset.py) -- or by the oracle in parity
+ * tests -- and uploaded. */
+typedef struct dtsim_init_state {
+  double pos[3];            /* cur_pos  simulator.py:740 */
+  double angle;             /* cur_angle simulator.py:741 */
+  int32_t map_id;
+  int32_t dynamics_trim_on; /* dynamics_rand: get_DB18_uncalibrated(trim) simulator.py:746-748 */
+  double dynamics_trim;
+  double wheel_dist;        /* simulator.py:597 */
+  double cam_height;        /* simulator.py:602,612 */
+  double cam_angle_deg;     /* simulator.py:605,613 */
+  double cam_fov_y_deg;     /* simulator.py:608,614 */
+  double camera_noise[3];   /* simulator.py:1768-1769 (applied only with DTSIM_F_DOMAIN_RAND) */
+  double horizon_color[3];  /* simulator.py:551-562 */
+  double ground_color[3];   /* simulator.py:594 */
+  double light_pos[4];      /* simulator.py:565-570, w=0 directional / w=1 positional */
+  double light_ambient[3];  /* simulator.py:573-574 */
+  double light_diffuse[3];  /* simulator.py:575-576 */
+} dtsim_init_state;
+
+/* Result of evaluating the reference's geometry queries at an arbitrary pose. */
+typedef struct dtsim_probe {
+  int32_t tile_i, tile_j;   /* get_grid_coords simulator.py:1134 */
+  int32_t curve_idx;        /* argmax curve of closest_curve_point simulator.py:1362, -1 */
+  uint8_t drivable;         /* _drivable_pos(pos) simulator.py:1411 */
+  uint8_t collision;        /* _collision(get_agent_corners(pos, angle)) simulator.py:1473 */
+  uint8_t valid;            /* _valid_pose(pos, angle, safety_factor) simulator.py:1494 */
+  uint8_t in_lane;          /* get_lane_pos2 did not raise NotInLane */
+  uint8_t inconvenient;     /* _inconvenient_spawn(pos) simulator.py:1461 */
+  uint8_t pad[3];
+  double t;                 /* bezier_closest graphics.py:316 */
+  double point[2], tangent[2]; /* closest_curve_point (x,z) */
+  double dist, dot_dir, angle_deg, angle_rad; /* LanePosition simulator.py:1371-1409 */
+  double prox;              /* proximity_penalty2 simulator.py:1430 */
+  double reward;            /* compute_reward(pos, angle, robot_speed) simulator.py:1654 */
+} dtsim_probe;
+
+/* SoA fields for dtsim_read / dtsim_write / dtsim_field_devptr. */
+enum {
+  DTSIM_FIELD_POS = 0,        /* double [N][3]  cur_pos */
+  DTSIM_FIELD_ANGLE = 1,      /* double [N]     cur_angle */
+  DTSIM_FIELD_REWARD = 2,     /* double [N] */
+  DTSIM_FIELD_DONE = 3,       /* uint8  [N] */
+  DTSIM_FIELD_DONE_CODE = 4,  /* uint8  [N] */
+  DTSIM_FIELD_STEP_COUNT = 5, /* int32  [N] */
+  DTSIM_FIELD_TILE = 6,       /* int32  [N][2] get_grid_coords(cur_pos) */
+  DTSIM_FIELD_LANE = 7,       /* double [N][4] dist, dot_dir, angle_deg, angle_rad (0 if not in lane) */
+  DTSIM_FIELD_IN_LANE = 8,    /* uint8  [N] */
+  DTSIM_FIELD_PROX = 9,       /* double [N] proximity_penalty2 */
+  DTSIM_FIELD_SPEED = 10,     /* double [N] simulator.py:1568 */
+  DTSIM_FIELD_TIMESTAMP = 11, /* double [N] */
+  DTSIM_FIELD_WHEELS = 12,    /* double [N][2] last [left,right] duty passed to the dynamics */
+  DTSIM_FIELD_MAP_ID = 13,    /* int32  [N] */
+  DTSIM_FIELD_OBJ_CENTER = 14,/* double [N][DTSIM_MAX_DYNAMIC][2] DuckieObj.center (x,z) */
+  DTSIM_FIELD_OBJ_ACTIVE = 15,/* uint8  [N][DTSIM_MAX_DYNAMIC] pedestrian_active */
+  DTSIM_FIELD_OBJ_YROT = 16,  /* double [N][DTSIM_MAX_DYNAMIC] y_rot in degrees */
+  DTSIM_FIELD_OBJ_PARAMS = 17,/* double [N][DTSIM_MAX_DYNAMIC][3] vel, wait_time, wiggle (write = DR override) */
+  DTSIM_FIELD_OBJ_VISIBLE = 18,/* uint8 [N][DTSIM_MAX_OBJECTS] obj.visible (simulator.py:653-656) */
+  DTSIM_FIELD_EPISODE = 19,   /* int32  [N] episodes started (auto-reset counter) */
+  DTSIM_FIELD_STATE_BLOB = 20,/* opaque: full SoA state, dtsim_state_bytes() bytes (checkpoint) */
+  DTSIM_FIELD__COUNT = 21
+};
+
+/* kernels for dtsim_profile_read */
+enum { DTSIM_KERNEL_STEP = 0, DTSIM_KERNEL_RENDER = 1, DTSIM_KERNEL_RESET = 2, DTSIM_KERNEL_QUERY = 3, DTSIM_KERNEL__COUNT = 4 };
+
+int dtsim_abi_version(void);
+const char* dtsim_last_error(void);
+/* Number of visible HIP devices, or a negative error code. */
+int dtsim_device_count(void);
+
+/* Simulator.__init__ (simulator.py:207-384), minus GL. */
+int dtsim_create(const dtsim_config* cfg, dtsim_t** out);
+void dtsim_destroy(dtsim_t* h);
+
+/* Textures (graphics.py:69-169 load_texture) and meshes (objmesh.py:62-293). */
+int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures,
+                     const dtsim_mesh* meshes, int n_meshes);
+/* Simulator._interpret_map output (simulator.py:788-1038), host-prepared. */
+int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps);
+/* Distortion.rmapx/rmapy (distortion.py:100-111): [cam_height][cam_width] float each.
+ * The per-frame cv2.remap(INTER_NEAREST) (distortion.py:118) is folded into the raster. */
+int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy);
+
+/* Simulator.reset() for the envs with mask[e] != 0 (mask NULL = all): state taken from
+ * states[e] (array of num_envs entries). */
+int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states);
+/* Pool of spawn states used by DTSIM_F_AUTO_RESET: env e starts episode k from
+ * pool[(e + k * num_envs) % n_pool]. */
+int dtsim_set_spawn_pool(dtsim_t* h, const dtsim_init_state* pool, int n_pool);
+
+/* n_steps x { [DuckietownEnv.step ->] Simulator.step } without the render
+ * (simulator.py:1669-1705; update_physics :1551; _update_pos :2076; _compute_done_reward :1685).
+ * actions: [n_steps][num_envs][2], float (or double with DTSIM_F_ACTIONS_F64), host or
+ * device pointer (actions_on_device).  Asynchronous. */
+int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_device);
+
+/* Simulator.render_obs (simulator.py:1953-1972) = _render_img (:1707-1951) + distort:
+ * writes [num_envs][cam_height][cam_width][3] uint8, row 0 = image top.  Asynchronous. */
+int dtsim_render(dtsim_t* h);
+void* dtsim_frames_devptr(dtsim_t* h);
+size_t dtsim_frames_bytes(const dtsim_t* h);
+/* Render into caller-owned device memory instead (e.g. a torch tensor that is the
+ * send buffer of the RCCL all-gather). NULL restores the internal buffer. */
+int dtsim_bind_frames(dtsim_t* h, void* devptr);
+
+/* Geometry queries of the reference at arbitrary poses, evaluated on the device against
+ * env env_idx[q]'s world (its map, dynamic objects and visibility): _valid_pose,
+ * _collision, _drivable_pos, get_lane_pos2, closest_curve_point, proximity_penalty2,
+ * compute_reward, _inconvenient_spawn.  poses: [n][3] = x, z, angle.  Synchronous. */
+int dtsim_query(dtsim_t* h, int n, const int32_t* env_idx, const double* poses,
+                double safety_factor, dtsim_probe* out);
+
+int dtsim_read(dtsim_t* h, int field, void* dst, size_t bytes);   /* synchronous D2H */
+int dtsim_write(dtsim_t* h, int field, const void* src, size_t bytes);
+void* dtsim_field_devptr(dtsim_t* h, int field);
+size_t dtsim_field_bytes(const dtsim_t* h, int field);
+size_t dtsim_state_bytes(const dtsim_t* h);
+
+int dtsim_sync(dtsim_t* h);
+void* dtsim_stream(dtsim_t* h);   /* the hipStream_t launches go to */
+/* Sum of HIP-event durations of the launches of `kernel` since the last call
+ * (requires DTSIM_F_PROFILE).  Synchronises the stream. */
+int dtsim_profile_read(dtsim_t* h, int kernel, int* n_launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTSIM_H */

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (oracle is the checker, never the product)."""
+import copy
+
+import numpy as np
+
+from dtsim import _ffi, assets
+from oracle import sim as osim
+
+EXT = assets.mesh_extents(("duckie",))
+
+
+def make_oracle(map_name, **kw):
+    return osim.OracleSim(assets.get_map(map_name), EXT, **kw)
+
+
+def init_state_from_oracle(o, map_id=0):
+    """dtsim_init_state equal to what the oracle's reset() decided (parity mode)."""
+    st = _ffi.InitState()
+    st.pos[:] = [float(v) for v in o.cur_pos]
+    st.angle = float(o.cur_angle)
+    st.map_id = map_id
+    st.dynamics_trim_on = 1 if o.dynamics_rand else 0
+    st.dynamics_trim = float(0 + o.randomization_settings["trim"][0])
+    st.wheel_dist = float(o.wheel_dist)
+    st.cam_height = float(np.asarray(o.cam_height).reshape(-1)[0])
+    st.cam_angle_deg = float(np.asarray(o.cam_angle[0]).reshape(-1)[0])
+    st.cam_fov_y_deg = float(np.asarray(o.cam_fov_y).reshape(-1)[0])
+    st.camera_noise[:] = [float(v) for v in o.randomization_settings["camera_noise"]]
+    st.horizon_color[:] = [float(v) for v in o.horizon_color]
+    st.ground_color[:] = [float(v) for v in o.ground_color]
+    lp = list(o.light_pos) + [0.0] * (4 - len(o.light_pos))
+    st.light_pos[:] = [float(v) for v in lp]
+    st.light_ambient[:] = [float(v) for v in o.light_ambient[:3]]
+    st.light_diffuse[:] = [float(v) for v in o.light_diffuse[:3]]
+    return st
+
+
+def random_poses(rng, mt_w, mt_h, ts, n, centers=None):
+    pos = np.stack([rng.uniform(-0.2, mt_w * ts + 0.2, n), rng.uniform(-0.2, mt_h * ts + 0.2, n),
+                    rng.uniform(-4, 7, n)], axis=1)
+    if centers is not None and len(centers):
+        k = n // 3
+        c = centers[rng.integers(0, len(centers), k)]
+        pos[:k, 0] = c[:, 0] + rng.uniform(-0.3, 0.3, k)
+        pos[:k, 1] = c[:, 1] + rng.uniform(-0.3, 0.3, k)
+    return pos
