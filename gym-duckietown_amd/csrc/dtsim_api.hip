@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,6 +85,8 @@ struct dtsim {
   std::vector<MeshDev> h_meshes;
   RenderMapDev* d_rmaps = nullptr;
   uint32_t* d_rtiles = nullptr;
+  TileLds* d_tilerecs = nullptr;
+  int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
   void* d_envcam = nullptr;
   ProfSlot prof[DTSIM_KERNEL__COUNT];
@@ -236,7 +239,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -316,6 +319,8 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   memset(dyn.data(), 0, dyn.size() * sizeof(DynInit));
   std::vector<RenderMapDev> rmaps(n_maps);
   std::vector<uint32_t> rtiles;
+  std::vector<TileLds> trecs;
+  int tex_w = 0, tex_h = 0;
   std::vector<ObjInstDev> robjs;
   MapSet M{};
   M.n_maps = n_maps;
@@ -379,6 +384,24 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
       const int tex = mp.tile_tex[t] < 0 ? 0xFF : mp.tile_tex[t];
       rtiles.push_back((uint32_t)tex | ((uint32_t)(mp.tile_angle[t] & 3) << 8) | ((present ? 1u : 0u) << 15) |
                        ((mp.tile_tex[t] >= 0 ? 1u : 0u) << 14));
+      TileLds tr{};
+      tr.flags = present ? 1u : 0u;
+      if (present && mp.tile_tex[t] >= 0 && mp.tile_tex[t] < (int)h->h_tex.size()) {
+        const TexDev& td = h->h_tex[mp.tile_tex[t]];
+        if (tex_w == 0) { tex_w = td.w; tex_h = td.h; }
+        if (td.w != tex_w || td.h != tex_h)
+          return fail(DTSIM_E_LIMIT, "map %d tile %d: all tile textures must share one size (%dx%d vs %dx%d)", mi, t, td.w, td.h, tex_w, tex_h);
+        const int ang = mp.tile_angle[t] & 3;
+        const float TW = (float)td.w, TH = (float)td.h;
+        tr.tex_off = (uint32_t)td.off;
+        tr.flags |= 2u;
+        // u = {1-fx, fz, fx, 1-fz}[ang], v = {fz, fx, 1-fz, 1-fx}[ang]; x = u*TW - 0.5, y = v*TH - 0.5
+        const bool swp = (ang & 1) != 0, flip_u = (ang == 0 || ang == 3), flip_v = (ang == 2 || ang == 3);
+        const float mu = flip_u ? -TW : TW, mv = flip_v ? -TH : TH;
+        tr.mxx = swp ? 0.f : mu; tr.mxz = swp ? mu : 0.f; tr.ox = flip_u ? TW - 0.5f : -0.5f;
+        tr.myx = swp ? mv : 0.f; tr.myz = swp ? 0.f : mv; tr.oy = flip_v ? TH - 0.5f : -0.5f;
+      }
+      trecs.push_back(tr);
     }
     for (int o = 0; o < mp.n_objects; ++o) {
       const dtsim_object& ob_ = mp.objects[o];
@@ -413,9 +436,16 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   M.total_words = (int32_t)blobs.size();
   if ((size_t)M.total_words * 8 > 60000)
     return fail(DTSIM_E_LIMIT, "map tables %zu B exceed the 60 KB LDS staging budget", (size_t)M.total_words * 8);
-  void* olds[] = {h->d_blobs, h->d_dyn, h->d_rmaps, h->d_rtiles, h->d_robjs};
+  if (trecs.size() > DTSIM_LDS_TILES)
+    return fail(DTSIM_E_LIMIT, "%zu tiles over all maps exceed the %d LDS raster records", trecs.size(), DTSIM_LDS_TILES);
+  void* olds[] = {h->d_blobs, h->d_dyn, h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_tilerecs};
   for (void* p : olds) if (p) (void)hipFree(p);
   h->d_blobs = nullptr; h->d_dyn = nullptr; h->d_rmaps = nullptr; h->d_rtiles = nullptr; h->d_robjs = nullptr;
+  h->d_tilerecs = nullptr;
+  HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
+  if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));
+  h->n_tilerecs = (int)trecs.size();
+  h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
   HIPCHK(hipMalloc(&h->d_blobs, blobs.size() * 8));
   HIPCHK(hipMemcpy(h->d_blobs, blobs.data(), blobs.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->d_dyn, dyn.size() * sizeof(DynInit)));
@@ -549,9 +579,11 @@ int dtsim_render(dtsim_t* h) {
   R.distortion = (h->cfg.flags & DTSIM_F_DISTORTION) ? 1 : 0;
   R.domain_rand = (h->cfg.flags & DTSIM_F_DOMAIN_RAND) ? 1 : 0;
   R.n_maps = h->M.n_maps;
+  { const char* a = getenv("DTSIM_RASTER_NO_MSAA"); R.no_msaa = (a && a[0] == '1') ? 1 : 0; }
   R.frames = h->frames; R.lut = h->d_lut; R.texels = h->d_texels; R.tex = h->d_tex;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
+  R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
     dt_launch_render(h->stream, h->A, R);

@@ -120,9 +120,19 @@ struct ObjInstDev {         // static render instance (dynamic ones are patched 
   int32_t mesh_id, dyn_slot, pad;
 };
 
+// LDS-staged raster tile record: texel base of the (padded) texture, flags (bit0 present,
+// bit1 textured), and the affine map tile-fraction (fx, fz) -> texel coordinates
+// x = mxx*fx + mxz*fz + ox, y = myx*fx + myz*fz + oy encoding glRotatef(angle*90+180)
+// about y, uv = (pu, 1-pv) (simulator.py:394-401,1872-1873) and the GL_LINEAR half-texel shift.
+struct alignas(16) TileLds { uint32_t tex_off, flags; float mxx, mxz, ox, myx, myz, oy; };
+static_assert(sizeof(TileLds) == 32, "TileLds is 32 bytes");
+#define DTSIM_LDS_TILES 1024   // raster tile records of all maps together (32 KB of LDS)
+
 struct RenderParams {
   int32_t N, W, H, distortion;
-  int32_t domain_rand, n_maps, pad0, pad1;
+  int32_t domain_rand, n_maps, n_tile_recs, no_msaa;   // no_msaa: profiling ablation only (DTSIM_RASTER_NO_MSAA=1)
+  int32_t tex_w, tex_h;           // all tile textures share one (power-of-two) size
+  const TileLds* tile_recs;       // [n_tile_recs], maps concatenated (RenderMapDev.tile_off)
   uint8_t* frames;
   const float* lut;             // [H*W][4]: source-pixel NDC x, y (of the rectilinear pixel), valid flag, pad
   const uint32_t* texels;       // RGBA8 pool

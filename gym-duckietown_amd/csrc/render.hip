@@ -2,45 +2,51 @@
 //
 // Replaces simulator.py:1707-1951 (_render_img: fixed-function GL into a 4xMSAA FBO,
 // glReadPixels, flip) and distortion.py:85-125 (cv2.remap INTER_NEAREST through the
-// inverted rectify map).  Render spec: SURVEY.md Appendix B / DESIGN.md "Render spec".
+// inverted rectify map).  Render spec: SURVEY.md Appendix B / DESIGN.md "Render spec";
+// the CPU statement of the same spec is oracle/raster.py.
 //
 // Structure
-//   k_cam_setup : one thread per env -> EnvCam (camera centre, yaw/pitch sin/cos, frustum
-//                 tangents, colours, light, ground-corner shading), 128 B per env.
-//   k_raster    : workgroup = 256 threads = one 1024-pixel strip of the frame, 4 adjacent
-//                 pixels per thread.  The strip's per-pixel LUT entries (NDC of the
-//                 rectilinear source pixel of each output pixel: the fisheye remap is folded
-//                 into the ray set-up, no second pass) stay in REGISTERS while the workgroup
-//                 loops over ENVS_PER_BLOCK envs; per env only the 128-B EnvCam changes
-//                 (wave-uniform scalar loads).
-//                 Fast path: one ray per pixel (pixel centre).  Pixels whose 4 MSAA samples
-//                 may see different primitives (horizon, map border, tile seams) are pushed
-//                 to an LDS queue and re-shaded with the exact 4-sample resolve by whichever
-//                 lanes are free (stream compaction instead of divergent lanes).
-//                 Output: the strip is assembled in LDS and written with one 12-byte
-//                 (dwordx3) fully-coalesced store per lane.
+//   k_cam_setup : one thread per env -> EnvCam (camera centre, yaw, colours, ground-corner
+//                 lighting; with DR also pitch / frustum / light), 128 B per env.
+//   k_raster<DR>: workgroup = 4 independent wavefronts; a wavefront owns 256 consecutive
+//                 pixels of the frame (4 adjacent pixels per lane) and loops over
+//                 ENVS_PER_BLOCK envs.  Everything that does not depend on the env -- the
+//                 LUT entry of each pixel (NDC of the rectilinear source pixel: the fisheye
+//                 remap is folded into the ray set-up, there is no second pass) and, for the
+//                 shared camera (DR=false), the whole ray / ground-plane intersection in the
+//                 yaw-local frame, the light term and the MSAA edge margin -- is computed
+//                 once and kept in REGISTERS across the env loop; per env only the 128-B
+//                 EnvCam changes (wave-uniform scalar loads) and a pixel costs one 2-D
+//                 rotation + tile lookup (LDS) + one bilinear fetch (two 8-byte loads from
+//                 the L2-resident padded texture) + lighting.
+//                 MSAA: pixels whose 4 samples may see different primitives (horizon, map
+//                 border, tile seams; conservative test) are compacted into a per-wavefront
+//                 LDS queue and re-shaded with the exact 4-sample resolve by whichever lanes
+//                 are free -- no workgroup barrier anywhere in the env loop.
+//                 Output: 12 B (4 px) per lane, contiguous across the wavefront => every
+//                 store instruction writes 768 contiguous bytes.
 //
 // Roofline: HBM-write bound by construction -- algorithmic bytes per env-step = W*H*3
 // (921 600 B at 640x480), written exactly once; LUT / textures / tables are shared by all
-// envs and stay in registers / L2.  float32 arithmetic (dtype "f32" shading, "u8" output).
+// envs and stay in registers / LDS / L2.  float32 shading, uint8 output.
 #include "dtsim_dev.h"
 
-#define RB 256            // threads per workgroup
+#define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT 4             // pixels per thread
+#define WAVE_PIX (64 * PPT)
 #define STRIP (RB * PPT)  // pixels per workgroup
 #define ENVS_PER_BLOCK 16
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
 #define CLS_TILE 2
-#define CLS_BORDER 3      // outside the source image: cv2.remap BORDER_CONSTANT 0
 
 #define NEAR_Z 0.04f
 #define FAR_Z 100.0f
 #define GROUND_Y (-0.008f)   // ground quad: y=-0.8 scaled by 0.01 (simulator.py:510-526,1810)
 #define GROUND_HALF 50.0f
 
-struct EnvCam {          // 32 floats = 128 B, written by k_cam_setup
+struct alignas(16) EnvCam {          // 32 floats = 128 B, written by k_cam_setup
   float Cx, Cy, Cz;      // camera centre (world)
   float sa, ca;          // yaw
   float sth, cth;        // pitch (cam_angle[0])
@@ -58,6 +64,20 @@ static_assert(sizeof(EnvCam) == 128, "EnvCam is 128 bytes");
 
 namespace {
 
+// Camera intrinsics / light shared by all envs when DTSIM_F_DOMAIN_RAND is off
+// (simulator.py:119-131 CAMERA_ANGLE / CAMERA_FOV_Y / CAMERA_FLOOR_DIST, :570-576).
+struct CamShared { float sth, cth, tx, ty, Cy, base, dif; float L[4]; };
+
+__device__ inline CamShared default_cam(float aspect) {
+  CamShared s;
+  const float th = 19.15f * 0.017453292519943295f;
+  s.sth = sinf(th); s.cth = cosf(th);
+  s.ty = tanf(0.5f * 75.0f * 0.017453292519943295f); s.tx = s.ty * aspect;
+  s.Cy = 0.108f; s.base = 0.3f + 0.25f; s.dif = 0.35f;
+  s.L[0] = 0.f; s.L[1] = 3.f; s.L[2] = 0.f; s.L[3] = 1.f;
+  return s;
+}
+
 __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
@@ -66,28 +86,34 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
   const double ang = A.angle[e];
   const double sa = sin(ang), ca = cos(ang);
   double px = A.pos_x[e], py = 0.0, pz = A.pos_z[e];
-  if (domain_rand) {  // simulator.py:1768-1769
+  float base[3], dif[3], L[4];
+  if (domain_rand) {  // per-env camera / light (simulator.py:565-614, 1768-1769)
     px += (double)A.cam[3 * N + e]; py += (double)A.cam[4 * N + e]; pz += (double)A.cam[5 * N + e];
+    py += (double)A.cam[0 * N + e];
+    const float th = A.cam[1 * N + e], fov = A.cam[2 * N + e];
+    for (int k = 0; k < 3; ++k) { base[k] = 0.3f + A.colors[(6 + k) * N + e]; dif[k] = A.colors[(9 + k) * N + e]; }
+    for (int k = 0; k < 4; ++k) L[k] = A.colors[(12 + k) * N + e];
+    c.sth = sinf(th); c.cth = cosf(th);
+    const float tanh_ = tanf(0.5f * fov);
+    c.tx = tanh_ * aspect; c.ty = tanh_;
+    c.Cy = (float)py;
+  } else {
+    const CamShared s = default_cam(aspect);
+    c.sth = s.sth; c.cth = s.cth; c.tx = s.tx; c.ty = s.ty; c.Cy = s.Cy;
+    for (int k = 0; k < 3; ++k) { base[k] = s.base; dif[k] = s.dif; }
+    for (int k = 0; k < 4; ++k) L[k] = s.L[k];
   }
-  py += (double)A.cam[0 * N + e];  // cam_height simulator.py:1780
   // glTranslatef(0,0,CAMERA_FORWARD_DIST) before gluLookAt (simulator.py:1784,1803): the
   // camera centre sits 6.6 cm ahead of the axle along dir = (cos a, 0, -sin a).
   c.Cx = (float)(px + DT_CAMERA_FORWARD_DIST * ca);
-  c.Cy = (float)py;
   c.Cz = (float)(pz - DT_CAMERA_FORWARD_DIST * sa);
   c.sa = (float)sa; c.ca = (float)ca;
-  const float th = A.cam[1 * N + e];
-  c.sth = sinf(th); c.cth = cosf(th);
-  const float tanh_ = tanf(0.5f * A.cam[2 * N + e]);
-  c.tx = tanh_ * aspect; c.ty = tanh_;
   for (int k = 0; k < 3; ++k) {
     c.hor[k] = 255.f * A.colors[(0 + k) * N + e];
     c.gnd[k] = 255.f * A.colors[(3 + k) * N + e];
-    c.base[k] = 0.3f + A.colors[(6 + k) * N + e];   // GL_LIGHT_MODEL_AMBIENT 0.3 (simulator.py:1741)
-    c.dif[k] = A.colors[(9 + k) * N + e];
+    c.base[k] = base[k];     // GL_LIGHT_MODEL_AMBIENT 0.3 (simulator.py:1741) + light ambient
+    c.dif[k] = dif[k];
   }
-  float L[4];
-  for (int k = 0; k < 4; ++k) L[k] = A.colors[(12 + k) * N + e];
   if (L[3] == 0.f) {  // directional: normalise once
     const float inv = rsqrtf(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
     L[0] *= inv; L[1] *= inv; L[2] *= inv;
@@ -113,24 +139,86 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
   out[e] = c;
 }
 
-struct Hit {       // classification of one ray
-  int cls;
-  int ti, tj;      // tile
-  float t;         // ray parameter (= eye-space depth, d_eye.z = -1)
-  float wx, wz;    // world hit on the plane of the primitive
-};
+// ---- per-map constants the raster needs (wave-uniform) -------------------------------
+struct MapU { float its, ts, gwf, ghf; int gw, gh, tile_off; };
 
-struct Ray {
-  float xe, ye, yla, fwd;
-};
+__device__ inline MapU map_u(const RenderMapDev& m) {
+  MapU u;
+  u.its = m.inv_tile_size; u.ts = m.tile_size; u.gw = m.grid_w; u.gh = m.grid_h;
+  u.gwf = (float)m.grid_w; u.ghf = (float)m.grid_h; u.tile_off = m.tile_off;
+  return u;
+}
 
-__device__ inline Ray make_ray(const EnvCam& c, float nx, float ny) {
+struct Ray { float xe, ye, yla, fwd; };
+
+__device__ inline Ray make_ray(float nx, float ny, float tx, float ty, float sth, float cth) {
   Ray r;
-  r.xe = nx * c.tx; r.ye = ny * c.ty;
-  r.yla = r.ye * c.cth - c.sth;      // world-up component of the ray
-  r.fwd = r.ye * c.sth + c.cth;      // component along dir
+  r.xe = nx * tx; r.ye = ny * ty;
+  r.yla = r.ye * cth - sth;      // world-up component of the ray
+  r.fwd = r.ye * sth + cth;      // component along dir
   return r;
 }
+
+// positional / directional light on a surface with eye-space normal (0, cth, sth) at the
+// eye-space point t*(xe, ye, -1): max(0, N.L)   (tiles; simulator.py:565-591)
+__device__ inline float plane_ndl(const float L[4], float sth, float cth, const Ray& r, float t) {
+  float ndl;
+  if (L[3] == 0.f) ndl = cth * L[1] + sth * L[2];
+  else {
+    const float lx = L[0] - t * r.xe, ly = L[1] - t * r.ye, lz = L[2] + t;
+    ndl = (cth * ly + sth * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+  }
+  return fmaxf(ndl, 0.f);
+}
+
+// bilinear GL_LINEAR/GL_REPEAT fetch from the padded texture, times the lit vertex colour I.
+__device__ inline void tile_color(const RenderParams& R, const TileLds& tr, float fx, float fz, const float I[3],
+                                  float out[3]) {
+  if (!(tr.flags & 2u)) {  // untextured tile: white vertex colour
+    out[0] = 255.f * I[0]; out[1] = 255.f * I[1]; out[2] = 255.f * I[2];
+    return;
+  }
+  const float x = fmaf(tr.mxz, fz, fmaf(tr.mxx, fx, tr.ox)), y = fmaf(tr.myz, fz, fmaf(tr.myx, fx, tr.oy));
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float ax = x - x0f, ay = y - y0f;
+  const int x0 = ((int)x0f) & (R.tex_w - 1), y0 = ((int)y0f) & (R.tex_h - 1);
+  const uint32_t* pt = R.texels + tr.tex_off + y0 * (R.tex_w + 1) + x0;
+  uint2 top2, bot2;               // two 8-byte loads: (x0,y0),(x0+1,y0) and the row above
+  __builtin_memcpy(&top2, pt, 8);
+  __builtin_memcpy(&bot2, pt + (R.tex_w + 1), 8);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c00 = (float)((top2.x >> (8 * k)) & 255u), c10 = (float)((top2.y >> (8 * k)) & 255u);
+    const float c01 = (float)((bot2.x >> (8 * k)) & 255u), c11 = (float)((bot2.y >> (8 * k)) & 255u);
+    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
+    out[k] = (top + ay * (bot - top)) * I[k];
+  }
+}
+
+__device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
+  const float a = fminf(fmaxf((wx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+  const float b = fminf(fmaxf((wz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+  const float n0 = c.gndl[0] + a * (c.gndl[1] - c.gndl[0]);
+  const float n1 = c.gndl[2] + a * (c.gndl[3] - c.gndl[2]);
+  return n0 + b * (n1 - n0);
+}
+
+// floor(x) as int in one instruction
+__device__ inline int flr_i32(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// v_cvt_f32_ubyteN: one instruction per texel channel (the compiler does not pick it)
+__device__ inline float ubyte0(uint32_t x) { float r; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ inline float ubyte1(uint32_t x) { float r; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ inline float ubyte2(uint32_t x) { float r; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(x)); return r; }
+
+__device__ inline uint32_t pack_rgb(const float col[3]) {  // glReadPixels float -> unorm8: round(255 c)
+  const uint32_t r = (uint32_t)(fminf(fmaxf(col[0], 0.f), 255.f) + 0.5f);
+  const uint32_t g = (uint32_t)(fminf(fmaxf(col[1], 0.f), 255.f) + 0.5f);
+  const uint32_t b = (uint32_t)(fminf(fmaxf(col[2], 0.f), 255.f) + 0.5f);
+  return r | (g << 8) | (b << 16);
+}
+
+// ---- generic (exact) per-sample path, used for edge pixels ---------------------------
+struct Hit { int cls; int ti, tj; float t, wx, wz; };
 
 __device__ inline void plane_hit(const EnvCam& c, const Ray& r, float h, float& t, float& wx, float& wz) {
   t = h / (-r.yla);
@@ -139,17 +227,17 @@ __device__ inline void plane_hit(const EnvCam& c, const Ray& r, float h, float& 
   wz = c.Cz + rr * c.ca - ff * c.sa;
 }
 
-__device__ inline Hit classify(const EnvCam& c, const RenderMapDev& m, const uint32_t* tiles, const Ray& r) {
+__device__ inline Hit classify(const EnvCam& c, const MapU& m, const TileLds* tiles, const Ray& r) {
   Hit h;
   h.cls = CLS_SKY; h.ti = h.tj = 0; h.t = 0.f; h.wx = h.wz = 0.f;
   if (!(r.yla < 0.f)) return h;
   float t, wx, wz;
   plane_hit(c, r, c.Cy, t, wx, wz);                 // tile plane y = 0
   if (t >= NEAR_Z && t <= FAR_Z) {
-    const float fi = floorf(wx * m.inv_tile_size), fj = floorf(wz * m.inv_tile_size);
-    if (fi >= 0.f && fj >= 0.f && fi < (float)m.grid_w && fj < (float)m.grid_h) {
+    const float fi = floorf(wx * m.its), fj = floorf(wz * m.its);
+    if (fi >= 0.f && fj >= 0.f && fi < m.gwf && fj < m.ghf) {
       const int i = (int)fi, j = (int)fj;
-      if (tiles[m.tile_off + j * m.grid_w + i] & 0x8000u) {
+      if (tiles[m.tile_off + j * m.gw + i].flags & 1u) {
         h.cls = CLS_TILE; h.ti = i; h.tj = j; h.t = t; h.wx = wx; h.wz = wz;
         return h;
       }
@@ -162,136 +250,143 @@ __device__ inline Hit classify(const EnvCam& c, const RenderMapDev& m, const uin
   return h;
 }
 
-// lit vertex colour factor clamp01(base + dif * max(0, N.L)) at eye-space point t*(xe,ye,-1)
-// on a surface with eye-space normal (0, cth, sth)  (tiles; simulator.py:565-591)
-__device__ inline void tile_light(const EnvCam& c, const Ray& r, float t, float I[3]) {
-  float ndl;
-  if (c.L[3] == 0.f) ndl = c.cth * c.L[1] + c.sth * c.L[2];
-  else {
-    const float lx = c.L[0] - t * r.xe, ly = c.L[1] - t * r.ye, lz = c.L[2] + t;
-    ndl = (c.cth * ly + c.sth * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
-  }
-  ndl = fmaxf(ndl, 0.f);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) I[k] = fminf(c.base[k] + c.dif[k] * ndl, 1.f);
-}
-
 // Colour (0..255 floats) of primitive `h` evaluated at the pixel-centre ray `rc`
-// (MSAA: coverage per sample, shading once at the pixel centre).
-__device__ inline void shade(const EnvCam& c, const RenderMapDev& m, const RenderParams& R, const Hit& h,
-                             const Ray& rc, float out[3]) {
+// (MSAA: coverage per sample, shading once per primitive at the pixel centre).
+__device__ inline void shade(const EnvCam& c, const MapU& m, const RenderParams& R, const TileLds* tiles,
+                             const Hit& h, const Ray& rc, float out[3]) {
   if (h.cls == CLS_SKY) { out[0] = c.hor[0]; out[1] = c.hor[1]; out[2] = c.hor[2]; return; }
   if (h.cls == CLS_GROUND) {
     float t = h.t, wx = h.wx, wz = h.wz;
     if (rc.yla < 0.f) plane_hit(c, rc, c.Cy - GROUND_Y, t, wx, wz);
-    const float a = fminf(fmaxf((wx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-    const float b = fminf(fmaxf((wz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-    const float n0 = c.gndl[0] + a * (c.gndl[1] - c.gndl[0]);
-    const float n1 = c.gndl[2] + a * (c.gndl[3] - c.gndl[2]);
-    const float ndl = n0 + b * (n1 - n0);
+    const float ndl = ground_ndl(c, wx, wz);
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = c.gnd[k] * fminf(c.base[k] + c.dif[k] * ndl, 1.f);
     return;
   }
-  // tile (ti,tj): attributes extrapolated to the pixel centre
   float t = h.t, wx = h.wx, wz = h.wz;
   if (rc.yla < 0.f) plane_hit(c, rc, c.Cy, t, wx, wz);
-  const uint32_t tw = R.tiles[m.tile_off + h.tj * m.grid_w + h.ti];
+  const float ndl = plane_ndl(c.L, c.sth, c.cth, rc, t);
   float I[3];
-  tile_light(c, rc, t, I);
-  if (!(tw & 0x4000u)) {  // untextured tile: white vertex colour
-    out[0] = 255.f * I[0]; out[1] = 255.f * I[1]; out[2] = 255.f * I[2];
-    return;
-  }
-  const float fx = wx * m.inv_tile_size - (float)h.ti, fz = wz * m.inv_tile_size - (float)h.tj;
-  // glRotatef(angle*90+180) about y + uv = (pu, 1-pv)  (simulator.py:394-401,1872-1873)
-  const int ang = (tw >> 8) & 3;
-  float u, v;
-  if (ang == 0) { u = 1.f - fx; v = fz; }
-  else if (ang == 1) { u = fz; v = fx; }
-  else if (ang == 2) { u = fx; v = 1.f - fz; }
-  else { u = 1.f - fz; v = 1.f - fx; }
-  const TexDev td = R.tex[tw & 0xFF];
-  // GL_LINEAR, GL_REPEAT; storage padded by one row/column (dtsim_set_assets)
-  const float x = u * (float)td.w - 0.5f, y = v * (float)td.h - 0.5f;
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float ax = x - x0f, ay = y - y0f;
-  const int x0 = ((int)x0f) & (td.w - 1), y0 = ((int)y0f) & (td.h - 1);
-  const uint32_t* p = R.texels + td.off + y0 * (td.w + 1) + x0;
-  const uint32_t t00 = p[0], t10 = p[1], t01 = p[td.w + 1], t11 = p[td.w + 2];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
-    const float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
-    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
-    out[k] = (top + ay * (bot - top)) * I[k];
-  }
-}
-
-__device__ inline uint32_t to_u8(float v) {  // glReadPixels float -> unorm8: round(255 c)
-  return (uint32_t)(fminf(fmaxf(v, 0.f), 255.f) + 0.5f);
-}
-
-// Conservative test: can the 4 MSAA samples of this pixel see a primitive other than
-// the centre's?  (false => the 1-sample fast path is exact.)
-__device__ inline bool maybe_edge(const EnvCam& c, const RenderMapDev& m, const Ray& r, const Hit& h,
-                                  float ex, float ey) {
-  const float dy = ey * fabsf(c.cth);
-  if (h.cls == CLS_SKY) return (r.yla - dy) < 0.f;   // also catches "below horizon but nothing hit"
-  const float rho = dy / (-r.yla);
-  if (rho > 0.25f) return true;
-  float t, wx, wz;
-  plane_hit(c, r, c.Cy, t, wx, wz);
-  const float rr = fabsf(t * r.xe), ff = fabsf(t * r.fwd);
-  const float mrg = 1.5f * (t * (ex + ey) + (rr + ff) * 1.34f * rho);
-  if (t * (1.f + 2.f * rho) > FAR_Z * 0.98f || t * (1.f - 2.f * rho) < NEAR_Z * 1.02f) return true;
-  if (h.cls == CLS_TILE) {
-    const float fx = wx * m.inv_tile_size - (float)h.ti, fz = wz * m.inv_tile_size - (float)h.tj;
-    const float d = fminf(fminf(fx, 1.f - fx), fminf(fz, 1.f - fz)) * m.tile_size;
-    return !(d > mrg);
-  }
-  // ground: every sample's tile-plane hit must stay outside the grid, ground hit inside the quad
-  const float gw = m.grid_w * m.tile_size, gh = m.grid_h * m.tile_size;
-  const bool clear_of_grid = (wx < -mrg) || (wx > gw + mrg) || (wz < -mrg) || (wz > gh + mrg);
-  if (!clear_of_grid) return true;
-  return !(fabsf(h.wx) + 2.f * mrg < GROUND_HALF && fabsf(h.wz) + 2.f * mrg < GROUND_HALF);
+  for (int k = 0; k < 3; ++k) I[k] = fminf(c.base[k] + c.dif[k] * ndl, 1.f);
+  const float fx = wx * m.its - (float)h.ti, fz = wz * m.its - (float)h.tj;
+  tile_color(R, tiles[m.tile_off + h.tj * m.gw + h.ti], fx, fz, I, out);
 }
 
 // exact 4-sample resolve of one pixel (centre NDC nx, ny)
-__device__ inline void shade_msaa(const EnvCam& c, const RenderMapDev& m, const RenderParams& R, float nx,
-                                  float ny, float out[3]) {
+__device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const RenderParams& R,
+                                            const TileLds* tiles, float nx, float ny) {
   // standard 4x rotated-grid pattern, offsets in pixels (+x right, +y down)
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
-  const Ray rc = make_ray(c, nx, ny);
+  const Ray rc = make_ray(nx, ny, c.tx, c.ty, c.sth, c.cth);
   float acc[3] = {0.f, 0.f, 0.f};
   int pc = -1, pi = 0, pj = 0;
   float col[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int s = 0; s < 4; ++s) {
-    const Ray rs = make_ray(c, nx + ox[s] * sxn, ny - oy[s] * syn);
-    const Hit hs = classify(c, m, R.tiles, rs);
+    const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
+    const Hit hs = classify(c, m, tiles, rs);
     if (!(hs.cls == pc && (hs.cls != CLS_TILE || (hs.ti == pi && hs.tj == pj)))) {
-      shade(c, m, R, hs, rc, col);
+      shade(c, m, R, tiles, hs, rc, col);
       pc = hs.cls; pi = hs.ti; pj = hs.tj;
     }
     acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
   }
-  out[0] = 0.25f * acc[0]; out[1] = 0.25f * acc[1]; out[2] = 0.25f * acc[2];
+  const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
+  return pack_rgb(o);
 }
 
-__global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* cams) {
-  __shared__ uint32_t s_out[RB * 3];     // the strip: 1024 px * 3 B
-  __shared__ uint16_t s_queue[STRIP];
-  __shared__ int s_qn;
+// ---- per-pixel quantities that do not depend on the env when the camera is shared ------
+struct PixInv {
+  float lr, lf;     // tile-plane hit in the yaw-local frame (right, forward), metres
+  float ndl;        // max(0, N.L) of the tile plane at the hit
+  float mrg;        // conservative world-space footprint radius of the 4 MSAA samples
+  uint32_t flags;   // PF_*
+};
+#define PF_VALID 1u       // inside the source image (else BORDER_CONSTANT 0)
+#define PF_SKY 2u         // all 4 samples certainly miss every plane
+#define PF_ALWAYS_EDGE 4u // horizon band / near-far limits: always take the exact path
+#define PF_TILE_OK 8u     // tile-plane hit within [near, far]
+#define PF_GROUND_OK 16u  // ground-plane hit within [near, far]
 
+__device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float ty, float sth, float cth,
+                                 float Cy, const float L[4], float ex_n, float ey_n) {
+  PixInv p;
+  p.flags = valid ? PF_VALID : 0u;
+  p.lr = p.lf = p.ndl = p.mrg = 0.f;
+  const Ray r = make_ray(nx, ny, tx, ty, sth, cth);
+  const float ex = ex_n * tx, ey = ey_n * ty;
+  const float dy = ey * fabsf(cth);
+  if (!(r.yla < 0.f)) {
+    p.flags |= (r.yla - dy >= 0.f) ? PF_SKY : PF_ALWAYS_EDGE;
+    return p;
+  }
+  const float inv = 1.f / (-r.yla);
+  const float t = Cy * inv;
+  p.lr = t * r.xe; p.lf = t * r.fwd;
+  p.ndl = plane_ndl(L, sth, cth, r, t);
+  const float rho = dy * inv;
+  p.mrg = 1.5f * (t * (ex + ey) + (fabsf(p.lr) + fabsf(p.lf)) * 1.34f * rho);
+  const float tg = (Cy - GROUND_Y) * inv;
+  if (t >= NEAR_Z && t <= FAR_Z) p.flags |= PF_TILE_OK;
+  if (tg >= NEAR_Z && tg <= FAR_Z) p.flags |= PF_GROUND_OK;
+  if (rho > 0.25f || tg * (1.f + 2.f * rho) > FAR_Z * 0.98f || t * (1.f - 2.f * rho) < NEAR_Z * 1.02f)
+    p.flags |= PF_ALWAYS_EDGE;
+  return p;
+}
+
+// Resolve up to 64 queued edge pixels (one per lane) with the exact 4-sample path and patch
+// them into the frame.  Queue entry = (env-in-chunk << 8) | pixel-in-wavefront.
+__device__ inline void resolve_edges(const RenderParams& R, const EnvCam* s_cams, const TileLds* s_tiles,
+                                     const uint16_t* w_queue, int first, int count, int lane, int e0, int wbase,
+                                     int npix) {
+  if (lane < count) {
+    const uint32_t ent = w_queue[first + lane];
+    const int el = ent >> 8, lp = ent & 255;
+    const EnvCam c = s_cams[el];
+    const MapU m = map_u(R.maps[c.map_id]);
+    const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
+    const uint32_t v = shade_msaa(c, m, R, s_tiles, l.x, l.y);
+    uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
+    dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+  }
+}
+
+#define QCAP (WAVE_PIX + 64)
+
+template <bool DR>
+__global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
+                                               uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
+                                               const float4* __restrict__ lut, const RenderMapDev* __restrict__ maps,
+                                               const TileLds* __restrict__ tile_recs) {
+  extern __shared__ uint32_t s_mem[];
+  TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);                                   // [n_tile_recs]
+  EnvCam* s_cams = reinterpret_cast<EnvCam*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4)); // [ENVS_PER_BLOCK]
+  uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_cams + ENVS_PER_BLOCK);               // [4 waves][QCAP]
+
+  const int tid = threadIdx.x;
   const int npix = R.W * R.H;
   const int n_strips = (npix + STRIP - 1) / STRIP;
   const int strip = blockIdx.x % n_strips;
   const int chunk = blockIdx.x / n_strips;
-  const int tid = threadIdx.x;
-  const int p0 = strip * STRIP + tid * PPT;
+  const int e0 = chunk * ENVS_PER_BLOCK;
+  const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
+  {  // stage the raster tile records of every map and this chunk's EnvCams once per workgroup
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tile_recs);
+    for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
+    const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cams + e0);
+    uint32_t* cdst = reinterpret_cast<uint32_t*>(s_cams);
+    for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wbase = strip * STRIP + wave * WAVE_PIX;   // first pixel of this wavefront
+  const int p0 = wbase + lane * PPT;
+  const float aspect = (float)R.W / (float)R.H;
+  const float ex_n = 0.375f * 2.f / (float)R.W * 1.01f, ey_n = 0.375f * 2.f / (float)R.H * 1.01f;
 
   // per-pixel LUT -> registers (shared by all envs)
   float nx[PPT], ny[PPT];
@@ -300,58 +395,138 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* cam
   for (int k = 0; k < PPT; ++k) {
     const int p = p0 + k;
     if (p < npix) {
-      const float4 l = reinterpret_cast<const float4*>(R.lut)[p];
+      const float4 l = lut[p];
       nx[k] = l.x; ny[k] = l.y; ok[k] = l.z != 0.f;
     } else { nx[k] = ny[k] = 0.f; ok[k] = false; }
   }
-  const float ex_n = 0.375f * 2.f / (float)R.W * 1.01f, ey_n = 0.375f * 2.f / (float)R.H * 1.01f;
+  PixInv pv[PPT];
+  if (!DR) {
+    const CamShared cs = default_cam(aspect);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+      pv[k] = pix_inv(nx[k], ny[k], ok[k], cs.tx, cs.ty, cs.sth, cs.cth, cs.Cy, cs.L, ex_n, ey_n);
+  }
 
-  const int e0 = chunk * ENVS_PER_BLOCK;
-  const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
+  uint16_t* w_queue = s_queue + wave * QCAP;
+  int qn = 0;                                           // wave-uniform queue fill
+  const bool full_store = (p0 + PPT <= npix) && ((npix & 3) == 0);
+  const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
+
   for (int e = e0; e < e1; ++e) {
     const EnvCam c = cams[e];                       // wave-uniform: scalar loads
-    const RenderMapDev m = R.maps[c.map_id];
-    const float ex = ex_n * c.tx, ey = ey_n * c.ty;
-    if (tid == 0) s_qn = 0;
-    __syncthreads();
-    uint32_t b[12];
+    const MapU m = map_u(maps[c.map_id]);
+    if (DR) {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      float col[3] = {0.f, 0.f, 0.f};
-      if (ok[k]) {
-        const Ray r = make_ray(c, nx[k], ny[k]);
-        const Hit h = classify(c, m, R.tiles, r);
-        shade(c, m, R, h, r, col);
-        if (maybe_edge(c, m, r, h, ex, ey)) {
-          const int qi = atomicAdd(&s_qn, 1);
-          s_queue[qi] = (uint16_t)(tid * PPT + k);
+      for (int k = 0; k < PPT; ++k)
+        pv[k] = pix_inv(nx[k], ny[k], ok[k], c.tx, c.ty, c.sth, c.cth, c.Cy, c.L, ex_n, ey_n);
+    }
+    const float kg = (c.Cy - GROUND_Y) / c.Cy;       // ground-plane hit = C + kg * (tile-plane offset)
+    const float gw_m = m.gwf * m.ts, gh_m = m.ghf * m.ts;
+    const uint32_t hor_rgb = pack_rgb(c.hor);
+    // yaw rotation straight into tile units
+    const float A = c.sa * m.its, B = c.ca * m.its, Cxi = c.Cx * m.its, Czi = c.Cz * m.its;
+
+    // ---- fast path: one ray per pixel, straight-line (predicated) code so that the LDS
+    // tile-record reads and the 8 texel loads of the 4 pixels are all in flight together.
+    uint32_t px[PPT];
+    uint32_t edge_mask = 0;
+    bool any_work = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) any_work |= (pv[k].flags & (PF_VALID | PF_SKY)) == PF_VALID;
+    if (!__ballot(any_work)) {                       // wave-uniform: all sky / border
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) px[k] = (pv[k].flags & PF_VALID) ? hor_rgb : 0u;
+    } else {
+      float fx[PPT], fz[PPT], gxs[PPT], gzs[PPT];
+      bool cand[PPT], is_tile[PPT];
+      TileLds tr[PPT];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const PixInv& p = pv[k];
+        const float gx = fmaf(p.lf, B, fmaf(p.lr, A, Cxi));
+        const float gz = fmaf(p.lf, -A, fmaf(p.lr, B, Czi));
+        gxs[k] = gx; gzs[k] = gz;
+        fx[k] = __builtin_amdgcn_fractf(gx); fz[k] = __builtin_amdgcn_fractf(gz);
+        const int ti = flr_i32(gx), tj = flr_i32(gz);
+        cand[k] = (p.flags & (PF_VALID | PF_SKY | PF_ALWAYS_EDGE)) == PF_VALID;
+        const bool ingrid = cand[k] & ((p.flags & PF_TILE_OK) != 0) & ((unsigned)ti < (unsigned)m.gw) & ((unsigned)tj < (unsigned)m.gh);
+        const int idx = ingrid ? m.tile_off + (int)__umul24(tj, m.gw) + ti : m.tile_off;
+        tr[k] = s_tiles[idx];
+        is_tile[k] = ingrid & ((tr[k].flags & 1u) != 0);
+      }
+      uint2 top2[PPT], bot2[PPT];
+      float ax[PPT], ay[PPT];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const float x = fmaf(tr[k].mxz, fz[k], fmaf(tr[k].mxx, fx[k], tr[k].ox));
+        const float y = fmaf(tr[k].myz, fz[k], fmaf(tr[k].myx, fx[k], tr[k].oy));
+        ax[k] = __builtin_amdgcn_fractf(x); ay[k] = __builtin_amdgcn_fractf(y);
+        const int x0 = flr_i32(x) & xmask, y0 = flr_i32(y) & ymask;
+        const uint32_t* pt = texels + (tr[k].tex_off + __umul24(y0, tw1) + x0);   // always in bounds
+        __builtin_memcpy(&top2[k], pt, 8);
+        __builtin_memcpy(&bot2[k], pt + tw1, 8);
+      }
+      bool need_ground = false;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const PixInv& p = pv[k];
+        const float I0 = fminf(fmaf(c.dif[0], p.ndl, c.base[0]), 1.f);
+        const float I1 = DR ? fminf(fmaf(c.dif[1], p.ndl, c.base[1]), 1.f) : I0;
+        const float I2 = DR ? fminf(fmaf(c.dif[2], p.ndl, c.base[2]), 1.f) : I0;
+        uint32_t rgb = 0;
+        {
+          const float c00 = ubyte0(top2[k].x), c10 = ubyte0(top2[k].y), c01 = ubyte0(bot2[k].x), c11 = ubyte0(bot2[k].y);
+          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I0, 0, rgb);
+        }
+        {
+          const float c00 = ubyte1(top2[k].x), c10 = ubyte1(top2[k].y), c01 = ubyte1(bot2[k].x), c11 = ubyte1(bot2[k].y);
+          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I1, 1, rgb);
+        }
+        {
+          const float c00 = ubyte2(top2[k].x), c10 = ubyte2(top2[k].y), c01 = ubyte2(bot2[k].x), c11 = ubyte2(bot2[k].y);
+          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I2, 2, rgb);
+        }
+        const float d = fminf(fminf(fx[k], 1.f - fx[k]), fminf(fz[k], 1.f - fz[k]));
+        // untextured tiles and everything that is not a plain tile interior: other paths
+        const bool textured = (tr[k].flags & 2u) != 0;
+        const bool tile_fast = is_tile[k] & textured;
+        const bool tile_edge = is_tile[k] & (!(d > p.mrg * m.its) | !textured);
+        const bool gcand = cand[k] & !is_tile[k];
+        need_ground |= gcand;
+        px[k] = tile_fast ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
+        const bool edge = (((p.flags & PF_VALID) != 0) & ((p.flags & PF_ALWAYS_EDGE) != 0)) | tile_edge;
+        edge_mask |= edge ? (1u << k) : 0u;
+      }
+      if (__ballot(need_ground)) {                   // wave-uniform: ground quad beyond the map
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const PixInv& p = pv[k];
+          const bool gcand = cand[k] & !is_tile[k];
+          // every sample's tile-plane hit must stay clear of the grid, ground hit inside the quad
+          const float wx = gxs[k] * m.ts, wz = gzs[k] * m.ts;
+          const float wxg = fmaf(kg, wx - c.Cx, c.Cx), wzg = fmaf(kg, wz - c.Cz, c.Cz);
+          const bool clear = (wx < -p.mrg) | (wx > gw_m + p.mrg) | (wz < -p.mrg) | (wz > gh_m + p.mrg);
+          const bool inq = (fabsf(wxg) + 2.f * p.mrg < GROUND_HALF) & (fabsf(wzg) + 2.f * p.mrg < GROUND_HALF);
+          const bool gfast = gcand & clear & inq & ((p.flags & PF_GROUND_OK) != 0);
+          const float ndl = ground_ndl(c, wxg, wzg);
+          uint32_t rgb = 0;
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[0] * fminf(c.base[0] + c.dif[0] * ndl, 1.f), 0, rgb);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[1] * fminf(c.base[1] + c.dif[1] * ndl, 1.f), 1, rgb);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[2] * fminf(c.base[2] + c.dif[2] * ndl, 1.f), 2, rgb);
+          px[k] = gfast ? rgb : px[k];
+          edge_mask |= (gcand & !gfast) ? (1u << k) : 0u;
         }
       }
-      b[3 * k + 0] = to_u8(col[0]); b[3 * k + 1] = to_u8(col[1]); b[3 * k + 2] = to_u8(col[2]);
     }
-    uint32_t w0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    uint32_t w1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-    uint32_t w2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-    __syncthreads();
-    const int qn = s_qn;
-    if (qn > 0) {                                   // workgroup-uniform
-      s_out[tid * 3 + 0] = w0; s_out[tid * 3 + 1] = w1; s_out[tid * 3 + 2] = w2;
-      __syncthreads();
-      uint8_t* sb = reinterpret_cast<uint8_t*>(s_out);
-      for (int q = tid; q < qn; q += RB) {
-        const int lp = s_queue[q];
-        const float4 l = reinterpret_cast<const float4*>(R.lut)[strip * STRIP + lp];
-        float col[3];
-        shade_msaa(c, m, R, l.x, l.y, col);
-        sb[lp * 3 + 0] = (uint8_t)to_u8(col[0]);
-        sb[lp * 3 + 1] = (uint8_t)to_u8(col[1]);
-        sb[lp * 3 + 2] = (uint8_t)to_u8(col[2]);
-      }
-      __syncthreads();
-      w0 = s_out[tid * 3 + 0]; w1 = s_out[tid * 3 + 1]; w2 = s_out[tid * 3 + 2];
-    }
-    uint8_t* dst = R.frames + ((size_t)e * npix + p0) * 3;
-    if (p0 + PPT <= npix && (npix & 3) == 0) {
+
+    uint8_t* dst = frames + ((size_t)e * npix + p0) * 3;
+    const uint32_t w0 = px[0] | (px[1] << 24);
+    const uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
+    const uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
+    if (full_store) {
       uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);    // 12-byte aligned: p0 % 4 == 0
       d32[0] = w0; d32[1] = w1; d32[2] = w2;
     } else {
@@ -359,7 +534,54 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* cam
       for (int k = 0; k < PPT * 3; ++k)
         if (p0 + k / 3 < npix) dst[k] = (uint8_t)(ws[k >> 2] >> (8 * (k & 3)));
     }
-    __syncthreads();   // s_out / s_queue reuse
+
+    // ---- edge pixels: exact 4-sample resolve, deferred.  They are appended to a
+    // per-wavefront LDS queue ACROSS the env loop and resolved 64 at a time, so the
+    // expensive generic path always runs with every lane busy (wavefront-local LDS
+    // traffic only: DS operations of one wavefront execute in program order; the fences
+    // just stop the compiler from reordering across them).
+    if (!R.no_msaa && __ballot(edge_mask != 0)) {    // wave-uniform
+      const int n_mine = __popc(edge_mask);
+      int incl = n_mine;                             // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      const int total = __shfl(incl, 63);
+      int pos = qn + incl - n_mine;
+      const uint32_t etag = (uint32_t)(e - e0) << 8;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        if (edge_mask & (1u << k)) w_queue[pos++] = (uint16_t)(etag | (uint32_t)(lane * PPT + k));
+      qn += total;
+      if (qn >= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // patch stores must land after the fast-path stores of the same pixels
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int first = 0;
+        while (qn - first >= 64) { resolve_edges(R, s_cams, s_tiles, w_queue, first, 64, lane, e0, wbase, npix); first += 64; }
+        // move the remainder (< 64 entries) to the front
+        const int rem = qn - first;
+        uint16_t keep = 0;
+        if (lane < rem) keep = w_queue[first + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) w_queue[lane] = keep;
+        qn = rem;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (qn > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    resolve_edges(R, s_cams, s_tiles, w_queue, 0, qn, lane, e0, wbase, npix);
   }
 }
 
@@ -372,5 +594,11 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const int npix = R.W * R.H;
   const int n_strips = (npix + STRIP - 1) / STRIP;
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-  hipLaunchKernelGGL(k_raster, dim3(n_strips * n_chunks), dim3(RB), 0, s, R, cams);
+  const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds) + ENVS_PER_BLOCK * sizeof(EnvCam) + (RB / 64) * QCAP * 2;
+  if (R.domain_rand)
+    hipLaunchKernelGGL(k_raster<true>, dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels,
+                       reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs);
+  else
+    hipLaunchKernelGGL(k_raster<false>, dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels,
+                       reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs);
 }

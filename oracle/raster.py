@@ -1,0 +1,353 @@
+"""Oracle restatement of Simulator._render_img + Distortion.distort.
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Follows
+src/gym_duckietown/simulator.py:1707-1951 (scene order, camera, lighting state),
+:386-526 (tile / ground vertex lists), objects.py:123-148, objmesh.py:181-293,
+graphics.py:172-251 (4x MSAA float FBO + resolve) and distortion.py:85-125, per the
+render spec of SURVEY.md Appendix B.  OpenGL itself cannot run here: PARITY UNPINNED
+against real GL; this file fixes ONE documented interpretation of the fixed-function
+pipeline, in float64, evaluating all four MSAA samples of every pixel (no fast path).
+
+Interpretation choices (also in DESIGN.md "Render spec"):
+  * 4 samples at the standard rotated-grid offsets; coverage/depth per sample, shading
+    once per primitive at the pixel centre (attributes extrapolated) -- GL MSAA semantics.
+  * lighting: C = clamp01(m * (0.3 + A + D max(0, N.L))), unit normals (GL_NORMALIZE is
+    off in the reference and mesh units are unknown, so the 1/scale gain is not modelled);
+    light position is fixed in eye space (modelview = identity when reset() calls glLightfv).
+  * tiles: `lighting="gouraud"` evaluates the lit colour at the 8x8 vertex grid of the tile
+    (simulator.py:386-433) and interpolates bilinearly inside each quad (the driver's
+    triangle split is unknown); `lighting="pixel"` evaluates it at the fragment -- what the
+    HIP raster does (difference < 1/255, tests/test_gpu_render.py measures it).
+  * ground quad: lit at its 4 corners, bilinear over the quad, unit normal +y.
+  * objects: per-vertex lighting, perspective-correct barycentric interpolation; triangles
+    with a vertex closer than the near plane are dropped (no near clipping).
+  * readback: round(255 * clamp01(mean of the 4 samples)).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+NEAR, FAR = 0.04, 100.0
+GROUND_Y, GROUND_HALF = -0.008, 50.0
+CAMERA_FORWARD_DIST = 0.066
+SAMPLE_OFFSETS = [(-0.125, -0.375), (0.375, -0.125), (-0.375, 0.125), (0.125, 0.375)]  # (dx, dy) px, +y down
+
+
+class Camera:
+    """Camera / light state of one env (simulator.py:1758-1803, 565-584)."""
+
+    def __init__(self, pos, angle, *, cam_height=0.108, cam_angle_deg=19.15, cam_fov_y_deg=75.0,
+                 camera_noise=(0, 0, 0), domain_rand=False, horizon_color=(0.45, 0.82, 1.0),
+                 ground_color=(0.15, 0.15, 0.15), light_pos=(0.0, 3.0, 0.0, 1.0),
+                 light_ambient=(0.25, 0.25, 0.25), light_diffuse=(0.35, 0.35, 0.35), width=640, height=480):
+        pos = np.asarray(pos, dtype=np.float64)
+        if domain_rand:
+            pos = pos + np.asarray(camera_noise, dtype=np.float64)
+        self.sa, self.ca = math.sin(angle), math.cos(angle)
+        self.C = np.array([pos[0] + CAMERA_FORWARD_DIST * self.ca, pos[1] + cam_height,
+                           pos[2] - CAMERA_FORWARD_DIST * self.sa])
+        th = math.radians(float(cam_angle_deg))
+        self.sth, self.cth = math.sin(th), math.cos(th)
+        self.ty = math.tan(math.radians(float(cam_fov_y_deg)) / 2)
+        self.tx = self.ty * (width / float(height))
+        self.W, self.H = width, height
+        self.horizon = np.asarray(horizon_color, dtype=np.float64)[:3] * 255.0
+        self.ground = np.asarray(ground_color, dtype=np.float64)[:3] * 255.0
+        self.base = 0.3 + np.asarray(light_ambient, dtype=np.float64)[:3]
+        self.dif = np.asarray(light_diffuse, dtype=np.float64)[:3]
+        L = np.zeros(4)
+        lp = list(light_pos)
+        L[:len(lp)] = lp
+        if L[3] == 0:
+            L[:3] = L[:3] / np.linalg.norm(L[:3])
+        self.L = L
+
+    # world -> eye (rotation part acts on offsets from the camera centre)
+    def to_eye(self, P):
+        rel = np.asarray(P, dtype=np.float64) - self.C
+        xla = rel[..., 0] * self.sa + rel[..., 2] * self.ca
+        yla = rel[..., 1]
+        zla = -(rel[..., 0] * self.ca - rel[..., 2] * self.sa)
+        return np.stack([xla, yla * self.cth - zla * self.sth, yla * self.sth + zla * self.cth], axis=-1)
+
+    def normal_to_eye(self, n):
+        n = np.asarray(n, dtype=np.float64)
+        xla = n[..., 0] * self.sa + n[..., 2] * self.ca
+        yla = n[..., 1]
+        zla = -(n[..., 0] * self.ca - n[..., 2] * self.sa)
+        return np.stack([xla, yla * self.cth - zla * self.sth, yla * self.sth + zla * self.cth], axis=-1)
+
+    def ndl(self, p_eye, n_eye):
+        """max(0, N.L) for eye-space points / unit normals."""
+        if self.L[3] == 0:
+            d = n_eye @ self.L[:3]
+        else:
+            lv = self.L[:3] - p_eye
+            d = np.sum(n_eye * lv, axis=-1) / np.linalg.norm(lv, axis=-1)
+        return np.maximum(d, 0.0)
+
+    def lit(self, ndl):
+        """clamp01(base + dif * ndl) per channel -> [...,3]."""
+        return np.minimum(self.base + self.dif * np.asarray(ndl)[..., None], 1.0)
+
+
+def _rays(cam, nx, ny):
+    xe, ye = nx * cam.tx, ny * cam.ty
+    return xe, ye, ye * cam.cth - cam.sth, ye * cam.sth + cam.cth
+
+
+def _plane_hit(cam, xe, fwd, yla, h):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = h / (-yla)
+    rr, ff = t * xe, t * fwd
+    return t, cam.C[0] + rr * cam.sa + ff * cam.ca, cam.C[2] + rr * cam.ca - ff * cam.sa
+
+
+def _tile_uv(angle, fx, fz):
+    u = np.where(angle == 0, 1 - fx, np.where(angle == 1, fz, np.where(angle == 2, fx, 1 - fz)))
+    v = np.where(angle == 0, fz, np.where(angle == 1, fx, np.where(angle == 2, 1 - fz, 1 - fx)))
+    return u, v
+
+
+def _bilinear_repeat(tex, u, v):
+    """GL_LINEAR / GL_REPEAT fetch; tex [h,w,4] uint8 with row 0 = v=0."""
+    h, w = tex.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    x0f, y0f = np.floor(x), np.floor(y)
+    ax, ay = (x - x0f)[..., None], (y - y0f)[..., None]
+    x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
+    x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+    t = tex[..., :3].astype(np.float64)
+    top = t[y0, x0] + ax * (t[y0, x1] - t[y0, x0])
+    bot = t[y1, x0] + ax * (t[y1, x1] - t[y1, x0])
+    return top + ay * (bot - top)
+
+
+class Scene:
+    """Static inputs of the raster: map grid, textures per tile kind, object instances."""
+
+    def __init__(self, omap, textures, meshes):
+        self.m = omap
+        self.textures = textures          # kind -> [h,w,4] uint8 (GL row order)
+        self.meshes = meshes              # kind -> MeshData-like (verts, normals, colors)
+        W, H = omap.grid_width, omap.grid_height
+        self.present = np.zeros((H, W), bool)
+        self.angle = np.zeros((H, W), np.int64)
+        self.kinds = [[None] * W for _ in range(H)]
+        for t in omap.grid:
+            if t is None:
+                continue
+            i, j = t["coords"]
+            self.present[j, i] = True
+            self.angle[j, i] = t["angle"]
+            self.kinds[j][i] = t["kind"]
+
+
+def _tile_light(cam, scene, lighting, ti, tj, t_c, xe_c, ye_c, wx, wz):
+    """Lit white vertex colour of tile pixels -> [...,3]."""
+    n_eye = np.array([0.0, cam.cth, cam.sth])
+    if lighting == "pixel" or cam.L[3] == 0:
+        p_eye = np.stack([t_c * xe_c, t_c * ye_c, -t_c], axis=-1)
+        return cam.lit(cam.ndl(p_eye, n_eye))
+    # gouraud: 8x8 vertices per tile in the tile-local frame (simulator.py:388-401);
+    # the vertex grid is symmetric under the 90-degree tile rotations, so it is
+    # axis-aligned in world space with spacing ts/7.
+    ts = scene.m.tile_size
+    gx = (wx - ti * ts) / ts * 7.0
+    gz = (wz - tj * ts) / ts * 7.0
+    qx, qz = np.clip(np.floor(gx), 0, 6), np.clip(np.floor(gz), 0, 6)
+    ax, az = (gx - qx)[..., None], (gz - qz)[..., None]
+
+    def vert(dx, dz):
+        P = np.stack([(ti + (qx + dx) / 7.0) * ts, np.zeros_like(wx), (tj + (qz + dz) / 7.0) * ts], axis=-1)
+        return cam.lit(cam.ndl(cam.to_eye(P), n_eye))
+
+    top = vert(0, 0) + ax * (vert(1, 0) - vert(0, 0))
+    bot = vert(0, 1) + ax * (vert(1, 1) - vert(0, 1))
+    return top + az * (bot - top)
+
+
+def _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc):
+    """Colour (0..255) of the plane primitive seen by each sample, evaluated at the pixel
+    centre.  cls: 0 sky 1 ground 2 tile."""
+    xe_c, ye_c, yla_c, fwd_c = rc
+    out = np.empty(cls.shape + (3,))
+    out[:] = cam.horizon
+    centre_down = yla_c < 0
+    # ground
+    g = cls == 1
+    if g.any():
+        t_c, wx_c, wz_c = _plane_hit(cam, xe_c, fwd_c, yla_c, cam.C[1] - GROUND_Y)
+        wx = np.where(centre_down, wx_c, wx_s)[g]
+        wz = np.where(centre_down, wz_c, wz_s)[g]
+        corners = np.array([[-GROUND_HALF, GROUND_Y, -GROUND_HALF], [GROUND_HALF, GROUND_Y, -GROUND_HALF],
+                            [-GROUND_HALF, GROUND_Y, GROUND_HALF], [GROUND_HALF, GROUND_Y, GROUND_HALF]])
+        nd = np.broadcast_to(cam.ndl(cam.to_eye(corners), np.array([0.0, cam.cth, cam.sth])), (4,))
+        a = np.clip((wx + GROUND_HALF) / (2 * GROUND_HALF), 0, 1)
+        b = np.clip((wz + GROUND_HALF) / (2 * GROUND_HALF), 0, 1)
+        n0 = nd[0] + a * (nd[1] - nd[0])
+        n1 = nd[2] + a * (nd[3] - nd[2])
+        out[g] = cam.ground * cam.lit(n0 + b * (n1 - n0))
+    # tiles
+    tl = cls == 2
+    if tl.any():
+        t_c, wx_c, wz_c = _plane_hit(cam, xe_c, fwd_c, yla_c, cam.C[1])
+        t = np.where(centre_down, t_c, t_s)[tl]
+        wx = np.where(centre_down, wx_c, wx_s)[tl]
+        wz = np.where(centre_down, wz_c, wz_s)[tl]
+        i, j = ti[tl], tj[tl]
+        ts = scene.m.tile_size
+        I = _tile_light(cam, scene, lighting, i, j, t, xe_c[tl], ye_c[tl], wx, wz)
+        fx, fz = wx / ts - i, wz / ts - j
+        u, v = _tile_uv(scene.angle[j, i], fx, fz)
+        col = np.empty((i.size, 3))
+        col[:] = 255.0
+        flat_kind = np.array([hash(scene.kinds[jj][ii]) for ii, jj in zip(i.tolist(), j.tolist())]) if i.size else np.zeros(0)
+        for kind in {scene.kinds[jj][ii] for ii, jj in zip(i.tolist(), j.tolist())}:
+            sel = flat_kind == hash(kind)
+            tex = scene.textures.get(kind)
+            if tex is not None:
+                col[sel] = _bilinear_repeat(tex, u[sel], v[sel])
+        out[tl] = col * I
+    return out
+
+
+def _object_instances(scene, obj_states):
+    """World-space lit-ready triangles of all visible objects: list of
+    (verts [T,3,3], normals [T,3,3], colors [T,3,3])."""
+    out = []
+    for k, o in enumerate(scene.m.objects):
+        st = obj_states[k] if obj_states is not None else None
+        if st is not None and not st.get("visible", True):
+            continue
+        if st is None and not getattr(o, "visible", True):
+            continue
+        mesh = scene.meshes.get(o.kind) or scene.meshes.get("*")
+        if mesh is None:
+            continue
+        pos = np.asarray(st["pos"] if st is not None else o.pos, dtype=np.float64)
+        yrot = math.radians(st["y_rot"] if st is not None else o.y_rot)
+        c, s = math.cos(yrot), math.sin(yrot)
+        # glRotatef(y_rot, 0,1,0): x' = x c + z s ; z' = -x s + z c   (objects.py:140-146)
+        V = mesh.verts.astype(np.float64) * o.scale
+        Vw = np.stack([V[..., 0] * c + V[..., 2] * s, V[..., 1], -V[..., 0] * s + V[..., 2] * c], axis=-1) + pos
+        Nn = mesh.normals.astype(np.float64)
+        Nw = np.stack([Nn[..., 0] * c + Nn[..., 2] * s, Nn[..., 1], -Nn[..., 0] * s + Nn[..., 2] * c], axis=-1)
+        out.append((Vw, Nw, mesh.colors.astype(np.float64)))
+    return out
+
+
+def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
+    """[H,W,3] float (0..255) of the un-distorted frame, row 0 = top."""
+    W, H = cam.W, cam.H
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    nxc = 2 * (cols + 0.5) / W - 1
+    nyc = 1 - 2 * (rows + 0.5) / H
+    rc = _rays(cam, nxc, nyc)
+    gw, gh, ts = scene.m.grid_width, scene.m.grid_height, scene.m.tile_size
+
+    # objects: eye-space vertices, per-vertex lit colours, screen coordinates
+    tris = []
+    for Vw, Nw, Cc in _object_instances(scene, obj_states):
+        Pe = cam.to_eye(Vw)
+        Ne = cam.normal_to_eye(Nw)
+        Ne = Ne / np.linalg.norm(Ne, axis=-1, keepdims=True)
+        lit = np.minimum(Cc * (cam.base + cam.dif * cam.ndl(Pe, Ne)[..., None]), 1.0) * 255.0
+        w = -Pe[..., 2]
+        ok = (w > NEAR).all(axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sx = (Pe[..., 0] / w / cam.tx + 1) * 0.5 * W       # pixel coords, x right
+            sy = (1 - Pe[..., 1] / w / cam.ty) * 0.5 * H       # y down
+        for k in np.flatnonzero(ok):
+            tris.append((sx[k], sy[k], w[k], lit[k]))
+
+    acc = np.zeros((H, W, 3))
+    for (ox, oy) in SAMPLE_OFFSETS:
+        nx, ny = nxc + 2 * ox / W, nyc - 2 * oy / H
+        xe, ye, yla, fwd = _rays(cam, nx, ny)
+        down = yla < 0
+        cls = np.zeros((H, W), np.int64)
+        ti = np.zeros((H, W), np.int64)
+        tj = np.zeros((H, W), np.int64)
+        depth = np.full((H, W), np.inf)
+        t_s = np.zeros((H, W)); wx_s = np.zeros((H, W)); wz_s = np.zeros((H, W))
+        # ground
+        tg, wxg, wzg = _plane_hit(cam, xe, fwd, yla, cam.C[1] - GROUND_Y)
+        gok = down & (tg >= NEAR) & (tg <= FAR) & (np.abs(wxg) <= GROUND_HALF) & (np.abs(wzg) <= GROUND_HALF)
+        cls[gok] = 1
+        depth[gok] = tg[gok]; t_s[gok] = tg[gok]; wx_s[gok] = wxg[gok]; wz_s[gok] = wzg[gok]
+        # tiles (depth func LESS: y=0 is in front of y=-0.008 wherever both are hit)
+        tt, wxt, wzt = _plane_hit(cam, xe, fwd, yla, cam.C[1])
+        with np.errstate(invalid="ignore"):
+            fi, fj = np.floor(wxt / ts), np.floor(wzt / ts)
+        tok = down & (tt >= NEAR) & (tt <= FAR) & (fi >= 0) & (fj >= 0) & (fi < gw) & (fj < gh)
+        ii = np.where(tok, fi, 0).astype(np.int64)
+        jj = np.where(tok, fj, 0).astype(np.int64)
+        tok &= scene.present[jj, ii]
+        cls[tok] = 2
+        ti[tok] = ii[tok]; tj[tok] = jj[tok]
+        depth[tok] = tt[tok]; t_s[tok] = tt[tok]; wx_s[tok] = wxt[tok]; wz_s[tok] = wzt[tok]
+        col = _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc)
+        # objects: z-buffered triangles, coverage at the sample, colour at the pixel centre
+        for (sx, sy, w, lit) in tris:
+            x0 = max(int(math.floor(sx.min() - 1)), 0); x1 = min(int(math.ceil(sx.max() + 1)), W - 1)
+            y0 = max(int(math.floor(sy.min() - 1)), 0); y1 = min(int(math.ceil(sy.max() + 1)), H - 1)
+            if x0 > x1 or y0 > y1:
+                continue
+            area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0])
+            if area == 0:
+                continue
+            px = cols[y0:y1 + 1, x0:x1 + 1] + 0.5
+            py = rows[y0:y1 + 1, x0:x1 + 1] + 0.5
+
+            def bary(qx, qy):
+                b0 = ((sx[1] - qx) * (sy[2] - qy) - (sx[2] - qx) * (sy[1] - qy)) / area
+                b1 = ((sx[2] - qx) * (sy[0] - qy) - (sx[0] - qx) * (sy[2] - qy)) / area
+                return b0, b1, 1 - b0 - b1
+
+            b0, b1, b2 = bary(px + ox, py + oy)
+            inside = (b0 >= 0) & (b1 >= 0) & (b2 >= 0)
+            if not inside.any():
+                continue
+            iw = b0 / w[0] + b1 / w[1] + b2 / w[2]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                d = 1.0 / iw
+            sub = depth[y0:y1 + 1, x0:x1 + 1]
+            win = inside & (d < sub) & (d >= NEAR) & (d <= FAR)
+            if not win.any():
+                continue
+            c0, c1, c2 = bary(px, py)                      # attributes at the pixel centre
+            iwc = c0 / w[0] + c1 / w[1] + c2 / w[2]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                colc = (c0[..., None] * lit[0] / w[0] + c1[..., None] * lit[1] / w[1] + c2[..., None] * lit[2] / w[2]) / iwc[..., None]
+            colc = np.clip(np.nan_to_num(colc, nan=0.0, posinf=255.0, neginf=0.0), 0.0, 255.0)
+            sub[win] = d[win]
+            csub = col[y0:y1 + 1, x0:x1 + 1]
+            csub[win] = colc[win]
+        acc += col
+    return acc / 4.0
+
+
+def to_u8(img):
+    return np.floor(np.clip(img, 0.0, 255.0) + 0.5).astype(np.uint8)
+
+
+def distort(img_u8, rmapx, rmapy):
+    """cv2.remap(INTER_NEAREST, BORDER_CONSTANT 0) (distortion.py:118-124)."""
+    H, W = img_u8.shape[:2]
+    sx = np.rint(rmapx.astype(np.float64)).astype(np.int64)
+    sy = np.rint(rmapy.astype(np.float64)).astype(np.int64)
+    ok = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+    out = np.zeros_like(img_u8)
+    out[ok] = img_u8[sy[ok], sx[ok]]
+    return out
+
+
+def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None):
+    """Simulator.render_obs (simulator.py:1953-1972): uint8 [H,W,3]."""
+    img = to_u8(render_rectilinear(cam, scene, lighting, obj_states))
+    if rmap is not None:
+        img = distort(img, rmap[0], rmap[1])
+    return img

@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: tools/prof_render.sh <tag> ; writes gpurun_out/prof_<tag>/...
+TAG=${1:-r}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp
+K=5 N=${N:-1024} rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/trace.log 2>&1
+K=5 N=${N:-1024} rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc1 -o pmc1 -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/pmc1.log 2>&1
+K=5 N=${N:-1024} rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM -d $OUT/pmc2 -o pmc2 -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/pmc2.log 2>&1
+K=5 N=${N:-1024} rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/pmc3.log 2>&1
+K=5 N=${N:-1024} rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o pmc4 -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/pmc4.log 2>&1
+find $OUT -name "*.csv" | head -30
