@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the dtsim hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[2] -- Duckietown-small_loop-v0, 4096
+batched envs PER GPU, 640x480 RGB raster + fisheye distortion, domain_rand off, random
+DuckietownEnv (vel, steer) actions resident in HBM, auto-reset from a pre-sampled spawn
+pool.  One "step" = one pass of the hot path over the batch: dtsim_step (kinematics,
+dynamics, lane pose, SAT collision, proximity, reward/done) + dtsim_render (raster + fisheye).
+Envs are independent, so GPUs shard them with NO data-path collective: `value` is the
+sim throughput, scaling "weak".  The north star's RCCL all-gather of the uint8 frame batch
+is measured separately (`gather`, xGMI-link bound) and never part of `value`.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(dominant kernel = the raster; achieved = algorithmic bytes / HIP-event kernel time) and
+`cpu_baseline` (the oracle, 1 host core, bounded sample; N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gym-duckietown_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_HBM = 8.0e12          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+W, H = 640, 480
+FRAME_BYTES = W * H * 3    # algorithmic bytes per env-step: the frame, written once
+
+
+def cpu_baseline(n_steps: int):
+    """The oracle (kind "port") on ONE host core: full Simulator.step incl. software raster
+    and fisheye remap, same map / resolution / action distribution, bounded sample."""
+    from dtsim import assets
+    from dtsim import distortion as pdist
+    from oracle import raster, sim as osim
+    ext = assets.mesh_extents(("duckie",))
+    o = osim.OracleSim(assets.get_map("small_loop"), ext, domain_rand=False, seed=1000)
+    kinds = {t["kind"] for t in o.map.grid if t is not None}
+    scene = raster.Scene(o.map, {k: assets.get_texture(k) for k in kinds},
+                         {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")})
+    rmap = pdist.distortion_maps(W, H)
+    rng = np.random.default_rng(1234)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        a = rng.uniform(-1, 1, 2)
+        _, done, _ = o.step_vel_steer(a)
+        cam = raster.Camera(o.cur_pos, o.cur_angle, width=W, height=H, horizon_color=o.horizon_color,
+                            ground_color=o.ground_color)
+        raster.render_obs(cam, scene, "gouraud", rmap)
+        if done:
+            o.reset()
+    dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_steps} env-steps of small_loop 640x480 + fisheye on the numpy oracle (oracle/sim.py + oracle/raster.py); "
+                      "the reference's Pyglet/OpenGL path is not runnable on this host (no pyglet/duckietown_world/GL)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="oracle env-steps for cpu_baseline")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dtsim import BatchedSimulator, _ffi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, K, Wm = args.envs, args.steps, args.warmup
+    sim = BatchedSimulator("small_loop", N, domain_rand=False, distortion=True, camera_width=W, camera_height=H,
+                           seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
+                           device=local_rank, do_reset=False)
+    t_setup = time.perf_counter()
+    sim.make_spawn_pool(N)                     # reference-order resets, geometry evaluated on the GPU
+    sim.reset(states=sim._pool)                # start from the first pool entry of each env
+    t_setup = time.perf_counter() - t_setup
+
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    acts = torch.rand((K + Wm, N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1   # resident in HBM
+
+    def one_step(t):
+        sim.step(acts[t])
+        sim.render()
+
+    def sync_all():
+        sim.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for t in range(Wm):
+        one_step(t)
+    sync_all()
+    sim.profile_read(_ffi.KERNEL_RENDER)
+    sim.profile_read(_ffi.KERNEL_STEP)
+    t0 = time.perf_counter()
+    for t in range(Wm, Wm + K):
+        one_step(t)
+    sim.sync()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    n_r, ms_r = sim.profile_read(_ffi.KERNEL_RENDER)
+    n_s, ms_s = sim.profile_read(_ffi.KERNEL_STEP)
+    tt = torch.tensor([t_local], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    t_max = float(tt.item())
+
+    # ---- optional: frame all-gather over RCCL/xGMI (north star; link-bound, not in `value`)
+    gather = None
+    if world > 1 and not args.no_gather:
+        frames = torch.as_tensor(sim.frames_device(), device=dev)
+        try:
+            out = torch.empty((world,) + tuple(frames.shape), dtype=torch.uint8, device=dev)
+            ks = min(K, 3)
+            sync_all()
+            tg = time.perf_counter()
+            for t in range(ks):
+                one_step(Wm + t)
+                sim.sync()
+                dist.all_gather_into_tensor(out, frames)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+            gather = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "steps": ks,
+                      "collective": "all_gather_into_tensor(uint8 frames)", "bytes_per_rank_per_step": int(frames.numel())}
+            del out
+        except Exception as ex:  # e.g. OOM on small-memory parts
+            gather = {"error": repr(ex)[:200]}
+
+    done_frac = float(sim.read(_ffi.FIELD_EPISODE).mean())
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        cpu = cpu_baseline(args.cpu_steps)
+
+    if rank == 0:
+        k_ms = ms_r / max(n_r, 1)
+        achieved = N * FRAME_BYTES / (k_ms * 1e-3)
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
+        if os.path.exists(pj):
+            try:
+                d = json.load(open(pj))
+                if d.get("envs") == N:
+                    traffic = d.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        line = {
+            "metric": "env-steps/sec (4096 envs, 640x480 RGB) at 1/2/4/8 MI355X; % HBM roofline",
+            "value": world * N * K / t_max,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1e3 * t_max / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 raster -> u8 frames; f64 physics",
+            "data": "synthetic",
+            "config": {"workload": "Duckietown-small_loop-v0 (fixture), 4096 batched envs per GPU, 640x480 RGB raster + fisheye "
+                                   "distortion, domain_rand off, random (vel, steer) actions, auto-reset from spawn pool "
+                                   "[BASELINE.json configs[2]]",
+                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": False,
+                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_raster<false>", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
+                         "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
+                         "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
+                         "step_kernel_ms": ms_s / max(n_s, 1)},
+            "cpu_baseline": cpu,
+            "gather": gather,
+            "episodes_per_env": done_frac,
+            "setup_s": t_setup,
+        }
+        print(json.dumps(line), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,360 @@
+"""Drop-in `Simulator` (reference: src/gym_duckietown/simulator.py:188-2053) over the HIP library.
+
+Same constructor keywords, `reset() / step() / render() / seed() / close()`, attributes
+(`cur_pos`, `cur_angle`, `speed`, `step_count`, `timestamp`, `wheel_dist`, `grid`,
+`drivable_tiles`, ...) and query methods (`closest_curve_point`, `get_lane_pos2`,
+`_valid_pose`, `_collision`, `proximity_penalty2`, `compute_reward`, `_compute_done_reward`,
+`get_grid_coords`, `_get_tile`, `_drivable_pos`, `get_agent_info`) plus the module-level
+`_update_pos`, `get_agent_corners`, `get_dir_vec`, `get_right_vec`, `_actual_center`.
+It is an N=1 view of dtsim.BatchedSimulator: every number comes from the GPU kernels
+(`dtsim_step`, `dtsim_render`, `dtsim_query`); nothing is recomputed on the host.
+
+Not provided (out of scope): the pyglet human window, `top_down` / `free_cam` /
+`segment` renders, `draw_bbox` / `draw_curve`, LEDs, `randomize_maps_on_reset`, `camera_rand`'s
+carnivalmirror calibration sampling.
+"""
+from __future__ import annotations
+
+import math
+from collections import namedtuple
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from dtsim import BatchedSimulator, _ffi
+from dtsim.reset import BLUE_SKY
+
+from . import logger
+from .exceptions import InvalidMapException, NotInLane
+
+try:  # gym is optional
+    import gym
+    from gym import spaces
+    _EnvBase = gym.Env
+except Exception:  # pragma: no cover
+    gym = None
+    _EnvBase = object
+
+    class _Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.dtype = low, high, dtype
+            self.shape = tuple(shape) if shape is not None else np.asarray(low).shape
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high, self.shape).astype(self.dtype)
+
+    class spaces:  # noqa: N801
+        Box = _Box
+
+# constants of the reference (simulator.py:99-177)
+WINDOW_WIDTH, WINDOW_HEIGHT = 800, 600
+DEFAULT_CAMERA_WIDTH, DEFAULT_CAMERA_HEIGHT = 640, 480
+CAMERA_ANGLE, CAMERA_FOV_Y, CAMERA_FLOOR_DIST, CAMERA_FORWARD_DIST = 19.15, 75, 0.108, 0.066
+WHEEL_DIST = 0.102
+ROBOT_WIDTH = 0.13 + 0.02
+ROBOT_LENGTH = 0.18
+ROBOT_HEIGHT = 0.12
+SAFETY_RAD_MULT = 1.8
+AGENT_SAFETY_RAD = (max(ROBOT_LENGTH, ROBOT_WIDTH) / 2) * SAFETY_RAD_MULT
+MIN_SPAWN_OBJ_DIST = 0.25
+DEFAULT_ROBOT_SPEED = 1.20
+DEFAULT_FRAMERATE = 30
+DEFAULT_MAX_STEPS = 1500
+DEFAULT_MAP_NAME = "udem1"
+DEFAULT_FRAME_SKIP = 1
+DEFAULT_ACCEPT_START_ANGLE_DEG = 60
+REWARD_INVALID_POSE = -1000
+MAX_SPAWN_ATTEMPTS = 5000
+
+LanePosition0 = namedtuple("LanePosition", "dist dot_dir angle_deg angle_rad")
+
+
+class LanePosition(LanePosition0):
+    def as_json_dict(self):
+        return dict(dist=self.dist, dot_dir=self.dot_dir, angle_deg=self.angle_deg, angle_rad=self.angle_rad)
+
+
+@dataclass
+class DoneRewardInfo:
+    done: bool
+    done_why: str
+    done_code: str
+    reward: float
+
+
+_DONE_MSG = {
+    _ffi.DONE_IN_PROGRESS: "",
+    _ffi.DONE_INVALID_POSE: "Stopping the simulator because we are at an invalid pose.",
+}
+
+
+class Simulator(_EnvBase):
+    metadata = {"render.modes": ["human", "rgb_array", "app"], "video.frames_per_second": 30}
+    _ACTION_MODE = "wheels"
+
+    def __init__(self, map_name: str = DEFAULT_MAP_NAME, max_steps: int = DEFAULT_MAX_STEPS, draw_curve: bool = False,
+                 draw_bbox: bool = False, domain_rand: bool = True, frame_rate: float = DEFAULT_FRAMERATE,
+                 frame_skip: int = DEFAULT_FRAME_SKIP, camera_width: int = DEFAULT_CAMERA_WIDTH,
+                 camera_height: int = DEFAULT_CAMERA_HEIGHT, robot_speed: float = DEFAULT_ROBOT_SPEED,
+                 accept_start_angle_deg=DEFAULT_ACCEPT_START_ANGLE_DEG, full_transparency: bool = False,
+                 user_tile_start=None, seed: int = None, distortion: bool = False, dynamics_rand: bool = False,
+                 camera_rand: bool = False, randomize_maps_on_reset: bool = False, num_tris_distractors: int = 12,
+                 color_ground: Sequence[float] = (0.15, 0.15, 0.15), color_sky: Sequence[float] = BLUE_SKY,
+                 style: str = "photos", enable_leds: bool = False, device: int = 0, **env_kwargs):
+        if draw_curve or draw_bbox or randomize_maps_on_reset or enable_leds or camera_rand:
+            raise NotImplementedError("draw_curve / draw_bbox / randomize_maps_on_reset / enable_leds / camera_rand "
+                                      "are outside the hot path this backend implements")
+        self.enable_leds = enable_leds
+        self.seed_value = seed
+        self.num_tris_distractors = num_tris_distractors
+        self.color_ground, self.color_sky = color_ground, list(color_sky)
+        self.full_transparency = full_transparency
+        self.max_steps, self.draw_curve, self.draw_bbox, self.domain_rand = max_steps, draw_curve, draw_bbox, domain_rand
+        self.frame_rate, self.delta_time, self.frame_skip = frame_rate, 1.0 / frame_rate, frame_skip
+        self.graphics = True
+        self.action_space = spaces.Box(low=-1, high=1, shape=(2,), dtype=np.float32)
+        self.camera_width, self.camera_height = camera_width, camera_height
+        self.robot_speed = robot_speed
+        self.observation_space = spaces.Box(low=0, high=255, shape=(camera_height, camera_width, 3), dtype=np.uint8)
+        self.reward_range = (-1000, 1000)
+        self.window = None
+        self.accept_start_angle_deg = accept_start_angle_deg
+        self.distortion = distortion and not draw_bbox
+        self.camera_rand = False
+        self.undistort = False
+        self.dynamics_rand = dynamics_rand
+        self.user_tile_start = user_tile_start
+        self.style = style
+        self.randomize_maps_on_reset = False
+        try:
+            self._sim = BatchedSimulator(
+                map_name, 1, max_steps=max_steps, domain_rand=domain_rand, frame_rate=frame_rate, frame_skip=frame_skip,
+                camera_width=camera_width, camera_height=camera_height, robot_speed=robot_speed,
+                accept_start_angle_deg=accept_start_angle_deg, user_tile_start=user_tile_start, seed=seed,
+                distortion=self.distortion, dynamics_rand=dynamics_rand, num_tris_distractors=num_tris_distractors,
+                color_ground=color_ground, color_sky=color_sky, action_mode=self._ACTION_MODE, actions_f64=True,
+                device=device, do_reset=False, **env_kwargs)
+        except KeyError as e:
+            raise InvalidMapException("Cannot load map data", map_name=map_name) from e
+        mt = self._sim.maps[0]
+        self._mt = mt
+        self.map_name = mt.name
+        self.road_tile_size = mt.tile_size
+        self.grid_width, self.grid_height = mt.grid_w, mt.grid_h
+        self.grid = []
+        for idx, kind in enumerate(mt.tile_kind_names):
+            if kind is None:
+                self.grid.append(None)
+                continue
+            t = {"coords": (idx % mt.grid_w, idx // mt.grid_w), "kind": kind, "angle": int(mt.tile_angle[idx]),
+                 "drivable": bool(mt.tile_curve_off[idx] >= 0)}
+            if t["drivable"]:
+                o, c = int(mt.tile_curve_off[idx]), int(mt.tile_curve_cnt[idx])
+                t["curves"] = mt.curves3[o:o + c]
+            self.grid.append(t)
+        self.drivable_tiles = [self.grid[j * mt.grid_w + i] for (i, j) in mt.drivable_tiles]
+        self.objects = mt.objects
+        self.start_tile = self._get_tile(*mt.start_tile) if mt.start_tile is not None else None
+        self.start_pose = mt.start_pose
+        self.cam_offset = np.array([0, 0, 0])
+        self.reset()
+        self.last_action = np.array([0, 0])
+        self.wheelVels = np.array([0, 0])
+
+    # ---------------------------------------------------------------- state views --
+    def _f(self, field):
+        return self._sim.read(field)[0]
+
+    @property
+    def cur_pos(self):
+        return self._f(_ffi.FIELD_POS).copy()
+
+    @property
+    def cur_angle(self):
+        return float(self._f(_ffi.FIELD_ANGLE))
+
+    @property
+    def speed(self):
+        return float(self._f(_ffi.FIELD_SPEED))
+
+    @property
+    def step_count(self):
+        return int(self._f(_ffi.FIELD_STEP_COUNT))
+
+    @property
+    def timestamp(self):
+        return float(self._f(_ffi.FIELD_TIMESTAMP))
+
+    @property
+    def np_random(self):
+        return self._sim.env_state[0].np_random
+
+    # --------------------------------------------------------------------- gym API --
+    def seed(self, seed=None):
+        self._sim.env_state[0].np_random = np.random.default_rng(seed)     # simulator.py:1043-1045
+        return [seed]
+
+    def close(self):
+        pass
+
+    def reset(self, segment: bool = False):
+        if segment:
+            raise NotImplementedError("segmentation render is out of scope")
+        self._sim.reset()
+        st = self._sim.init_states[0]
+        es = self._sim.env_state[0]
+        self.randomization_settings = es.settings
+        self.horizon_color = np.array(list(st.horizon_color))
+        self.ground_color = np.array(list(st.ground_color))
+        self.wheel_dist = st.wheel_dist
+        self.cam_height, self.cam_angle, self.cam_fov_y = st.cam_height, [st.cam_angle_deg, 0, 0], st.cam_fov_y_deg
+        return self.render_obs()
+
+    def step(self, action: np.ndarray):
+        action = np.clip(action, -1, 1) if self._ACTION_MODE == "wheels" else np.asarray(action)
+        action = np.array(action, dtype=np.float64)
+        self._sim.step(action.reshape(1, 2))
+        self.last_action = action
+        obs = self.render_obs()
+        misc = self.get_agent_info()
+        d = self._compute_done_reward()
+        misc["Simulator"]["msg"] = d.done_why
+        return obs, d.reward, d.done, misc
+
+    def render_obs(self, segment: bool = False) -> np.ndarray:
+        self._sim.render()
+        return self._sim.frames_host()[0]
+
+    def render(self, mode: str = "human", close: bool = False, segment: bool = False):
+        assert mode in ["human", "top_down", "free_cam", "rgb_array"]
+        if close:
+            return
+        if mode != "rgb_array" or segment:
+            raise NotImplementedError("only mode='rgb_array' is implemented (the camera observation at the "
+                                      "configured resolution); human/top_down/free_cam windows are out of scope")
+        return self.render_obs()
+
+    # --------------------------------------------------------- device-side queries --
+    def _probe(self, pos, angle, safety_factor=1.0):
+        p = self._sim.query(np.zeros(1, np.int32), np.array([[pos[0], pos[2], angle]], np.float64), safety_factor)
+        return p[0]
+
+    def get_grid_coords(self, abs_pos) -> Tuple[int, int]:
+        pr = self._probe(abs_pos, 0.0)
+        return int(pr["tile_i"]), int(pr["tile_j"])
+
+    def _get_tile(self, i, j):
+        i, j = int(i), int(j)
+        if i < 0 or i >= self.grid_width or j < 0 or j >= self.grid_height:
+            return None
+        return self.grid[j * self.grid_width + i]
+
+    def _drivable_pos(self, pos) -> bool:
+        return bool(self._probe(pos, 0.0)["drivable"])
+
+    def closest_curve_point(self, pos, angle):
+        pr = self._probe(pos, angle)
+        if not pr["in_lane"]:
+            return None, None
+        return (np.array([pr["point"][0], 0.0, pr["point"][1]]), np.array([pr["tangent"][0], 0.0, pr["tangent"][1]]))
+
+    def get_lane_pos2(self, pos, angle):
+        pr = self._probe(pos, angle)
+        if not pr["in_lane"]:
+            raise NotInLane(f"Point not in lane: {pos}")
+        return LanePosition(dist=float(pr["dist"]), dot_dir=float(pr["dot_dir"]), angle_deg=float(pr["angle_deg"]),
+                            angle_rad=float(pr["angle_rad"]))
+
+    def proximity_penalty2(self, pos, angle) -> float:
+        return float(self._probe(pos, angle)["prox"])
+
+    def _valid_pose(self, pos, angle, safety_factor: float = 1.0) -> bool:
+        return bool(self._probe(pos, angle, safety_factor)["valid"])
+
+    def _inconvenient_spawn(self, pos) -> bool:
+        return bool(self._probe(pos, 0.0)["inconvenient"])
+
+    def _collision(self, agent_corners) -> bool:
+        """simulator.py:1473: takes the 4 corners of get_agent_corners(pos, angle); the pose is
+        recovered from them (rear-left, rear-right, front-right, front-left) and evaluated on the device."""
+        c = np.asarray(agent_corners, dtype=np.float64)
+        centre = c.mean(axis=0)
+        fwd = (c[2] + c[3]) * 0.5 - (c[0] + c[1]) * 0.5
+        angle = math.atan2(-fwd[1], fwd[0])
+        d = np.array([math.cos(angle), -math.sin(angle)])
+        p = centre - (CAMERA_FORWARD_DIST - ROBOT_LENGTH / 2) * d
+        return bool(self._probe([p[0], 0.0, p[1]], angle)["collision"])
+
+    def compute_reward(self, pos, angle, speed):
+        pr = self._probe(pos, angle)
+        if speed == self.robot_speed:
+            return float(pr["reward"])
+        if not pr["in_lane"]:
+            return 40 * float(pr["prox"])
+        return +1.0 * speed * float(pr["dot_dir"]) + -10 * abs(float(pr["dist"])) + +40 * float(pr["prox"])
+
+    def _compute_done_reward(self) -> DoneRewardInfo:
+        code = int(self._f(_ffi.FIELD_DONE_CODE))
+        msg = _DONE_MSG.get(code, "Stopping the simulator because we reached max_steps = %s" % self.max_steps)
+        return DoneRewardInfo(done=bool(self._f(_ffi.FIELD_DONE)), done_why=msg, reward=float(self._f(_ffi.FIELD_REWARD)),
+                              done_code=_ffi.DONE_CODES[code])
+
+    def update_physics(self, action, delta_time: float = None):
+        """simulator.py:1551: one dynamics/objects step without reward bookkeeping semantics
+        changes -- runs dtsim_step (which also refreshes done/reward, harmlessly)."""
+        self._sim.step(np.asarray(action, np.float64).reshape(1, 2))
+
+    def get_agent_info(self) -> dict:
+        info = {"action": list(self.last_action)}
+        if self.full_transparency:
+            lane, in_lane = self._f(_ffi.FIELD_LANE), bool(self._f(_ffi.FIELD_IN_LANE))
+            if in_lane:
+                info["lane_position"] = LanePosition(*[float(v) for v in lane]).as_json_dict()
+            pos = self.cur_pos
+            w = self._f(_ffi.FIELD_WHEELS)
+            info["robot_speed"] = self.speed
+            info["proximity_penalty"] = float(self._f(_ffi.FIELD_PROX))
+            info["cur_pos"] = [float(pos[0]), float(pos[1]), float(pos[2])]
+            info["cur_angle"] = self.cur_angle
+            info["wheel_velocities"] = [float(w[0]) * self.robot_speed, float(w[1]) * self.robot_speed]
+            info["timestamp"] = self.timestamp
+            info["tile_coords"] = [int(v) for v in self._f(_ffi.FIELD_TILE)]
+        return {"Simulator": info}
+
+    def cartesian_from_weird(self, pos, angle) -> np.ndarray:
+        gx, gy, gz = pos
+        cp = [gx, self.grid_height * self.road_tile_size - gz]
+        c, s = math.cos(angle), math.sin(angle)
+        return np.array([[c, -s, cp[0]], [s, c, cp[1]], [0, 0, 1.0]])
+
+    def weird_from_cartesian(self, q):
+        return [q[0, 2], 0, self.grid_height * self.road_tile_size - q[1, 2]], math.atan2(q[1, 0], q[0, 0])
+
+
+# ---- module-level helpers of the reference (simulator.py:2056-2116) ------------------
+def get_dir_vec(cur_angle: float) -> np.ndarray:
+    return np.array([math.cos(cur_angle), 0, -math.sin(cur_angle)])
+
+
+def get_right_vec(cur_angle: float) -> np.ndarray:
+    return np.array([math.sin(cur_angle), 0, math.cos(cur_angle)])
+
+
+def _actual_center(pos, angle):
+    return pos + (CAMERA_FORWARD_DIST - (ROBOT_LENGTH / 2)) * get_dir_vec(angle)
+
+
+def get_agent_corners(pos, angle):
+    """simulator.py:2112 / collision.py:9 -- pure formatting of the pose for callers that pass
+    the corners back into Simulator._collision (run_tests.py:50); no hot-path arithmetic."""
+    c = _actual_center(np.asarray(pos, dtype=np.float64), angle)
+    f, r = get_dir_vec(angle), get_right_vec(angle)
+    hw, hl = 0.5 * ROBOT_WIDTH, 0.5 * ROBOT_LENGTH
+    return np.array([c - hw * r - hl * f, c + hw * r - hl * f, c + hw * r + hl * f, c - hw * r + hl * f])[:, [0, 2]]
+
+
+def _update_pos(self, action):
+    """simulator.py:2076: advance the dynamics by one delta_time on the device; returns (pos, angle)."""
+    self._sim.step(np.asarray(action, np.float64).reshape(1, 2))
+    return self.cur_pos, self.cur_angle

@@ -1,0 +1,155 @@
+"""`not gpu`: the C-ABI library loads and exports every symbol include/dtsim.h declares,
+struct layouts agree between the header (gcc) and ctypes, the no-GPU failure is loud, and the
+host-side preparation (maps, reset RNG order, assets, distortion) is right.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dtsim import _ffi, assets, maps, reset as R
+from dtsim import distortion as pdist
+from oracle import sim as osim
+from util import EXT, make_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "dtsim.h")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()
+    src = open(HDR).read()
+    declared = set(re.findall(r"\b(dtsim_[a-z_]+)\s*\(", src))
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.dtsim_abi_version() == _ffi.ABI_VERSION
+
+
+def test_struct_layouts_match_header(tmp_path):
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include "dtsim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                    'sizeof(dtsim_config),sizeof(dtsim_object),sizeof(dtsim_map),sizeof(dtsim_init_state),sizeof(dtsim_probe),'
+                    'sizeof(dtsim_texture),sizeof(dtsim_mesh),offsetof(dtsim_probe,prox),offsetof(dtsim_init_state,light_pos));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_ffi.Config), C.sizeof(_ffi.Object), C.sizeof(_ffi.Map), C.sizeof(_ffi.InitState), C.sizeof(_ffi.Probe),
+            C.sizeof(_ffi.Texture), C.sizeof(_ffi.Mesh), _ffi.Probe.prox.offset, _ffi.InitState.light_pos.offset]
+    assert got == want
+    assert _ffi.probe_dtype().itemsize == C.sizeof(_ffi.Probe)
+    # header constants mirrored in Python
+    src = open(HDR).read()
+    for name, val in [("DTSIM_MAX_DYNAMIC", _ffi.MAX_DYNAMIC), ("DTSIM_MAX_OBJECTS", _ffi.MAX_OBJECTS),
+                      ("DTSIM_MAX_DELAY", _ffi.MAX_DELAY), ("DTSIM_F_PROFILE", _ffi.F_PROFILE), ("DTSIM_E_NOGPU", _ffi.E_NOGPU)]:
+        m = re.search(rf"#define {name} \(?(-?\d+)u?\)?", src)
+        assert m and int(m.group(1)) == val, name
+
+
+def test_no_gpu_fails_loudly_and_bad_args_rejected():
+    import torch
+    lib = _ffi.load()
+    h = C.c_void_p()
+    cfg = _ffi.Config()
+    assert lib.dtsim_create(C.byref(cfg), C.byref(h)) == _ffi.E_INVALID      # struct_size 0
+    assert lib.dtsim_create(None, C.byref(h)) == _ffi.E_INVALID
+    assert lib.dtsim_render(None) == _ffi.E_INVALID and lib.dtsim_sync(None) == _ffi.E_INVALID
+    if not torch.cuda.is_available():
+        from dtsim import BatchedSimulator
+        with pytest.raises(_ffi.DtsimError) as ei:
+            BatchedSimulator("small_loop", 2, render=False)
+        assert ei.value.code == _ffi.E_NOGPU and "no CPU fallback" in str(ei.value)
+    with pytest.raises(_ffi.DtsimLibraryError):
+        _ffi.load("/nonexistent/libdtsim.so")
+
+
+@pytest.mark.parametrize("m", list(assets.MAPS))
+def test_map_tables_match_oracle_interpretation(m):
+    """Product host prep (dtsim/maps.py) vs the oracle's reference-pinned _interpret_map."""
+    mt = maps.interpret_map(assets.get_map(m), m)
+    om = osim.OracleMap(assets.get_map(m), EXT)
+    assert (mt.grid_w, mt.grid_h, mt.tile_size) == (om.grid_width, om.grid_height, om.tile_size)
+    assert mt.drivable_tiles == [t["coords"] for t in om.drivable_tiles]
+    for t in om.grid:
+        i, j = t["coords"]
+        idx = j * mt.grid_w + i
+        assert mt.tile_kind_names[idx] == t["kind"] and mt.tile_angle[idx] == t["angle"]
+        if t["drivable"]:
+            o, c = mt.tile_curve_off[idx], mt.tile_curve_cnt[idx]
+            assert np.array_equal(mt.curves3[o:o + c], t["curves"])
+            ch = t["curves"][:, -1, :] - t["curves"][:, 0, :]
+            ch = ch / np.linalg.norm(ch).reshape(1, -1)
+            assert np.array_equal(mt.curve_heads[o:o + c], ch[:, [0, 2]])
+    assert len(mt.objects) == len(om.objects)
+    for a, b in zip(mt.objects, om.objects):
+        assert np.array_equal(a.pos, b.pos) and a.angle == b.angle and a.scale == b.scale
+        assert np.array_equal(a.corners, b.obj_corners) and np.array_equal(a.norm, b.obj_norm)
+        assert a.safety_radius == b.safety_radius and a.static == b.static
+    f = mt.to_ffi({"duckie": 0, "*": 1})
+    assert f.n_curves == mt.curves.shape[0] and f.n_objects == len(mt.objects)
+
+
+@pytest.mark.parametrize("dr", [False, True])
+def test_reset_prefix_draw_order_matches_oracle(dr):
+    """Host RNG order (dtsim/reset.py) up to the spawn loop == oracle reset (reference-pinned)."""
+    for m in ("small_loop", "loop_only_duckies"):
+        mt = maps.interpret_map(assets.get_map(m), m)
+        for seed in (1, 2, 3):
+            es = R.EnvResetState(seed)
+            st, tile, vis = R.draw_prefix(es, mt, domain_rand=dr, camera_rand=False, dynamics_rand=True,
+                                          color_sky=list(R.BLUE_SKY), color_ground=(0.15, 0.15, 0.15),
+                                          num_tris_distractors=12, n_visible_draw=(), user_tile_start=None)
+            o = make_oracle(m, domain_rand=dr, seed=seed, dynamics_rand=True)
+            assert list(st.horizon_color) == [float(v) for v in o.horizon_color]
+            assert list(st.ground_color) == [float(v) for v in o.ground_color]
+            assert st.wheel_dist == float(o.wheel_dist) and st.dynamics_trim == float(o.randomization_settings["trim"][0])
+            assert st.cam_fov_y_deg == float(np.asarray(o.cam_fov_y).reshape(-1)[0])
+            assert list(st.light_ambient) == [float(v) for v in o.light_ambient[:3]]
+            # first attempt of the spawn loop == the oracle's first attempt; commit advances identically
+            blk = R.attempt_block(es, tile, mt.tile_size, k=o.spawn_attempts)
+            assert np.array_equal(blk[-1, :2], o.cur_pos[[0, 2]]) and blk[-1, 2] == o.cur_angle
+            R.commit_attempts(es, o.spawn_attempts)
+            assert es.np_random.bit_generator.state == o.np_random.bit_generator.state
+
+
+def test_assets_are_deterministic_and_well_formed():
+    t1, t2 = assets.make_texture("straight"), assets.make_texture("straight")
+    assert np.array_equal(t1, t2) and t1.shape == (256, 256, 4) and t1.dtype == np.uint8
+    assert np.array_equal(assets.gl_rows(t1)[0], t1[-1])
+    mesh = assets.get_mesh("duckie")
+    assert mesh.verts.dtype == np.float32 and mesh.verts.shape == mesh.normals.shape == mesh.colors.shape
+    assert mesh.min_coords.tolist() == [-0.5, 0.0, -0.34375] and mesh.max_coords.tolist() == [0.5, 1.0, 0.34375]
+    assert np.allclose(np.linalg.norm(mesh.normals, axis=-1), 1.0, atol=1e-5)
+    with pytest.raises(KeyError):
+        assets.get_map("udem1")
+
+
+def test_product_distortion_matches_golden_and_oracle():
+    from oracle import distortion as od
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_distortion.npz"))
+    px, py = pdist.distortion_maps(640, 480)
+    assert np.array_equal(np.rint(px.astype(np.float64)).astype(np.int16), g["sx_640x480"])
+    assert np.array_equal(np.rint(py.astype(np.float64)).astype(np.int16), g["sy_640x480"])
+    ox, oy = od.distortion_maps(84, 84)
+    p2x, p2y = pdist.distortion_maps(84, 84)
+    assert np.array_equal(ox, p2x) and np.array_equal(oy, p2y)
+    assert np.array_equal(pdist.optimal_new_camera_matrix(), od.new_camera_matrix())
+
+
+def test_dropin_facade_surface_imports_without_gpu():
+    import gym_duckietown
+    from gym_duckietown.envs import DuckietownEnv, MultiMapEnv
+    from gym_duckietown.simulator import (AGENT_SAFETY_RAD, Simulator, _actual_center, _update_pos, get_agent_corners,
+                                          get_dir_vec, get_right_vec)
+    from gym_duckietown.exceptions import InvalidMapException, NotInLane
+    assert AGENT_SAFETY_RAD == osim.AGENT_SAFETY_RAD
+    for name in ("reset", "step", "render", "seed", "close", "closest_curve_point", "get_lane_pos2", "get_grid_coords",
+                 "_get_tile", "_valid_pose", "_collision", "proximity_penalty2", "compute_reward", "_compute_done_reward",
+                 "update_physics", "get_agent_info"):
+        assert callable(getattr(Simulator, name)), name
+    assert issubclass(DuckietownEnv, Simulator) and callable(MultiMapEnv.reset)
+    assert np.array_equal(get_agent_corners(np.array([1.0, 0, 1.0]), 0.3), osim.get_agent_corners(np.array([1.0, 0, 1.0]), 0.3))
+    assert np.array_equal(_actual_center(np.array([1.0, 0, 1.0]), 0.3), osim.actual_center(np.array([1.0, 0, 1.0]), 0.3))

@@ -1,0 +1,80 @@
+"""`not gpu`: the N>1 path (env sharding + frame/reward exchange) with world_size 2 on gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dtsim import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_frames(lo, hi, h=6, w=8):
+    """Deterministic per-env 'frame': what the raster would write for global env e."""
+    e = torch.arange(lo, hi, dtype=torch.int64).view(-1, 1, 1, 1)
+    yy = torch.arange(h).view(1, -1, 1, 1)
+    xx = torch.arange(w).view(1, 1, -1, 1)
+    cc = torch.arange(3).view(1, 1, 1, -1)
+    return ((e * 7 + yy * 3 + xx * 5 + cc * 11) % 251).to(torch.uint8)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(rank, world, total)
+        frames = _fake_frames(lo, hi)
+        allf = sharding.gather_batch(frames, world)                 # all-gather
+        ok = bool(torch.equal(allf, _fake_frames(0, total)))
+        rew = torch.arange(lo, hi, dtype=torch.float64) * 0.5
+        root = sharding.gather_batch(rew, world, dst=0)             # gather to the learner
+        if rank == 0:
+            ok = ok and bool(torch.equal(root, torch.arange(0, total, dtype=torch.float64) * 0.5))
+        else:
+            ok = ok and root is None
+        # per-env seeds are a function of the GLOBAL env index
+        seeds = [sharding.env_seed(1000, e) for e in range(lo, hi)]
+        ok = ok and seeds == list(range(1000 + lo, 1000 + hi))
+        acts = np.arange(2 * total * 2, dtype=np.float32).reshape(2, total, 2)
+        ok = ok and np.array_equal(acts[:, lo:hi], np.ascontiguousarray(acts[..., lo:hi, :]))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_sharding():
+    world, total = 2, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_range_properties():
+    assert sharding.shard_range(0, 8, 32768) == (0, 4096) and sharding.shard_range(7, 8, 32768) == (28672, 32768)
+    cover = []
+    for r in range(4):
+        lo, hi = sharding.shard_range(r, 4, 16)
+        cover += list(range(lo, hi))
+    assert cover == list(range(16))
+    with pytest.raises(ValueError):
+        sharding.shard_range(0, 3, 10)
+    assert sharding.env_seed(None, 5) is None
