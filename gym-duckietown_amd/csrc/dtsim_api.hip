@@ -86,6 +86,10 @@ struct dtsim {
   RenderMapDev* d_rmaps = nullptr;
   uint32_t* d_rtiles = nullptr;
   TileLds* d_tilerecs = nullptr;
+  ScreenTri* d_stris = nullptr;
+  ObjEnv* d_objenv = nullptr;
+  ObjBox* d_objbox = nullptr;
+  int max_tris = 0;
   int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
   void* d_envcam = nullptr;
@@ -239,7 +243,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -285,7 +289,11 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
     const dtsim_mesh& ms = meshes[m];
     if (ms.n_tris < 0 || (ms.n_tris > 0 && (!ms.verts || !ms.normals || !ms.colors)))
       return fail(DTSIM_E_INVALID, "mesh %d: null arrays", m);
-    MeshDev d{ms.n_tris, (int32_t)tris.size()};
+    MeshDev d{};
+    d.n_tris = ms.n_tris; d.off = (int32_t)tris.size();
+    for (int k = 0; k < 3; ++k) { d.mn[k] = 1e30f; d.mx[k] = -1e30f; }
+    for (int t = 0; t < ms.n_tris * 3; ++t)
+      for (int k = 0; k < 3; ++k) { d.mn[k] = std::min(d.mn[k], ms.verts[t * 3 + k]); d.mx[k] = std::max(d.mx[k], ms.verts[t * 3 + k]); }
     for (int t = 0; t < ms.n_tris; ++t) {
       TriDev td;
       memcpy(td.v, ms.verts + (size_t)t * 9, 36);
@@ -376,7 +384,9 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     double* ob = reinterpret_cast<double*>(&b[hd.off_objs]);
     int si = 0, di = 0;
     RenderMapDev& rm = rmaps[mi];
-    rm.grid_w = mp.grid_w; rm.grid_h = mp.grid_h; rm.n_obj = mp.n_objects; rm.pad = 0;
+    rm.grid_w = mp.grid_w; rm.grid_h = mp.grid_h; rm.n_obj = mp.n_objects; rm.n_tris = 0;
+    for (int o = 0; o < mp.n_objects; ++o)
+      if (mp.objects[o].mesh_id >= 0 && mp.objects[o].mesh_id < (int)h->h_meshes.size()) rm.n_tris += h->h_meshes[mp.objects[o].mesh_id].n_tris;
     rm.tile_size = (float)mp.tile_size; rm.inv_tile_size = (float)(1.0 / mp.tile_size);
     rm.tile_off = (int32_t)rtiles.size(); rm.obj_off = (int32_t)robjs.size();
     for (int t = 0; t < nt; ++t) {
@@ -444,6 +454,16 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   h->d_tilerecs = nullptr;
   HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
   if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));
+  if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
+  if (h->d_objenv) { (void)hipFree(h->d_objenv); h->d_objenv = nullptr; }
+  if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
+  h->max_tris = 0;
+  for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
+  if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
+    HIPCHK(hipMalloc(&h->d_stris, sizeof(ScreenTri) * (size_t)h->max_tris * h->N));
+    HIPCHK(hipMalloc(&h->d_objenv, sizeof(ObjEnv) * (size_t)h->N));
+    HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
+  }
   h->n_tilerecs = (int)trecs.size();
   h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
   HIPCHK(hipMalloc(&h->d_blobs, blobs.size() * 8));
@@ -583,6 +603,7 @@ int dtsim_render(dtsim_t* h) {
   R.frames = h->frames; R.lut = h->d_lut; R.texels = h->d_texels; R.tex = h->d_tex;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
+  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox;
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);

@@ -105,11 +105,11 @@ void dt_launch_query(hipStream_t s, const SimArrays& A, const MapSet& M, const S
 
 // ---- raster -----------------------------------------------------------------
 struct TexDev { int32_t w, h, off, pad; };   // off: texel offset into the texel pool; storage is (h+1) x (w+1), padded for REPEAT
-struct MeshDev { int32_t n_tris, off; };     // off: triangle offset into the triangle pool
+struct MeshDev { int32_t n_tris, off; float mn[3], mx[3]; };   // off: triangle offset into the pool; model-space AABB
 struct TriDev { float v[3][3]; float n[3][3]; float c[3][3]; };
 
 struct RenderMapDev {       // per map, raster view of the grid + objects
-  int32_t grid_w, grid_h, n_obj, pad;
+  int32_t grid_w, grid_h, n_obj, n_tris;   // n_tris: total mesh triangles of the map's objects
   float tile_size, inv_tile_size;
   int32_t tile_off;         // offset into tile table (uint32 per tile: tex | angle<<8 | present<<15)
   int32_t obj_off;          // offset into object-instance table
@@ -128,6 +128,18 @@ struct alignas(16) TileLds { uint32_t tex_off, flags; float mxx, mxz, ox, myx, m
 static_assert(sizeof(TileLds) == 32, "TileLds is 32 bytes");
 #define DTSIM_LDS_TILES 1024   // raster tile records of all maps together (32 KB of LDS)
 
+// One mesh triangle of one env after model/view/projection and per-vertex lighting
+// (objects.py:123-148, objmesh.py:360-375): rectilinear pixel coordinates, 1/w, lit colour/w.
+struct alignas(16) ScreenTri {
+  float sx[3], sy[3], iw[3];
+  float cw[3][3];            // per-vertex lit colour (0..255) divided by w
+  float bx0, bx1, by0, by1;  // pixel bounding box (+-1 px)
+  float inv_area;            // 0 => culled (behind the near plane / degenerate / invisible)
+};
+static_assert(sizeof(ScreenTri) == 96, "ScreenTri is 96 bytes");
+struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
+struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };          // screen box + triangle range of one object
+
 struct RenderParams {
   int32_t N, W, H, distortion;
   int32_t domain_rand, n_maps, n_tile_recs, no_msaa;   // no_msaa: profiling ablation only (DTSIM_RASTER_NO_MSAA=1)
@@ -143,6 +155,11 @@ struct RenderParams {
   const MeshDev* meshes;
   const TriDev* tris;
   void* envcam;                 // [N] EnvCam scratch written by the setup kernel
+  // mesh objects: per-env screen-space triangles written by the object setup kernel
+  int32_t max_tris, pad2;       // triangle slots per env (max over maps), 0 = no objects anywhere
+  ScreenTri* stris;             // [N][max_tris]
+  ObjEnv* objenv;               // [N]
+  ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

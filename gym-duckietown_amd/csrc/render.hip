@@ -139,6 +139,129 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
   out[e] = c;
 }
 
+// ---- mesh objects -> per-env screen-space triangles ------------------------------------
+// One workgroup per env.  WorldObj.render (objects.py:123-148): T(pos) S(scale) Ry(y_rot), mesh
+// chunks with per-vertex Kd colour (objmesh.py:241-293), GL per-vertex lighting (unit normals,
+// DESIGN.md "Render spec"), projected to rectilinear pixel coordinates.
+__global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams) {
+  const int e = blockIdx.x;
+  const int tid = threadIdx.x;
+  const size_t N = A.N;
+  const EnvCam c = cams[e];
+  const RenderMapDev m = R.maps[c.map_id];
+  ScreenTri* out = R.stris + (size_t)e * R.max_tris;
+  if (tid < m.n_obj) {                     // per-object screen box from the 8 corners of the mesh AABB
+    const ObjInstDev oi = R.objs[m.obj_off + tid];
+    ObjBox ob;
+    ob.bx0 = 1e30f; ob.bx1 = -1e30f; ob.by0 = 1e30f; ob.by1 = -1e30f; ob.first = 0; ob.count = 0; ob.pad[0] = ob.pad[1] = 0;
+    for (int o = 0; o < tid; ++o) { const int mid = R.objs[m.obj_off + o].mesh_id; ob.first += mid >= 0 ? R.meshes[mid].n_tris : 0; }
+    if (oi.mesh_id >= 0 && A.ob_visible[(size_t)tid * N + e]) {
+      const MeshDev md = R.meshes[oi.mesh_id];
+      ob.count = md.n_tris;
+      float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
+      if (oi.dyn_slot >= 0) {
+        px = (float)A.ob_cx[(size_t)oi.dyn_slot * N + e]; pz = (float)A.ob_cz[(size_t)oi.dyn_slot * N + e];
+        yrot = (float)A.ob_yrot[(size_t)oi.dyn_slot * N + e];
+      }
+      const float ang = yrot * 0.017453292519943295f, co = cosf(ang), so = sinf(ang);
+      int behind = 0;
+      for (int k = 0; k < 8; ++k) {
+        const float mx = ((k & 1) ? md.mx[0] : md.mn[0]) * oi.scale, my = ((k & 2) ? md.mx[1] : md.mn[1]) * oi.scale;
+        const float mz = ((k & 4) ? md.mx[2] : md.mn[2]) * oi.scale;
+        const float rx = (mx * co + mz * so + px) - c.Cx, ry = (my + py) - c.Cy, rz = (-mx * so + mz * co + pz) - c.Cz;
+        const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
+        const float ye = ry * c.cth - zla * c.sth, ze = ry * c.sth + zla * c.cth;
+        const float w = -ze;
+        if (w <= NEAR_Z) { ++behind; continue; }
+        const float sx = (xla / w / c.tx + 1.f) * 0.5f * (float)R.W, sy = (1.f - ye / w / c.ty) * 0.5f * (float)R.H;
+        ob.bx0 = fminf(ob.bx0, sx); ob.bx1 = fmaxf(ob.bx1, sx); ob.by0 = fminf(ob.by0, sy); ob.by1 = fmaxf(ob.by1, sy);
+      }
+      if (behind == 8) ob.count = 0;                                                      // entirely behind the camera
+      else if (behind) { ob.bx0 = -1e30f; ob.bx1 = 1e30f; ob.by0 = -1e30f; ob.by1 = 1e30f; }   // straddles the near plane: conservative
+      if (ob.bx1 < 0.f || ob.bx0 > (float)R.W || ob.by1 < 0.f || ob.by0 > (float)R.H) ob.count = 0;   // off screen
+      ob.bx0 -= 1.5f; ob.bx1 += 1.5f; ob.by0 -= 1.5f; ob.by1 += 1.5f;
+    }
+    R.objbox[(size_t)e * DTSIM_MAX_OBJECTS + tid] = ob;
+  }
+  float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;
+  int obj = 0, obj_first = 0;              // walk the object list as t grows (t is monotone per thread)
+  for (int t = tid; t < m.n_tris; t += 256) {
+    ObjInstDev oi = R.objs[m.obj_off + obj];
+    int nt = oi.mesh_id >= 0 ? R.meshes[oi.mesh_id].n_tris : 0;
+    while (t >= obj_first + nt) {
+      obj_first += nt; ++obj;
+      oi = R.objs[m.obj_off + obj];
+      nt = oi.mesh_id >= 0 ? R.meshes[oi.mesh_id].n_tris : 0;
+    }
+    const TriDev td = R.tris[R.meshes[oi.mesh_id].off + (t - obj_first)];
+    float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
+    if (oi.dyn_slot >= 0) {               // DuckieObj: pos = center, y_rot wiggles (objects.py:408-410)
+      px = (float)A.ob_cx[(size_t)oi.dyn_slot * N + e]; pz = (float)A.ob_cz[(size_t)oi.dyn_slot * N + e];
+      yrot = (float)A.ob_yrot[(size_t)oi.dyn_slot * N + e];
+    }
+    const bool visible = A.ob_visible[(size_t)obj * N + e] != 0;
+    const float ang = yrot * 0.017453292519943295f;
+    const float co = cosf(ang), so = sinf(ang);
+    ScreenTri st;
+    bool ok = visible;
+    float w[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const float mx = td.v[v][0] * oi.scale, my = td.v[v][1] * oi.scale, mz = td.v[v][2] * oi.scale;
+      const float rx = (mx * co + mz * so + px) - c.Cx, ry = (my + py) - c.Cy, rz = (-mx * so + mz * co + pz) - c.Cz;
+      const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
+      const float xe = xla, ye = ry * c.cth - zla * c.sth, ze = ry * c.sth + zla * c.cth;
+      w[v] = -ze;
+      ok = ok && (w[v] > NEAR_Z);
+      // normal: Ry(y_rot) then view rotation, normalised
+      const float nwx = td.n[v][0] * co + td.n[v][2] * so, nwy = td.n[v][1], nwz = -td.n[v][0] * so + td.n[v][2] * co;
+      const float nxl = nwx * c.sa + nwz * c.ca, nzl = -(nwx * c.ca - nwz * c.sa);
+      float nex = nxl, ney = nwy * c.cth - nzl * c.sth, nez = nwy * c.sth + nzl * c.cth;
+      const float ninv = rsqrtf(nex * nex + ney * ney + nez * nez);
+      nex *= ninv; ney *= ninv; nez *= ninv;
+      float ndl;
+      if (c.L[3] == 0.f) ndl = nex * c.L[0] + ney * c.L[1] + nez * c.L[2];
+      else {
+        const float lx = c.L[0] - xe, ly = c.L[1] - ye, lz = c.L[2] - ze;
+        ndl = (nex * lx + ney * ly + nez * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+      }
+      ndl = fmaxf(ndl, 0.f);
+      const float iw = 1.f / w[v];
+      st.iw[v] = iw;
+      st.sx[v] = (xe * iw / c.tx + 1.f) * 0.5f * (float)R.W;
+      st.sy[v] = (1.f - ye * iw / c.ty) * 0.5f * (float)R.H;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        st.cw[v][k] = fminf(td.c[v][k] * (c.base[k] + c.dif[k] * ndl), 1.f) * 255.f * iw;
+    }
+    const float area = (st.sx[1] - st.sx[0]) * (st.sy[2] - st.sy[0]) - (st.sx[2] - st.sx[0]) * (st.sy[1] - st.sy[0]);
+    ok = ok && (area != 0.f);
+    st.inv_area = ok ? 1.f / area : 0.f;
+    st.bx0 = fminf(fminf(st.sx[0], st.sx[1]), st.sx[2]) - 1.f; st.bx1 = fmaxf(fmaxf(st.sx[0], st.sx[1]), st.sx[2]) + 1.f;
+    st.by0 = fminf(fminf(st.sy[0], st.sy[1]), st.sy[2]) - 1.f; st.by1 = fmaxf(fmaxf(st.sy[0], st.sy[1]), st.sy[2]) + 1.f;
+    if (ok && (st.bx1 < 0.f || st.bx0 > (float)R.W || st.by1 < 0.f || st.by0 > (float)R.H)) { ok = false; st.inv_area = 0.f; }
+    out[t] = st;
+    if (ok) { bx0 = fminf(bx0, st.bx0); bx1 = fmaxf(bx1, st.bx1); by0 = fminf(by0, st.by0); by1 = fmaxf(by1, st.by1); }
+  }
+  __shared__ float red[4][256];
+  red[0][tid] = bx0; red[1][tid] = bx1; red[2][tid] = by0; red[3][tid] = by1;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if (tid < sft) {
+      red[0][tid] = fminf(red[0][tid], red[0][tid + sft]); red[1][tid] = fmaxf(red[1][tid], red[1][tid + sft]);
+      red[2][tid] = fminf(red[2][tid], red[2][tid + sft]); red[3][tid] = fmaxf(red[3][tid], red[3][tid + sft]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ObjEnv oe;
+    oe.n_tris = red[1][0] >= red[0][0] ? m.n_tris : 0;
+    oe.bx0 = red[0][0]; oe.bx1 = red[1][0]; oe.by0 = red[2][0]; oe.by1 = red[3][0];
+    oe.n_obj = m.n_obj; oe.pad[0] = oe.pad[1] = 0;
+    R.objenv[e] = oe;
+  }
+}
+
 // ---- per-map constants the raster needs (wave-uniform) -------------------------------
 struct MapU { float its, ts, gwf, ghf; int gw, gh, tile_off; };
 
@@ -273,14 +396,40 @@ __device__ inline void shade(const EnvCam& c, const MapU& m, const RenderParams&
   tile_color(R, tiles[m.tile_off + h.tj * m.gw + h.ti], fx, fz, I, out);
 }
 
-// exact 4-sample resolve of one pixel (centre NDC nx, ny)
+// exact 4-sample resolve of one pixel (centre NDC nx, ny): coverage and depth per sample,
+// shading once per primitive at the pixel centre; mesh triangles z-buffered against the planes.
+template <bool OBJ>
 __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const RenderParams& R,
-                                            const TileLds* tiles, float nx, float ny) {
+                                      const TileLds* tiles, float nx, float ny, const ScreenTri* tris,
+                                      const ObjBox* boxes, int n_obj) {
   // standard 4x rotated-grid pattern, offsets in pixels (+x right, +y down)
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   const Ray rc = make_ray(nx, ny, c.tx, c.ty, c.sth, c.cth);
+  // mesh pass: nearest covering triangle per sample
+  float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+  int tbest[4] = {-1, -1, -1, -1};
+  const float pcx = (nx + 1.f) * 0.5f * (float)R.W, pcy = (1.f - ny) * 0.5f * (float)R.H;   // pixel centre, px
+  for (int o = 0; OBJ && o < n_obj; ++o) {
+   const ObjBox ob = boxes[o];
+   if (ob.count == 0 || pcx < ob.bx0 || pcx > ob.bx1 || pcy < ob.by0 || pcy > ob.by1) continue;
+   for (int t = ob.first; t < ob.first + ob.count; ++t) {
+    const ScreenTri& st = tris[t];
+    if (st.inv_area == 0.f || pcx < st.bx0 || pcx > st.bx1 || pcy < st.by0 || pcy > st.by1) continue;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float qx = pcx + ox[s], qy = pcy + oy[s];
+      const float b0 = ((st.sx[1] - qx) * (st.sy[2] - qy) - (st.sx[2] - qx) * (st.sy[1] - qy)) * st.inv_area;
+      const float b1 = ((st.sx[2] - qx) * (st.sy[0] - qy) - (st.sx[0] - qx) * (st.sy[2] - qy)) * st.inv_area;
+      const float b2 = 1.f - b0 - b1;
+      if (b0 >= 0.f && b1 >= 0.f && b2 >= 0.f) {
+        const float d = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
+        if (d < zbest[s] && d >= NEAR_Z && d <= FAR_Z) { zbest[s] = d; tbest[s] = t; }
+      }
+    }
+   }
+  }
   float acc[3] = {0.f, 0.f, 0.f};
   int pc = -1, pi = 0, pj = 0;
   float col[3] = {0.f, 0.f, 0.f};
@@ -288,6 +437,20 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
   for (int s = 0; s < 4; ++s) {
     const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
     const Hit hs = classify(c, m, tiles, rs);
+    const float zplane = hs.cls == CLS_SKY ? 3.0e38f : hs.t;
+    if (OBJ && tbest[s] >= 0 && zbest[s] < zplane) {      // depth func LESS
+      const ScreenTri& st = tris[tbest[s]];
+      const float b0 = ((st.sx[1] - pcx) * (st.sy[2] - pcy) - (st.sx[2] - pcx) * (st.sy[1] - pcy)) * st.inv_area;
+      const float b1 = ((st.sx[2] - pcx) * (st.sy[0] - pcy) - (st.sx[0] - pcx) * (st.sy[2] - pcy)) * st.inv_area;
+      const float b2 = 1.f - b0 - b1;
+      const float inv = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float v = (b0 * st.cw[0][k] + b1 * st.cw[1][k] + b2 * st.cw[2][k]) * inv;
+        acc[k] += fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f);
+      }
+      continue;
+    }
     if (!(hs.cls == pc && (hs.cls != CLS_TILE || (hs.ti == pi && hs.tj == pj)))) {
       shade(c, m, R, tiles, hs, rc, col);
       pc = hs.cls; pi = hs.ti; pj = hs.tj;
@@ -339,6 +502,7 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 
 // Resolve up to 64 queued edge pixels (one per lane) with the exact 4-sample path and patch
 // them into the frame.  Queue entry = (env-in-chunk << 8) | pixel-in-wavefront.
+template <bool OBJ>
 __device__ inline void resolve_edges(const RenderParams& R, const EnvCam* s_cams, const TileLds* s_tiles,
                                      const uint16_t* w_queue, int first, int count, int lane, int e0, int wbase,
                                      int npix) {
@@ -348,7 +512,16 @@ __device__ inline void resolve_edges(const RenderParams& R, const EnvCam* s_cams
     const EnvCam c = s_cams[el];
     const MapU m = map_u(R.maps[c.map_id]);
     const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
-    const uint32_t v = shade_msaa(c, m, R, s_tiles, l.x, l.y);
+    int n_obj = 0;
+    const ScreenTri* tris = nullptr;
+    const ObjBox* boxes = nullptr;
+    if (OBJ) {
+      const ObjEnv oe = R.objenv[e0 + el];
+      n_obj = oe.n_tris > 0 ? oe.n_obj : 0;
+      tris = R.stris + (size_t)(e0 + el) * R.max_tris;
+      boxes = R.objbox + (size_t)(e0 + el) * DTSIM_MAX_OBJECTS;
+    }
+    const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, boxes, n_obj);
     uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
     dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
   }
@@ -356,7 +529,7 @@ __device__ inline void resolve_edges(const RenderParams& R, const EnvCam* s_cams
 
 #define QCAP (WAVE_PIX + 64)
 
-template <bool DR>
+template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
                                                uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
                                                const float4* __restrict__ lut, const RenderMapDev* __restrict__ maps,
@@ -405,6 +578,20 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
       pv[k] = pix_inv(nx[k], ny[k], ok[k], cs.tx, cs.ty, cs.sth, cs.cth, cs.Cy, cs.L, ex_n, ey_n);
+  }
+
+  // source-pixel bounding box of this wavefront's pixels (for the mesh-object test)
+  float spx[PPT], spy[PPT];
+  float wbx0 = 1e30f, wbx1 = -1e30f, wby0 = 1e30f, wby1 = -1e30f;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    spx[k] = (nx[k] + 1.f) * 0.5f * (float)R.W; spy[k] = (1.f - ny[k]) * 0.5f * (float)R.H;
+    if (ok[k]) { wbx0 = fminf(wbx0, spx[k]); wbx1 = fmaxf(wbx1, spx[k]); wby0 = fminf(wby0, spy[k]); wby1 = fmaxf(wby1, spy[k]); }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    wbx0 = fminf(wbx0, __shfl_xor(wbx0, d)); wbx1 = fmaxf(wbx1, __shfl_xor(wbx1, d));
+    wby0 = fminf(wby0, __shfl_xor(wby0, d)); wby1 = fmaxf(wby1, __shfl_xor(wby1, d));
   }
 
   uint16_t* w_queue = s_queue + wave * QCAP;
@@ -522,6 +709,22 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
       }
     }
 
+    // ---- mesh objects: every pixel inside the union box of the env's projected triangles
+    // takes the exact path (which z-buffers the triangles per sample)
+    if (OBJ) {
+      const ObjEnv oe = R.objenv[e];                 // wave-uniform
+      if (oe.n_tris > 0 && wbx1 >= oe.bx0 && wbx0 <= oe.bx1 && wby1 >= oe.by0 && wby0 <= oe.by1) {
+        const ObjBox* boxes = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
+        for (int o = 0; o < oe.n_obj; ++o) {
+          const ObjBox ob = boxes[o];                // wave-uniform
+          if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
+#pragma unroll
+          for (int k = 0; k < PPT; ++k)
+            if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge_mask |= 1u << k;
+        }
+      }
+    }
+
     uint8_t* dst = frames + ((size_t)e * npix + p0) * 3;
     const uint32_t w0 = px[0] | (px[1] << 24);
     const uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
@@ -562,7 +765,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         // patch stores must land after the fast-path stores of the same pixels
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int first = 0;
-        while (qn - first >= 64) { resolve_edges(R, s_cams, s_tiles, w_queue, first, 64, lane, e0, wbase, npix); first += 64; }
+        while (qn - first >= 64) { resolve_edges<OBJ>(R, s_cams, s_tiles, w_queue, first, 64, lane, e0, wbase, npix); first += 64; }
         // move the remainder (< 64 entries) to the front
         const int rem = qn - first;
         uint16_t keep = 0;
@@ -581,7 +784,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    resolve_edges(R, s_cams, s_tiles, w_queue, 0, qn, lane, e0, wbase, npix);
+    resolve_edges<OBJ>(R, s_cams, s_tiles, w_queue, 0, qn, lane, e0, wbase, npix);
   }
 }
 
@@ -591,14 +794,16 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand,
                      (float)R.W / (float)R.H, cams);
+  if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
   const int npix = R.W * R.H;
   const int n_strips = (npix + STRIP - 1) / STRIP;
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds) + ENVS_PER_BLOCK * sizeof(EnvCam) + (RB / 64) * QCAP * 2;
-  if (R.domain_rand)
-    hipLaunchKernelGGL(k_raster<true>, dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels,
-                       reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs);
-  else
-    hipLaunchKernelGGL(k_raster<false>, dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels,
-                       reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs);
+#define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
+  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels, \
+                     reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs)
+  const bool obj = R.max_tris > 0;
+  if (R.domain_rand) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }
+  else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
+#undef LAUNCH_RASTER
 }
