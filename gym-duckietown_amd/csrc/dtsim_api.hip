@@ -89,6 +89,8 @@ struct dtsim {
   ScreenTri* d_stris = nullptr;
   ObjEnv* d_objenv = nullptr;
   ObjBox* d_objbox = nullptr;
+  uint16_t* d_queue = nullptr;
+  int32_t* d_qcount = nullptr;
   int max_tris = 0;
   int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
@@ -222,6 +224,12 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     h->frames = h->frames_own;
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
     if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * 128);
+    {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
+      const size_t npix = (size_t)cfg->cam_height * cfg->cam_width;
+      const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 15) / 16);
+      if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * 256 * 16 * sizeof(uint16_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, n_wg * 4 * sizeof(int32_t));
+    }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
     if (!(cfg->flags & DTSIM_F_DISTORTION)) {
       // identity LUT: output pixel == rectilinear pixel
@@ -243,7 +251,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -603,7 +611,7 @@ int dtsim_render(dtsim_t* h) {
   R.frames = h->frames; R.lut = h->d_lut; R.texels = h->d_texels; R.tex = h->d_tex;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
-  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox;
+  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);

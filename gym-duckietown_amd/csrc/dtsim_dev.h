@@ -160,6 +160,8 @@ struct RenderParams {
   ScreenTri* stris;             // [N][max_tris]
   ObjEnv* objenv;               // [N]
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
+  uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
+  int32_t* qcount;              // [workgroups][4]
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

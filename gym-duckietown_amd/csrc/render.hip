@@ -491,7 +491,19 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
   p.lr = t * r.xe; p.lf = t * r.fwd;
   p.ndl = plane_ndl(L, sth, cth, r, t);
   const float rho = dy * inv;
-  p.mrg = 1.5f * (t * (ex + ey) + (fabsf(p.lr) + fabsf(p.lf)) * 1.34f * rho);
+  // World-space reach of the MSAA samples around the pixel-centre hit.  A sample offset
+  // (dx, dy) px moves the hit by  t*ex*dx  along `right` and, through the change of the ray
+  // parameter (kappa = rho/(1-rho) per full y-offset), by (lr, lf)*kappa*dy + t*ey*|sth|*dy along
+  // (right, forward).  The rotated-grid samples sit at (+-0.375, +-0.125) and (+-0.125, +-0.375):
+  // take the larger of the two reaches (ex/ey already carry the 0.375 and a 1% pad), +5%.
+  {
+    const float kappa = rho / fmaxf(1.f - rho, 0.25f);
+    const float ax_ = t * ex, ry_ = fabsf(p.lr) * kappa, fy_ = fabsf(p.lf) * kappa + t * ey * fabsf(sth);
+    const float third = 1.f / 3.f;
+    const float r1x = ax_ + third * ry_, r1f = third * fy_;          // (0.375, 0.125)
+    const float r2x = third * ax_ + ry_, r2f = fy_;                  // (0.125, 0.375)
+    p.mrg = 1.05f * sqrtf(fmaxf(r1x * r1x + r1f * r1f, r2x * r2x + r2f * r2f));
+  }
   const float tg = (Cy - GROUND_Y) * inv;
   if (t >= NEAR_Z && t <= FAR_Z) p.flags |= PF_TILE_OK;
   if (tg >= NEAR_Z && tg <= FAR_Z) p.flags |= PF_GROUND_OK;
@@ -500,44 +512,19 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
   return p;
 }
 
-// Resolve up to 64 queued edge pixels (one per lane) with the exact 4-sample path and patch
-// them into the frame.  Queue entry = (env-in-chunk << 8) | pixel-in-wavefront.
-template <bool OBJ>
-__device__ inline void resolve_edges(const RenderParams& R, const EnvCam* s_cams, const TileLds* s_tiles,
-                                     const uint16_t* w_queue, int first, int count, int lane, int e0, int wbase,
-                                     int npix) {
-  if (lane < count) {
-    const uint32_t ent = w_queue[first + lane];
-    const int el = ent >> 8, lp = ent & 255;
-    const EnvCam c = s_cams[el];
-    const MapU m = map_u(R.maps[c.map_id]);
-    const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
-    int n_obj = 0;
-    const ScreenTri* tris = nullptr;
-    const ObjBox* boxes = nullptr;
-    if (OBJ) {
-      const ObjEnv oe = R.objenv[e0 + el];
-      n_obj = oe.n_tris > 0 ? oe.n_obj : 0;
-      tris = R.stris + (size_t)(e0 + el) * R.max_tris;
-      boxes = R.objbox + (size_t)(e0 + el) * DTSIM_MAX_OBJECTS;
-    }
-    const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, boxes, n_obj);
-    uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
-    dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
-  }
-}
-
-#define QCAP (WAVE_PIX + 64)
+// Edge-pixel queue: one fixed region per (workgroup, wavefront) of the raster launch, worst-case
+// sized (every pixel of every env of the chunk), so appends need no atomics; entry =
+// (env-in-chunk << 8) | pixel-in-wavefront.  k_resolve drains the regions 64 entries at a time.
+#define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
 
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
                                                uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
                                                const float4* __restrict__ lut, const RenderMapDev* __restrict__ maps,
-                                               const TileLds* __restrict__ tile_recs) {
+                                               const TileLds* __restrict__ tile_recs, uint16_t* __restrict__ queue,
+                                               int32_t* __restrict__ qcount) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);                                   // [n_tile_recs]
-  EnvCam* s_cams = reinterpret_cast<EnvCam*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4)); // [ENVS_PER_BLOCK]
-  uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_cams + ENVS_PER_BLOCK);               // [4 waves][QCAP]
 
   const int tid = threadIdx.x;
   const int npix = R.W * R.H;
@@ -546,12 +533,9 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   const int chunk = blockIdx.x / n_strips;
   const int e0 = chunk * ENVS_PER_BLOCK;
   const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
-  {  // stage the raster tile records of every map and this chunk's EnvCams once per workgroup
+  {  // stage the raster tile records of every map once per workgroup
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tile_recs);
     for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
-    const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cams + e0);
-    uint32_t* cdst = reinterpret_cast<uint32_t*>(s_cams);
-    for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
   }
   __syncthreads();
 
@@ -594,7 +578,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     wby0 = fminf(wby0, __shfl_xor(wby0, d)); wby1 = fmaxf(wby1, __shfl_xor(wby1, d));
   }
 
-  uint16_t* w_queue = s_queue + wave * QCAP;
+  uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   int qn = 0;                                           // wave-uniform queue fill
   const bool full_store = (p0 + PPT <= npix) && ((npix & 3) == 0);
   const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
@@ -738,11 +722,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         if (p0 + k / 3 < npix) dst[k] = (uint8_t)(ws[k >> 2] >> (8 * (k & 3)));
     }
 
-    // ---- edge pixels: exact 4-sample resolve, deferred.  They are appended to a
-    // per-wavefront LDS queue ACROSS the env loop and resolved 64 at a time, so the
-    // expensive generic path always runs with every lane busy (wavefront-local LDS
-    // traffic only: DS operations of one wavefront execute in program order; the fences
-    // just stop the compiler from reordering across them).
+    // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
+    // register budget): append them to this wavefront's queue region.
     if (!R.no_msaa && __ballot(edge_mask != 0)) {    // wave-uniform
       const int n_mine = __popc(edge_mask);
       int incl = n_mine;                             // inclusive prefix sum over the lanes
@@ -758,33 +739,58 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
       for (int k = 0; k < PPT; ++k)
         if (edge_mask & (1u << k)) w_queue[pos++] = (uint16_t)(etag | (uint32_t)(lane * PPT + k));
       qn += total;
-      if (qn >= 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // patch stores must land after the fast-path stores of the same pixels
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int first = 0;
-        while (qn - first >= 64) { resolve_edges<OBJ>(R, s_cams, s_tiles, w_queue, first, 64, lane, e0, wbase, npix); first += 64; }
-        // move the remainder (< 64 entries) to the front
-        const int rem = qn - first;
-        uint16_t keep = 0;
-        if (lane < rem) keep = w_queue[first + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rem) w_queue[lane] = keep;
-        qn = rem;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
     }
   }
-  if (qn > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    resolve_edges<OBJ>(R, s_cams, s_tiles, w_queue, 0, qn, lane, e0, wbase, npix);
+  if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
+}
+
+// Exact 4-sample resolve of the queued edge pixels; same grid as the raster launch
+// (workgroup <-> strip x env-chunk, wavefront <-> 256-pixel span), stream-ordered after it,
+// so the byte patches land after the fast-path stores.
+template <bool OBJ>
+__global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
+                                                const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount) {
+  extern __shared__ uint32_t s_mem[];
+  TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
+  EnvCam* s_cams = reinterpret_cast<EnvCam*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4));
+  const int tid = threadIdx.x;
+  const int npix = R.W * R.H;
+  const int n_strips = (npix + STRIP - 1) / STRIP;
+  const int strip = blockIdx.x % n_strips, chunk = blockIdx.x / n_strips;
+  const int e0 = chunk * ENVS_PER_BLOCK, e1 = min(e0 + ENVS_PER_BLOCK, R.N);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int total_wg = qcount[blockIdx.x * (RB / 64)] + qcount[blockIdx.x * (RB / 64) + 1] +
+                       qcount[blockIdx.x * (RB / 64) + 2] + qcount[blockIdx.x * (RB / 64) + 3];
+  if (total_wg == 0) return;                         // workgroup-uniform
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.tile_recs);
+    for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
+    const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cams + e0);
+    uint32_t* cdst = reinterpret_cast<uint32_t*>(s_cams);
+    for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
+  }
+  __syncthreads();
+  const int wbase = strip * STRIP + wave * WAVE_PIX;
+  const int n = qcount[blockIdx.x * (RB / 64) + wave];
+  const uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
+  for (int q = lane; q < n; q += 64) {
+    const uint32_t ent = w_queue[q];
+    const int el = ent >> 8, lp = ent & 255;
+    const EnvCam c = s_cams[el];
+    const MapU m = map_u(R.maps[c.map_id]);
+    const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
+    int n_obj = 0;
+    const ScreenTri* tris = nullptr;
+    const ObjBox* boxes = nullptr;
+    if (OBJ) {
+      const ObjEnv oe = R.objenv[e0 + el];
+      n_obj = oe.n_tris > 0 ? oe.n_obj : 0;
+      tris = R.stris + (size_t)(e0 + el) * R.max_tris;
+      boxes = R.objbox + (size_t)(e0 + el) * DTSIM_MAX_OBJECTS;
+    }
+    const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, boxes, n_obj);
+    uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
+    dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
   }
 }
 
@@ -798,12 +804,18 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const int npix = R.W * R.H;
   const int n_strips = (npix + STRIP - 1) / STRIP;
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-  const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds) + ENVS_PER_BLOCK * sizeof(EnvCam) + (RB / 64) * QCAP * 2;
+  const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
+  const size_t lds2 = lds + ENVS_PER_BLOCK * sizeof(EnvCam);
+  const dim3 grid(n_strips * n_chunks);
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
-  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), dim3(n_strips * n_chunks), dim3(RB), lds, s, R, cams, R.frames, R.texels, \
-                     reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs)
+  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds, s, R, cams, R.frames, R.texels,               \
+                     reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   const bool obj = R.max_tris > 0;
   if (R.domain_rand) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
+  if (!R.no_msaa) {
+    if (obj) hipLaunchKernelGGL(k_resolve<true>, grid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    else hipLaunchKernelGGL(k_resolve<false>, grid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+  }
 }

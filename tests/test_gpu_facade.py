@@ -1,0 +1,94 @@
+"""GPU: the drop-in gym_duckietown surface (Simulator / DuckietownEnv / MultiMapEnv, N=1 views of the
+HIP library) behaves like the reference's API, incl. the properties run_tests.py asserts
+(run_tests.py:10-52), and the batched MultiMap slot alternation (envs/multimap_env.py:44-49)."""
+import numpy as np
+import pytest
+
+from dtsim import BatchedSimulator, _ffi
+from oracle import sim as osim
+from util import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_duckietown_env_api_and_run_tests_properties():
+    from gym_duckietown.envs import DuckietownEnv
+    from gym_duckietown.simulator import get_agent_corners, NotInLane
+    env = DuckietownEnv(map_name="small_loop_only_duckies", domain_rand=False, seed=4, camera_width=160,
+                        camera_height=120, full_transparency=True)
+    first_obs = env.reset()
+    assert first_obs.shape == env.observation_space.shape == (120, 160, 3) and first_obs.dtype == np.uint8
+    m0, m1 = first_obs.mean(), env.render("rgb_array").mean()
+    assert 0 < m0 < 255 and abs(m0 - m1) < 5                        # run_tests.py:17-22
+    o = make_oracle("small_loop_only_duckies", domain_rand=False, seed=4)
+    o.reset()                      # like the reference, the constructor already reset once
+    assert np.array_equal(env.cur_pos, o.cur_pos) and env.cur_angle == o.cur_angle
+    for i in range(10):
+        obs, reward, done, info = env.step(np.array([0.4, 0.3]))
+        r, d, _ = o.step_vel_steer(np.array([0.4, 0.3]))
+        assert obs.shape == first_obs.shape and done == d and abs(reward - r) < 1e-9
+        assert "Simulator" in info and "DuckietownEnv" in info and info["Simulator"]["tile_coords"] == list(o.map.get_grid_coords(o.cur_pos))
+        assert abs(info["Simulator"]["lane_position"]["dist"] - o.get_lane_pos2(o.cur_pos, o.cur_angle)[0]) < 1e-9
+    assert env.step_count == 10 and abs(env.timestamp - 10 / 30) < 1e-12
+    # query methods evaluate on the device and agree with the oracle
+    pos, ang = env.cur_pos, env.cur_angle
+    assert env._valid_pose(pos, ang) == o._valid_pose(pos, ang)
+    assert env._collision(get_agent_corners(pos, ang)) == o._collision(osim.get_agent_corners(pos, ang))
+    assert abs(env.proximity_penalty2(pos, ang) - o.proximity_penalty2(pos, ang)) < 1e-9
+    pt, tg = env.closest_curve_point(pos, ang)
+    opt, otg = o.closest_curve_point(pos, ang)
+    assert np.allclose(pt, opt, atol=1e-9) and np.allclose(tg, otg, atol=1e-9)
+    assert env.get_grid_coords(pos) == o.map.get_grid_coords(pos)
+    with pytest.raises(NotInLane):
+        env.get_lane_pos2(np.array([0.1, 0, 0.1]), 0.0)
+    assert env._get_tile(1, 1)["kind"] == "curve_right" and env._get_tile(9, 9) is None
+    d = env._compute_done_reward()
+    assert d.done_code == "in-progress" and isinstance(d.reward, float)
+    env.close()
+
+
+def test_spawn_is_collision_free_like_run_tests():
+    """run_tests.py:47-52: no collision at spawn nor after one step of [0.05, 0]."""
+    from gym_duckietown.envs import DuckietownEnv
+    from gym_duckietown.simulator import get_agent_corners
+    env = DuckietownEnv(map_name="loop_only_duckies", seed=0, camera_width=84, camera_height=84)
+    for _ in range(15):
+        env.reset()
+        assert not env._collision(get_agent_corners(env.cur_pos, env.cur_angle)), "collision on spawn"
+        env.step(np.array([0.05, 0]))
+        assert not env._collision(get_agent_corners(env.cur_pos, env.cur_angle)), "collision after one step"
+
+
+def test_multimap_env_round_robin():
+    from gym_duckietown.envs import MultiMapEnv
+    env = MultiMapEnv(domain_rand=False, seed=1, camera_width=84, camera_height=84)
+    names = []
+    for _ in range(4):
+        env.reset()
+        names.append(env.env_list[env.cur_env_idx].map_name)
+        obs, r, d, info = env.step(np.array([0.2, 0.0]))
+        assert obs.shape == (84, 84, 3)
+    assert names == ["small_loop_only_duckies", "loop_only_duckies"] * 2     # first reset selects index 1
+    env.close()
+
+
+def test_batched_multimap_slot_alternation():
+    """BASELINE config C5 semantics on one GPU: every slot alternates between the two maps per reset."""
+    N = 8
+    sim = BatchedSimulator(["loop_only_duckies", "small_loop_only_duckies"], N, map_cycle=True, domain_rand=False,
+                           seed=10, camera_width=84, camera_height=84)
+    assert (sim.read(_ffi.FIELD_MAP_ID) == 1).all()                # first reset -> index 1
+    oracles = [make_oracle("small_loop_only_duckies", domain_rand=False, seed=10 + e) for e in range(N)]
+    pos = sim.read(_ffi.FIELD_POS)
+    for e, o in enumerate(oracles):
+        assert np.array_equal(pos[e], o.cur_pos)
+    mask = np.zeros(N, np.uint8); mask[::2] = 1
+    sim.reset(mask)
+    assert sim.read(_ffi.FIELD_MAP_ID).tolist() == [0, 1] * (N // 2)
+    sim.step(np.full((N, 2), 0.3, np.float32))
+    sim.render()
+    fr = sim.frames_host()
+    assert fr.shape == (N, 84, 84, 3) and 0 < fr.mean() < 255
+    tiles = sim.read(_ffi.FIELD_TILE)
+    assert (tiles[::2, 0] < 8).all() and (tiles[1::2, 0] < 5).all()
+    sim.close()
