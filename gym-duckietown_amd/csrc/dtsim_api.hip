@@ -228,7 +228,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
       const size_t npix = (size_t)cfg->cam_height * cfg->cam_width;
       const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 15) / 16);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * 256 * 16 * sizeof(uint16_t));
-      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, n_wg * 4 * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8) * sizeof(int32_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
     if (!(cfg->flags & DTSIM_F_DISTORTION)) {
@@ -612,12 +612,33 @@ int dtsim_render(dtsim_t* h) {
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
+  R.dbg = nullptr;
+  if (getenv("DTSIM_DEBUG_QUEUE")) {
+    const size_t npix_ = (size_t)R.W * R.H;
+    const size_t n_wg_ = ((npix_ + 1023) / 1024) * (((size_t)h->N + 15) / 16);
+    R.dbg = h->d_qcount + n_wg_ * 4;
+    HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
+  }
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
     dt_launch_render(h->stream, h->A, R);
   }
   HIPCHK(hipGetLastError());
+  if (getenv("DTSIM_DEBUG_QUEUE")) {   // profiling aid: how many pixels took the exact MSAA path
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t npix = (size_t)R.W * R.H;
+    const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 15) / 16);
+    std::vector<int32_t> qc(n_wg * 4);
+    HIPCHK(hipMemcpy(qc.data(), h->d_qcount, qc.size() * 4, hipMemcpyDeviceToHost));
+    long long tot = 0, mx = 0;
+    for (int32_t v : qc) { tot += v; mx = std::max<long long>(mx, v); }
+    int32_t dbg[8];
+    HIPCHK(hipMemcpy(dbg, h->d_qcount + n_wg * 4, sizeof dbg, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[dtsim] resolve LDS triangle lists: %d (wg,env) pairs overflowed, %d fit, %d triangles staged\n", dbg[0], dbg[1], dbg[2]);
+    fprintf(stderr, "[dtsim] exact-path pixels: %lld of %zu (%.2f%%), max per wavefront region %lld\n", tot, npix * h->N,
+            100.0 * tot / (double)(npix * h->N), mx);
+  }
   return DTSIM_OK;
 }
 

@@ -131,10 +131,11 @@ static_assert(sizeof(TileLds) == 32, "TileLds is 32 bytes");
 // One mesh triangle of one env after model/view/projection and per-vertex lighting
 // (objects.py:123-148, objmesh.py:360-375): rectilinear pixel coordinates, 1/w, lit colour/w.
 struct alignas(16) ScreenTri {
+  float bx0, bx1, by0, by1;  // pixel bounding box (+-1 px); empty (bx0 > bx1) when culled
   float sx[3], sy[3], iw[3];
   float cw[3][3];            // per-vertex lit colour (0..255) divided by w
-  float bx0, bx1, by0, by1;  // pixel bounding box (+-1 px)
   float inv_area;            // 0 => culled (behind the near plane / degenerate / invisible)
+  int32_t index;             // position in the env's triangle order (z-buffer tie break)
 };
 static_assert(sizeof(ScreenTri) == 96, "ScreenTri is 96 bytes");
 struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
@@ -162,6 +163,7 @@ struct RenderParams {
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
   uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
   int32_t* qcount;              // [workgroups][4]
+  int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

@@ -62,6 +62,11 @@ struct alignas(16) EnvCam {          // 32 floats = 128 B, written by k_cam_setu
 };
 static_assert(sizeof(EnvCam) == 128, "EnvCam is 128 bytes");
 
+// coverage-only part of a ScreenTri kept in LDS by k_resolve<true>; the winner's colours are fetched
+// from global memory.
+struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; float pad; };
+static_assert(sizeof(TriCov) == 64, "TriCov is 64 bytes");
+
 namespace {
 
 // Camera intrinsics / light shared by all envs when DTSIM_F_DOMAIN_RAND is off
@@ -150,39 +155,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   const EnvCam c = cams[e];
   const RenderMapDev m = R.maps[c.map_id];
   ScreenTri* out = R.stris + (size_t)e * R.max_tris;
-  if (tid < m.n_obj) {                     // per-object screen box from the 8 corners of the mesh AABB
-    const ObjInstDev oi = R.objs[m.obj_off + tid];
-    ObjBox ob;
-    ob.bx0 = 1e30f; ob.bx1 = -1e30f; ob.by0 = 1e30f; ob.by1 = -1e30f; ob.first = 0; ob.count = 0; ob.pad[0] = ob.pad[1] = 0;
-    for (int o = 0; o < tid; ++o) { const int mid = R.objs[m.obj_off + o].mesh_id; ob.first += mid >= 0 ? R.meshes[mid].n_tris : 0; }
-    if (oi.mesh_id >= 0 && A.ob_visible[(size_t)tid * N + e]) {
-      const MeshDev md = R.meshes[oi.mesh_id];
-      ob.count = md.n_tris;
-      float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
-      if (oi.dyn_slot >= 0) {
-        px = (float)A.ob_cx[(size_t)oi.dyn_slot * N + e]; pz = (float)A.ob_cz[(size_t)oi.dyn_slot * N + e];
-        yrot = (float)A.ob_yrot[(size_t)oi.dyn_slot * N + e];
-      }
-      const float ang = yrot * 0.017453292519943295f, co = cosf(ang), so = sinf(ang);
-      int behind = 0;
-      for (int k = 0; k < 8; ++k) {
-        const float mx = ((k & 1) ? md.mx[0] : md.mn[0]) * oi.scale, my = ((k & 2) ? md.mx[1] : md.mn[1]) * oi.scale;
-        const float mz = ((k & 4) ? md.mx[2] : md.mn[2]) * oi.scale;
-        const float rx = (mx * co + mz * so + px) - c.Cx, ry = (my + py) - c.Cy, rz = (-mx * so + mz * co + pz) - c.Cz;
-        const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
-        const float ye = ry * c.cth - zla * c.sth, ze = ry * c.sth + zla * c.cth;
-        const float w = -ze;
-        if (w <= NEAR_Z) { ++behind; continue; }
-        const float sx = (xla / w / c.tx + 1.f) * 0.5f * (float)R.W, sy = (1.f - ye / w / c.ty) * 0.5f * (float)R.H;
-        ob.bx0 = fminf(ob.bx0, sx); ob.bx1 = fmaxf(ob.bx1, sx); ob.by0 = fminf(ob.by0, sy); ob.by1 = fmaxf(ob.by1, sy);
-      }
-      if (behind == 8) ob.count = 0;                                                      // entirely behind the camera
-      else if (behind) { ob.bx0 = -1e30f; ob.bx1 = 1e30f; ob.by0 = -1e30f; ob.by1 = 1e30f; }   // straddles the near plane: conservative
-      if (ob.bx1 < 0.f || ob.bx0 > (float)R.W || ob.by1 < 0.f || ob.by0 > (float)R.H) ob.count = 0;   // off screen
-      ob.bx0 -= 1.5f; ob.bx1 += 1.5f; ob.by0 -= 1.5f; ob.by1 += 1.5f;
-    }
-    R.objbox[(size_t)e * DTSIM_MAX_OBJECTS + tid] = ob;
-  }
   float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;
   int obj = 0, obj_first = 0;              // walk the object list as t grows (t is monotone per thread)
   for (int t = tid; t < m.n_tris; t += 256) {
@@ -240,8 +212,24 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     st.bx0 = fminf(fminf(st.sx[0], st.sx[1]), st.sx[2]) - 1.f; st.bx1 = fmaxf(fmaxf(st.sx[0], st.sx[1]), st.sx[2]) + 1.f;
     st.by0 = fminf(fminf(st.sy[0], st.sy[1]), st.sy[2]) - 1.f; st.by1 = fmaxf(fmaxf(st.sy[0], st.sy[1]), st.sy[2]) + 1.f;
     if (ok && (st.bx1 < 0.f || st.bx0 > (float)R.W || st.by1 < 0.f || st.by0 > (float)R.H)) { ok = false; st.inv_area = 0.f; }
+    if (!ok) { st.bx0 = 1e30f; st.bx1 = -1e30f; st.by0 = 1e30f; st.by1 = -1e30f; }
+    st.index = t;
     out[t] = st;
     if (ok) { bx0 = fminf(bx0, st.bx0); bx1 = fmaxf(bx1, st.bx1); by0 = fminf(by0, st.by0); by1 = fmaxf(by1, st.by1); }
+  }
+  __syncthreads();                          // the env's ScreenTris are written (workgroup scope)
+  if (tid < m.n_obj) {                      // per-object screen box = union of its live triangles' boxes
+    ObjBox ob;
+    ob.bx0 = 1e30f; ob.bx1 = -1e30f; ob.by0 = 1e30f; ob.by1 = -1e30f; ob.first = 0; ob.count = 0; ob.pad[0] = ob.pad[1] = 0;
+    for (int o = 0; o < tid; ++o) { const int mid = R.objs[m.obj_off + o].mesh_id; ob.first += mid >= 0 ? R.meshes[mid].n_tris : 0; }
+    const int mid = R.objs[m.obj_off + tid].mesh_id;
+    const int cnt = mid >= 0 ? R.meshes[mid].n_tris : 0;
+    for (int t = ob.first; t < ob.first + cnt; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(out + t);
+      if (bb.x <= bb.y) { ob.bx0 = fminf(ob.bx0, bb.x); ob.bx1 = fmaxf(ob.bx1, bb.y); ob.by0 = fminf(ob.by0, bb.z); ob.by1 = fmaxf(ob.by1, bb.w); }
+    }
+    ob.count = ob.bx0 <= ob.bx1 ? cnt : 0;
+    R.objbox[(size_t)e * DTSIM_MAX_OBJECTS + tid] = ob;
   }
   __shared__ float red[4][256];
   red[0][tid] = bx0; red[1][tid] = bx1; red[2][tid] = by0; red[3][tid] = by1;
@@ -396,44 +384,43 @@ __device__ inline void shade(const EnvCam& c, const MapU& m, const RenderParams&
   tile_color(R, tiles[m.tile_off + h.tj * m.gw + h.ti], fx, fz, I, out);
 }
 
+
+// z-buffer one mesh triangle against the 4 samples of the pixel centred at (pcx, pcy) px.
+template <typename Tri>
+__device__ inline void test_tri(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
+  if (pcx < st.bx0 || pcx > st.bx1 || pcy < st.by0 || pcy > st.by1) return;
+  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float qx = pcx + ox[s], qy = pcy + oy[s];
+    const float b0 = ((st.sx[1] - qx) * (st.sy[2] - qy) - (st.sx[2] - qx) * (st.sy[1] - qy)) * st.inv_area;
+    const float b1 = ((st.sx[2] - qx) * (st.sy[0] - qy) - (st.sx[0] - qx) * (st.sy[2] - qy)) * st.inv_area;
+    const float b2 = 1.f - b0 - b1;
+    if (b0 >= 0.f && b1 >= 0.f && b2 >= 0.f) {
+      const float d = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
+      // depth func LESS; equal depth: the earlier triangle in draw order keeps the sample
+      if (d >= NEAR_Z && d <= FAR_Z && (d < zbest[s] || (d == zbest[s] && st.index < tbest[s]))) { zbest[s] = d; tbest[s] = st.index; }
+    }
+  }
+}
+
 // exact 4-sample resolve of one pixel (centre NDC nx, ny): coverage and depth per sample,
-// shading once per primitive at the pixel centre; mesh triangles z-buffered against the planes.
+// shading once per primitive at the pixel centre; zbest/tbest = nearest mesh triangle per sample
+// (from the mesh pass), z-buffered against the planes here.
 template <bool OBJ>
 __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const RenderParams& R,
                                       const TileLds* tiles, float nx, float ny, const ScreenTri* tris,
-                                      const ObjBox* boxes, int n_obj) {
-  // standard 4x rotated-grid pattern, offsets in pixels (+x right, +y down)
+                                      const float zbest[4], const int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   const Ray rc = make_ray(nx, ny, c.tx, c.ty, c.sth, c.cth);
-  // mesh pass: nearest covering triangle per sample
-  float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-  int tbest[4] = {-1, -1, -1, -1};
   const float pcx = (nx + 1.f) * 0.5f * (float)R.W, pcy = (1.f - ny) * 0.5f * (float)R.H;   // pixel centre, px
-  for (int o = 0; OBJ && o < n_obj; ++o) {
-   const ObjBox ob = boxes[o];
-   if (ob.count == 0 || pcx < ob.bx0 || pcx > ob.bx1 || pcy < ob.by0 || pcy > ob.by1) continue;
-   for (int t = ob.first; t < ob.first + ob.count; ++t) {
-    const ScreenTri& st = tris[t];
-    if (st.inv_area == 0.f || pcx < st.bx0 || pcx > st.bx1 || pcy < st.by0 || pcy > st.by1) continue;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float qx = pcx + ox[s], qy = pcy + oy[s];
-      const float b0 = ((st.sx[1] - qx) * (st.sy[2] - qy) - (st.sx[2] - qx) * (st.sy[1] - qy)) * st.inv_area;
-      const float b1 = ((st.sx[2] - qx) * (st.sy[0] - qy) - (st.sx[0] - qx) * (st.sy[2] - qy)) * st.inv_area;
-      const float b2 = 1.f - b0 - b1;
-      if (b0 >= 0.f && b1 >= 0.f && b2 >= 0.f) {
-        const float d = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
-        if (d < zbest[s] && d >= NEAR_Z && d <= FAR_Z) { zbest[s] = d; tbest[s] = t; }
-      }
-    }
-   }
-  }
   float acc[3] = {0.f, 0.f, 0.f};
   int pc = -1, pi = 0, pj = 0;
   float col[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll
   for (int s = 0; s < 4; ++s) {
     const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
     const Hit hs = classify(c, m, tiles, rs);
@@ -516,6 +503,7 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 // sized (every pixel of every env of the chunk), so appends need no atomics; entry =
 // (env-in-chunk << 8) | pixel-in-wavefront.  k_resolve drains the regions 64 entries at a time.
 #define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
+#define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
 
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
@@ -773,24 +761,79 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
   const int wbase = strip * STRIP + wave * WAVE_PIX;
   const int n = qcount[blockIdx.x * (RB / 64) + wave];
   const uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
-  for (int q = lane; q < n; q += 64) {
-    const uint32_t ent = w_queue[q];
-    const int el = ent >> 8, lp = ent & 255;
-    const EnvCam c = s_cams[el];
-    const MapU m = map_u(R.maps[c.map_id]);
+  TriCov* w_tris = reinterpret_cast<TriCov*>(s_cams + ENVS_PER_BLOCK) + wave * TRI_CAP;    // wavefront-local
+  for (int q0 = 0; q0 < n; q0 += 64) {               // wave-uniform
+    const bool have = q0 + lane < n;
+    const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
+    const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
     const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
-    int n_obj = 0;
-    const ScreenTri* tris = nullptr;
-    const ObjBox* boxes = nullptr;
+    const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
+    float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+    int tbest[4] = {-1, -1, -1, -1};
     if (OBJ) {
-      const ObjEnv oe = R.objenv[e0 + el];
-      n_obj = oe.n_tris > 0 ? oe.n_obj : 0;
-      tris = R.stris + (size_t)(e0 + el) * R.max_tris;
-      boxes = R.objbox + (size_t)(e0 + el) * DTSIM_MAX_OBJECTS;
+      // ---- mesh pass.  Queue entries are in env order, so these 64 pixels belong to a few
+      // consecutive envs.  Per env: stream its triangles 64 at a time (one per lane), keep those whose
+      // screen box meets the bounding box of this env's pixels, compact them into a wavefront-local
+      // LDS chunk and let every pixel of that env z-buffer the chunk.  No cap, no barrier: DS
+      // operations of one wavefront execute in program order.
+      int el_lo = have ? el : 0x7fffffff, el_hi = el;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { el_lo = min(el_lo, __shfl_xor(el_lo, d)); el_hi = max(el_hi, __shfl_xor(el_hi, d)); }
+      for (int ee = el_lo; ee <= el_hi; ++ee) {      // wave-uniform
+        const bool mine = el == ee;
+        if (!__ballot(mine)) continue;
+        const ObjEnv oe = R.objenv[e0 + ee];
+        if (oe.n_tris == 0) continue;
+        float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
+          y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+        }
+        if (oe.bx0 > x1 || oe.bx1 < x0 || oe.by0 > y1 || oe.by1 < y0) continue;
+        const ScreenTri* base = R.stris + (size_t)(e0 + ee) * R.max_tris;
+        int fill = 0;
+        for (int t0 = 0; t0 < oe.n_tris; t0 += 64) {
+          const int t = t0 + lane;
+          bool pass = false;
+          if (t < oe.n_tris) {
+            const float4 bb = *reinterpret_cast<const float4*>(base + t);     // bx0, bx1, by0, by1
+            pass = !(bb.x > x1 || bb.y < x0 || bb.z > y1 || bb.w < y0);
+          }
+          const unsigned long long pm = __ballot(pass);
+          if (pass) {
+            const int slot = fill + __popcll(pm & ((1ull << lane) - 1ull));
+            const ScreenTri st = base[t];
+            TriCov tc;
+            tc.bx0 = st.bx0; tc.bx1 = st.bx1; tc.by0 = st.by0; tc.by1 = st.by1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { tc.sx[k] = st.sx[k]; tc.sy[k] = st.sy[k]; tc.iw[k] = st.iw[k]; }
+            tc.inv_area = st.inv_area; tc.index = st.index; tc.pad = 0.f;
+            w_tris[slot] = tc;
+          }
+          fill += __popcll(pm);
+          const bool last = t0 + 64 >= oe.n_tris;
+          if (fill > TRI_CAP - 64 || (last && fill > 0)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (mine)
+              for (int k = 0; k < fill; ++k) test_tri(w_tris[k], pcx, pcy, zbest, tbest);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            fill = 0;
+          }
+        }
+      }
     }
-    const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, boxes, n_obj);
-    uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
-    dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+    if (have) {
+      const EnvCam c = s_cams[el];
+      const MapU m = map_u(R.maps[c.map_id]);
+      const ScreenTri* tris = OBJ ? R.stris + (size_t)(e0 + el) * R.max_tris : nullptr;
+      const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
+      uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
+      dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+    }
   }
 }
 
@@ -806,6 +849,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
   const size_t lds2 = lds + ENVS_PER_BLOCK * sizeof(EnvCam);
+  const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid(n_strips * n_chunks);
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds, s, R, cams, R.frames, R.texels,               \
@@ -815,7 +859,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
   if (!R.no_msaa) {
-    if (obj) hipLaunchKernelGGL(k_resolve<true>, grid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    if (obj) hipLaunchKernelGGL(k_resolve<true>, grid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount);
     else hipLaunchKernelGGL(k_resolve<false>, grid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
   }
 }
