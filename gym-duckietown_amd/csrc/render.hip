@@ -35,7 +35,7 @@
 #define PPT 4             // pixels per thread
 #define WAVE_PIX (64 * PPT)
 #define STRIP (RB * PPT)  // pixels per workgroup
-#define ENVS_PER_BLOCK 16
+#define ENVS_PER_BLOCK 32
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
@@ -62,6 +62,18 @@ struct alignas(16) EnvCam {          // 32 floats = 128 B, written by k_cam_setu
 };
 static_assert(sizeof(EnvCam) == 128, "EnvCam is 128 bytes");
 
+// Everything the fast path needs per env, fully precomputed by k_cam_setup so that the env loop of
+// k_raster does no wave-uniform arithmetic on the vector ALU (there is no scalar float ALU on gfx950):
+// one 64-byte scalar load per env.
+struct alignas(16) EnvFast {
+  float A, B, Cxi, Czi;        // yaw rotation straight into tile units: gx = Cxi + lr*A + lf*B, gz = Czi + lr*B - lf*A
+  float kg, Cx, Cz, its;       // ground-plane scale (Cy+0.008)/Cy, camera centre, 1/tile_size
+  float ts, gw_m, gh_m, I0;    // tile size, grid extent in metres, shared-camera light base (unused with DR)
+  uint32_t hor_rgb;            // packed horizon colour
+  int32_t gw, gh, tile_off;    // grid size, first tile record of the env's map
+};
+static_assert(sizeof(EnvFast) == 64, "EnvFast is 64 bytes");
+
 // coverage-only part of a ScreenTri kept in LDS by k_resolve<true>; the winner's colours are fetched
 // from global memory.
 struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; float pad; };
@@ -83,7 +95,8 @@ __device__ inline CamShared default_cam(float aspect) {
   return s;
 }
 
-__global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* out) {
+__global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* out, EnvFast* fast,
+                            const RenderMapDev* __restrict__ maps) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
   if (e >= A.N) return;
@@ -142,6 +155,20 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
   c.map_id = A.map_id[e];
   c.pad[0] = c.pad[1] = 0.f;
   out[e] = c;
+  const RenderMapDev m = maps[c.map_id];
+  EnvFast f;
+  f.its = m.inv_tile_size; f.ts = m.tile_size;
+  f.A = c.sa * f.its; f.B = c.ca * f.its; f.Cxi = c.Cx * f.its; f.Czi = c.Cz * f.its;
+  f.kg = (c.Cy - GROUND_Y) / c.Cy; f.Cx = c.Cx; f.Cz = c.Cz;
+  f.gw_m = (float)m.grid_w * m.tile_size; f.gh_m = (float)m.grid_h * m.tile_size;
+  f.I0 = 0.f;
+  {
+    const uint32_t r = (uint32_t)(fminf(fmaxf(c.hor[0], 0.f), 255.f) + 0.5f), g = (uint32_t)(fminf(fmaxf(c.hor[1], 0.f), 255.f) + 0.5f);
+    const uint32_t b = (uint32_t)(fminf(fmaxf(c.hor[2], 0.f), 255.f) + 0.5f);
+    f.hor_rgb = r | (g << 8) | (b << 16);
+  }
+  f.gw = m.grid_w; f.gh = m.grid_h; f.tile_off = m.tile_off;
+  fast[e] = f;
 }
 
 // ---- mesh objects -> per-env screen-space triangles ------------------------------------
@@ -507,7 +534,7 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
-                                               uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
+                                               const EnvFast* __restrict__ fasts, uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
                                                const float4* __restrict__ lut, const RenderMapDev* __restrict__ maps,
                                                const TileLds* __restrict__ tile_recs, uint16_t* __restrict__ queue,
                                                int32_t* __restrict__ qcount) {
@@ -548,8 +575,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   if (!DR) {
     const CamShared cs = default_cam(aspect);
 #pragma unroll
-    for (int k = 0; k < PPT; ++k)
+    for (int k = 0; k < PPT; ++k) {
       pv[k] = pix_inv(nx[k], ny[k], ok[k], cs.tx, cs.ty, cs.sth, cs.cth, cs.Cy, cs.L, ex_n, ey_n);
+      pv[k].ndl = fminf(fmaf(cs.dif, pv[k].ndl, cs.base), 1.f);   // lit factor, env-invariant
+    }
   }
 
   // source-pixel bounding box of this wavefront's pixels (for the mesh-object test)
@@ -572,18 +601,17 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
 
   for (int e = e0; e < e1; ++e) {
-    const EnvCam c = cams[e];                       // wave-uniform: scalar loads
-    const MapU m = map_u(maps[c.map_id]);
+    const EnvFast f = fasts[e];                      // wave-uniform: one 64-byte scalar load
+    float base0 = 0.f, base1 = 0.f, base2 = 0.f, dif0 = 0.f, dif1 = 0.f, dif2 = 0.f;
     if (DR) {
+      const EnvCam c = cams[e];
+      base0 = c.base[0]; base1 = c.base[1]; base2 = c.base[2]; dif0 = c.dif[0]; dif1 = c.dif[1]; dif2 = c.dif[2];
 #pragma unroll
       for (int k = 0; k < PPT; ++k)
         pv[k] = pix_inv(nx[k], ny[k], ok[k], c.tx, c.ty, c.sth, c.cth, c.Cy, c.L, ex_n, ey_n);
     }
-    const float kg = (c.Cy - GROUND_Y) / c.Cy;       // ground-plane hit = C + kg * (tile-plane offset)
-    const float gw_m = m.gwf * m.ts, gh_m = m.ghf * m.ts;
-    const uint32_t hor_rgb = pack_rgb(c.hor);
-    // yaw rotation straight into tile units
-    const float A = c.sa * m.its, B = c.ca * m.its, Cxi = c.Cx * m.its, Czi = c.Cz * m.its;
+    const uint32_t hor_rgb = f.hor_rgb;
+    const float A = f.A, B = f.B, Cxi = f.Cxi, Czi = f.Czi;
 
     // ---- fast path: one ray per pixel, straight-line (predicated) code so that the LDS
     // tile-record reads and the 8 texel loads of the 4 pixels are all in flight together.
@@ -608,8 +636,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         fx[k] = __builtin_amdgcn_fractf(gx); fz[k] = __builtin_amdgcn_fractf(gz);
         const int ti = flr_i32(gx), tj = flr_i32(gz);
         cand[k] = (p.flags & (PF_VALID | PF_SKY | PF_ALWAYS_EDGE)) == PF_VALID;
-        const bool ingrid = cand[k] & ((p.flags & PF_TILE_OK) != 0) & ((unsigned)ti < (unsigned)m.gw) & ((unsigned)tj < (unsigned)m.gh);
-        const int idx = ingrid ? m.tile_off + (int)__umul24(tj, m.gw) + ti : m.tile_off;
+        const bool ingrid = cand[k] & ((p.flags & PF_TILE_OK) != 0) & ((unsigned)ti < (unsigned)f.gw) & ((unsigned)tj < (unsigned)f.gh);
+        const int idx = ingrid ? f.tile_off + (int)__umul24(tj, f.gw) + ti : f.tile_off;
         tr[k] = s_tiles[idx];
         is_tile[k] = ingrid & ((tr[k].flags & 1u) != 0);
       }
@@ -629,9 +657,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const PixInv& p = pv[k];
-        const float I0 = fminf(fmaf(c.dif[0], p.ndl, c.base[0]), 1.f);
-        const float I1 = DR ? fminf(fmaf(c.dif[1], p.ndl, c.base[1]), 1.f) : I0;
-        const float I2 = DR ? fminf(fmaf(c.dif[2], p.ndl, c.base[2]), 1.f) : I0;
+        // shared camera: pv.ndl already holds the lit factor min(base + dif*ndl, 1) (all channels equal)
+        const float I0 = DR ? fminf(fmaf(dif0, p.ndl, base0), 1.f) : p.ndl;
+        const float I1 = DR ? fminf(fmaf(dif1, p.ndl, base1), 1.f) : I0;
+        const float I2 = DR ? fminf(fmaf(dif2, p.ndl, base2), 1.f) : I0;
         uint32_t rgb = 0;
         {
           const float c00 = ubyte0(top2[k].x), c10 = ubyte0(top2[k].y), c01 = ubyte0(bot2[k].x), c11 = ubyte0(bot2[k].y);
@@ -652,7 +681,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         // untextured tiles and everything that is not a plain tile interior: other paths
         const bool textured = (tr[k].flags & 2u) != 0;
         const bool tile_fast = is_tile[k] & textured;
-        const bool tile_edge = is_tile[k] & (!(d > p.mrg * m.its) | !textured);
+        const bool tile_edge = is_tile[k] & (!(d > p.mrg * f.its) | !textured);
         const bool gcand = cand[k] & !is_tile[k];
         need_ground |= gcand;
         px[k] = tile_fast ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
@@ -660,14 +689,15 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         edge_mask |= edge ? (1u << k) : 0u;
       }
       if (__ballot(need_ground)) {                   // wave-uniform: ground quad beyond the map
+        const EnvCam c = cams[e];                    // colours / ground-corner light: only needed here
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           const PixInv& p = pv[k];
           const bool gcand = cand[k] & !is_tile[k];
           // every sample's tile-plane hit must stay clear of the grid, ground hit inside the quad
-          const float wx = gxs[k] * m.ts, wz = gzs[k] * m.ts;
-          const float wxg = fmaf(kg, wx - c.Cx, c.Cx), wzg = fmaf(kg, wz - c.Cz, c.Cz);
-          const bool clear = (wx < -p.mrg) | (wx > gw_m + p.mrg) | (wz < -p.mrg) | (wz > gh_m + p.mrg);
+          const float wx = gxs[k] * f.ts, wz = gzs[k] * f.ts;
+          const float wxg = fmaf(f.kg, wx - f.Cx, f.Cx), wzg = fmaf(f.kg, wz - f.Cz, f.Cz);
+          const bool clear = (wx < -p.mrg) | (wx > f.gw_m + p.mrg) | (wz < -p.mrg) | (wz > f.gh_m + p.mrg);
           const bool inq = (fabsf(wxg) + 2.f * p.mrg < GROUND_HALF) & (fabsf(wzg) + 2.f * p.mrg < GROUND_HALF);
           const bool gfast = gcand & clear & inq & ((p.flags & PF_GROUND_OK) != 0);
           const float ndl = ground_ndl(c, wxg, wzg);
@@ -713,20 +743,17 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
     // register budget): append them to this wavefront's queue region.
     if (!R.no_msaa && __ballot(edge_mask != 0)) {    // wave-uniform
-      const int n_mine = __popc(edge_mask);
-      int incl = n_mine;                             // inclusive prefix sum over the lanes
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-      }
-      const int total = __shfl(incl, 63);
-      int pos = qn + incl - n_mine;
       const uint32_t etag = (uint32_t)(e - e0) << 8;
 #pragma unroll
-      for (int k = 0; k < PPT; ++k)
-        if (edge_mask & (1u << k)) w_queue[pos++] = (uint16_t)(etag | (uint32_t)(lane * PPT + k));
-      qn += total;
+      for (int k = 0; k < PPT; ++k) {                // per pixel slot: ballot -> rank -> masked store
+        const bool ek = (edge_mask >> k) & 1u;
+        const unsigned long long mk = __ballot(ek);
+        if (ek) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          w_queue[qn + rank] = (uint16_t)(etag | (uint32_t)(lane * PPT + k));
+        }
+        qn += __popcll(mk);
+      }
     }
   }
   if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
@@ -841,8 +868,9 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) {
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
+  EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand,
-                     (float)R.W / (float)R.H, cams);
+                     (float)R.W / (float)R.H, cams, fasts, R.maps);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
   const int npix = R.W * R.H;
   const int n_strips = (npix + STRIP - 1) / STRIP;
@@ -852,7 +880,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid(n_strips * n_chunks);
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
-  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds, s, R, cams, R.frames, R.texels,               \
+  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   const bool obj = R.max_tris > 0;
   if (R.domain_rand) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }
