@@ -287,6 +287,11 @@ __device__ inline MapU map_u(const RenderMapDev& m) {
   return u;
 }
 
+// 1-ulp hardware reciprocal / rsqrt / sqrt: a relative error of 1e-7 moves a ground hit by < 1e-3 texel
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline float fsqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 struct Ray { float xe, ye, yla, fwd; };
 
 __device__ inline Ray make_ray(float nx, float ny, float tx, float ty, float sth, float cth) {
@@ -304,7 +309,7 @@ __device__ inline float plane_ndl(const float L[4], float sth, float cth, const 
   if (L[3] == 0.f) ndl = cth * L[1] + sth * L[2];
   else {
     const float lx = L[0] - t * r.xe, ly = L[1] - t * r.ye, lz = L[2] + t;
-    ndl = (cth * ly + sth * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+    ndl = (cth * ly + sth * lz) * frsq(lx * lx + ly * ly + lz * lz);
   }
   return fmaxf(ndl, 0.f);
 }
@@ -359,7 +364,7 @@ __device__ inline uint32_t pack_rgb(const float col[3]) {  // glReadPixels float
 struct Hit { int cls; int ti, tj; float t, wx, wz; };
 
 __device__ inline void plane_hit(const EnvCam& c, const Ray& r, float h, float& t, float& wx, float& wz) {
-  t = h / (-r.yla);
+  t = h * frcp(-r.yla);
   const float rr = t * r.xe, ff = t * r.fwd;
   wx = c.Cx + rr * c.sa + ff * c.ca;
   wz = c.Cz + rr * c.ca - ff * c.sa;
@@ -500,7 +505,7 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
     p.flags |= (r.yla - dy >= 0.f) ? PF_SKY : PF_ALWAYS_EDGE;
     return p;
   }
-  const float inv = 1.f / (-r.yla);
+  const float inv = frcp(-r.yla);
   const float t = Cy * inv;
   p.lr = t * r.xe; p.lf = t * r.fwd;
   p.ndl = plane_ndl(L, sth, cth, r, t);
@@ -511,12 +516,12 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
   // (right, forward).  The rotated-grid samples sit at (+-0.375, +-0.125) and (+-0.125, +-0.375):
   // take the larger of the two reaches (ex/ey already carry the 0.375 and a 1% pad), +5%.
   {
-    const float kappa = rho / fmaxf(1.f - rho, 0.25f);
+    const float kappa = rho * frcp(fmaxf(1.f - rho, 0.25f));
     const float ax_ = t * ex, ry_ = fabsf(p.lr) * kappa, fy_ = fabsf(p.lf) * kappa + t * ey * fabsf(sth);
     const float third = 1.f / 3.f;
     const float r1x = ax_ + third * ry_, r1f = third * fy_;          // (0.375, 0.125)
     const float r2x = third * ax_ + ry_, r2f = fy_;                  // (0.125, 0.375)
-    p.mrg = 1.05f * sqrtf(fmaxf(r1x * r1x + r1f * r1f, r2x * r2x + r2f * r2f));
+    p.mrg = 1.05f * fsqrt_(fmaxf(r1x * r1x + r1f * r1f, r2x * r2x + r2f * r2f));
   }
   const float tg = (Cy - GROUND_Y) * inv;
   if (t >= NEAR_Z && t <= FAR_Z) p.flags |= PF_TILE_OK;
@@ -661,21 +666,22 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         const float I0 = DR ? fminf(fmaf(dif0, p.ndl, base0), 1.f) : p.ndl;
         const float I1 = DR ? fminf(fmaf(dif1, p.ndl, base1), 1.f) : I0;
         const float I2 = DR ? fminf(fmaf(dif2, p.ndl, base2), 1.f) : I0;
+        // bilinear as 4 weights (lighting folded in): w00 + w10 + w01 + w11 = I
+        const float wy1 = ay[k], wy0 = 1.f - ay[k];
+        const float w10_ = ax[k] * wy0, w11_ = ax[k] * wy1;
+        const float w00_ = wy0 - w10_, w01_ = wy1 - w11_;
         uint32_t rgb = 0;
         {
-          const float c00 = ubyte0(top2[k].x), c10 = ubyte0(top2[k].y), c01 = ubyte0(bot2[k].x), c11 = ubyte0(bot2[k].y);
-          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I0, 0, rgb);
+          const float v = fmaf(ubyte0(bot2[k].y), w11_, fmaf(ubyte0(bot2[k].x), w01_, fmaf(ubyte0(top2[k].y), w10_, ubyte0(top2[k].x) * w00_)));
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I0, 0, rgb);
         }
         {
-          const float c00 = ubyte1(top2[k].x), c10 = ubyte1(top2[k].y), c01 = ubyte1(bot2[k].x), c11 = ubyte1(bot2[k].y);
-          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I1, 1, rgb);
+          const float v = fmaf(ubyte1(bot2[k].y), w11_, fmaf(ubyte1(bot2[k].x), w01_, fmaf(ubyte1(top2[k].y), w10_, ubyte1(top2[k].x) * w00_)));
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I1, 1, rgb);
         }
         {
-          const float c00 = ubyte2(top2[k].x), c10 = ubyte2(top2[k].y), c01 = ubyte2(bot2[k].x), c11 = ubyte2(bot2[k].y);
-          const float top = fmaf(ax[k], c10 - c00, c00), bot = fmaf(ax[k], c11 - c01, c01);
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(ay[k], bot - top, top) * I2, 2, rgb);
+          const float v = fmaf(ubyte2(bot2[k].y), w11_, fmaf(ubyte2(bot2[k].x), w01_, fmaf(ubyte2(top2[k].y), w10_, ubyte2(top2[k].x) * w00_)));
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I2, 2, rgb);
         }
         const float d = fminf(fminf(fx[k], 1.f - fx[k]), fminf(fz[k], 1.f - fz[k]));
         // untextured tiles and everything that is not a plain tile interior: other paths
