@@ -64,6 +64,63 @@ def cpu_baseline(n_steps: int):
                       "the reference's Pyglet/OpenGL path is not runnable on this host (no pyglet/duckietown_world/GL)"}
 
 
+def main_c2(args):
+    """BASELINE.json configs[1]: small_loop, render off.  Latency-bound at N=4096 (working set in L2);
+    pass --envs 1048576 for the HBM-roofline reading."""
+    import torch
+    from dtsim import BatchedSimulator, _ffi
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    N, K, Wm, F = args.envs, args.steps, args.warmup, args.fuse
+    sim = BatchedSimulator("small_loop", min(N, 4096), render=False, domain_rand=False, seed=1000, action_mode="vel_steer",
+                           auto_reset=True, profile=True, device=local_rank, do_reset=False)
+    pool = sim.make_spawn_pool(min(N, 4096))
+    if N > 4096:   # large-N reading: replicate the sampled spawn states (reset sampling is host-side)
+        big = BatchedSimulator("small_loop", N, render=False, domain_rand=False, seed=1000, action_mode="vel_steer",
+                               auto_reset=True, profile=True, device=local_rank, do_reset=False)
+        states = (_ffi.InitState * N)()
+        for e in range(N):
+            states[e] = pool[e % len(pool)]
+        big._lib.dtsim_set_spawn_pool(big._h, pool, len(pool))
+        sim.close()
+        sim = big
+        sim.reset(states=states)
+    else:
+        sim.reset(states=pool)
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    acts = torch.rand((F, N, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    for _ in range(Wm):
+        sim.step(acts, n_steps=F)
+    sim.sync(); sim.profile_read(_ffi.KERNEL_STEP)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        sim.step(acts, n_steps=F)
+    sim.sync()
+    dt = time.perf_counter() - t0
+    n_s, ms_s = sim.profile_read(_ffi.KERNEL_STEP)
+    # state actually touched per env-step on a map without dynamic objects: 31 f64 arrays (pose, SE(2) state,
+    # velocities, 2x5 delay ring, gains, wheel_dist, timestamp, speed, reward, lane[4], prox, wheels[2]),
+    # 4 int32 (ring head, step count, tile i/j), 3 uint8 (done, code, in_lane); read + written once per step,
+    # plus the 8-byte f32 action.  (dtsim_state_bytes()/N also counts the 8 unused DuckieObj slots.)
+    S = 31 * 8 + 4 * 4 + 3
+    b_phys = 2 * S + 8
+    achieved = N * F * b_phys / (ms_s / n_s * 1e-3)
+    print(json.dumps({
+        "metric": "env-steps/sec (dynamics+collision only, render off)", "value": N * F * K / dt, "unit": "env-steps/s",
+        "n_gpus": 1, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Duckietown-small_loop-v0 (fixture), batched envs, render off [BASELINE.json configs[1]]",
+                   "envs_per_gpu": N, "fused_steps_per_launch": F},
+        "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                     "frac": achieved / PEAK_HBM, "traffic": None, "kernel_ms": ms_s / n_s,
+                     "algorithmic_bytes_per_env_step": b_phys, "state_bytes_touched_per_env": S,
+                     "state_bytes_allocated_per_env": sim.state_bytes / N,
+                     "note": "with fused steps the state stays in L2 between steps: read frac as HBM-bound only at --fuse 1"},
+        "cpu_baseline": None}), flush=True)
+    sim.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +129,13 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cpu-steps", type=int, default=8, help="oracle env-steps for cpu_baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2"],
+                    help="c3 (default, the headline): raster + fisheye; c2: dynamics+collision only, render off "
+                         "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch")
+    ap.add_argument("--fuse", type=int, default=32, help="c2: physics steps fused per dtsim_step launch")
     args = ap.parse_args()
+    if args.config == "c2":
+        return main_c2(args)
 
     import torch
     import torch.distributed as dist
