@@ -434,7 +434,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
         d.heading_x = std::cos(ob_.angle); d.heading_z = -std::sin(ob_.angle);  // collision.py:223-230
         d.angle = ob_.angle; d.safety_radius = ob_.safety_radius;
         d.walk_distance = ob_.walk_distance; d.vel = ob_.vel; d.wait_time = ob_.wait_time; d.wiggle = ob_.wiggle;
-        d.obj_index = o;
+        d.obj_index = o; d.kind = ob_.dynamic;
       } else if (ob_.collidable) {
         double* r = st + STATIC_WORDS * si++;
         memcpy(r, ob_.corners, 8 * sizeof(double));

@@ -48,8 +48,8 @@ static_assert(sizeof(TileRec) == 8, "TileRec is one word");
 
 struct DynInit {           // per map, per dynamic slot: initial DuckieObj state
   double cx, cz, corners[8], norm[4], heading_x, heading_z, angle, safety_radius;
-  double walk_distance, vel, wait_time, wiggle;
-  int32_t obj_index, pad;
+  double walk_distance, vel, wait_time, wiggle;   // DuckieObj; DuckiebotObj: follow_dist, velocity, gain, trim
+  int32_t obj_index, kind;                        // kind: 1 DuckieObj, 2 DuckiebotObj
 };
 
 // ---- per-env SoA ------------------------------------------------------------

@@ -292,6 +292,65 @@ __device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d,
   A.ob_yrot[ix] = (ang + angle_delta) * (180 / 3.141592653589793);
 }
 
+// objects.py:230-336 DuckiebotObj.step_duckiebot + _update_pos: pure pursuit on the lane curve with
+// its own differential-drive kinematics.  Corners are refreshed after a turn, the SAT axes
+// (DynInit.norm) deliberately never are (objects.py:333-336 vs :270).
+__device__ inline void duckiebot_step(const SimArrays& A, const MapView& m, const DynInit& di, int d, int e, double dt) {
+  const size_t N = A.N, ix = (size_t)d * N + e;
+  const double px = A.ob_cx[ix], pz = A.ob_cz[ix], ang = A.ob_angle[ix];
+  const Lane c0 = lane_pos(m, px, pz, ang);
+  if (!c0.in_lane) return;          // the reference raises here; the follower is left where it is
+  const double follow_dist = di.walk_distance, velocity = di.vel, gain = di.wait_time, trim = di.wiggle;
+  const double radius = 0.0318, kk = 27.0, limit = 1.0, wheel_dist = 0.102;
+  double lookup = follow_dist;
+  Lane c1;
+  c1.in_lane = false;
+  for (int it = 0; it < 1000; ++it) {
+    c1 = lane_pos(m, c0.pt_x + c0.tan_x * lookup, c0.pt_z + c0.tan_z * lookup, ang);
+    if (c1.in_lane) break;
+    lookup *= 0.5;
+  }
+  if (!c1.in_lane) return;
+  double vx = c1.pt_x - px, vz = c1.pt_z - pz;
+  const double vn = sqrt((vx * vx + 0.0) + vz * vz);
+  vx /= vn; vz /= vn;
+  const double sa = sin(ang), ca = cos(ang);
+  const double dot = (sa * vx + 0.0) + ca * vz;          // right_vec . point_vec
+  const double steering = gain * -dot;
+  // _update_pos
+  const double k_r_inv = (gain + trim) / kk, k_l_inv = (gain - trim) / kk;
+  const double omega_r = (velocity + 0.5 * steering * wheel_dist) / radius;
+  const double omega_l = (velocity - 0.5 * steering * wheel_dist) / radius;
+  const double u_r = omega_r * k_r_inv, u_l = omega_l * k_l_inv;
+  const double ur = fmax(fmin(u_r, limit), -limit), ul = fmax(fmin(u_l, limit), -limit);
+  if (ul == ur) {
+    A.ob_cx[ix] = px + dt * ul * ca;
+    A.ob_cz[ix] = pz + dt * ul * -sa;
+    return;
+  }
+  const double w = (ur - ul) / wheel_dist;
+  const double r = (wheel_dist * (ul + ur)) / (2 * (ul - ur));
+  const double rot = w * dt;
+  const double ccx = px + r * sa, ccz = pz + r * ca;
+  // graphics.py:254-265 rotate_point
+  const double ddx = px - ccx, ddz = pz - ccz;
+  const double cr = cos(rot), sr = sin(rot);
+  const double npx = ccx + (ddx * cr + ddz * sr), npz = ccz + (ddz * cr - ddx * sr);
+  const double nang = ang + rot;
+  A.ob_cx[ix] = npx; A.ob_cz[ix] = npz; A.ob_angle[ix] = nang;
+  A.ob_yrot[ix] = A.ob_yrot[ix] + rot * 180 / 3.141592653589793;
+  // agent_boundbox(pos, robot_width, robot_length, dir, right) collision.py:9-34
+  const double ndx = cos(nang), ndz = -sin(nang), nrx = sin(nang), nrz = cos(nang);
+  const double hw = 0.5 * DT_ROBOT_WIDTH, hl = 0.5 * DT_ROBOT_LENGTH;
+  const double cx4[4] = {(npx - hw * nrx) - hl * ndx, (npx + hw * nrx) - hl * ndx, (npx + hw * nrx) + hl * ndx, (npx - hw * nrx) + hl * ndx};
+  const double cz4[4] = {(npz - hw * nrz) - hl * ndz, (npz + hw * nrz) - hl * ndz, (npz + hw * nrz) + hl * ndz, (npz - hw * nrz) + hl * ndz};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    A.ob_corners[(size_t)((2 * k) * DTSIM_MAX_DYNAMIC + d) * N + e] = cx4[k];
+    A.ob_corners[(size_t)((2 * k + 1) * DTSIM_MAX_DYNAMIC + d) * N + e] = cz4[k];
+  }
+}
+
 // duckietown_world DB18 model + SE(2) exponential, restated (PARITY UNPINNED;
 // call sites simulator.py:745-755, 2076-2088).  Mirrors oracle/sim.py DynamicsDB18.
 struct Dyn { double x, y, c, s, u, w; };
@@ -460,7 +519,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       px = nx; pz = nz; ang = atan2(q.s, q.c);
       sc += 1; ts_ += dt;
       speed = sqrt((ddx * ddx + 0.0) + ddz * ddz) / dt;
-      for (int d = 0; d < m.h->n_dyn; ++d) duckie_step(A, dyn[d], d, e, dt);
+      for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
+        if (dyn[d].kind == 2) duckiebot_step(A, m, dyn[d], d, e, dt);
+        else duckie_step(A, dyn[d], d, e, dt);
+      }
     }
     A.q_x[e] = q.x; A.q_y[e] = q.y; A.q_c[e] = q.c; A.q_s[e] = q.s; A.vel_u[e] = q.u; A.vel_w[e] = q.w;
     A.pos_x[e] = px; A.pos_z[e] = pz; A.angle[e] = ang;

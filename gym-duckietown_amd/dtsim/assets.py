@@ -51,11 +51,19 @@ _SMALL_DUCKIES = [((2.5, 1.25), 30), ((1.75, 2.5), 60), ((2.5, 3.6), 120), ((3.4
 _LOOP_DUCKIES = [((4.75, 1.25), 60), ((3.25, 1.75), 210), ((1.25, 2.9), 300), ((1.75, 4.1), 270),
                  ((3.25, 5.8), 60), ((2.75, 5.2), 240), ((6.2, 2.75), 310), ((6.8, 3.25), 50)]
 
+def _bots(spec):
+    return [dict(kind="duckiebot", pos=list(p), rotate=r, height=0.12, static=False) for p, r in spec]
+
+
+# follower Duckiebots placed on the right-hand lanes of the loop (stand-in for `loop_dyn_duckiebots`)
+_LOOP_BOTS = [((3.5, 1.7), 0), ((1.3, 3.0), -90), ((6.7, 2.5), 90), ((2.5, 5.3), 180)]
+
 MAPS = {
     "small_loop": dict(tiles=_SMALL_LOOP_TILES, objects=[], tile_size=0.585),
     "small_loop_only_duckies": dict(tiles=_SMALL_LOOP_TILES, objects=_duckies(_SMALL_DUCKIES), tile_size=0.585),
     "loop_only_duckies": dict(tiles=_LOOP_TILES, objects=_duckies(_LOOP_DUCKIES), tile_size=0.585),
     "loop_pedestrians": dict(tiles=_LOOP_TILES, objects=_duckies(_LOOP_DUCKIES, static=False), tile_size=0.585),
+    "loop_dyn_duckiebots": dict(tiles=_LOOP_TILES, objects=_bots(_LOOP_BOTS) + _duckies(_LOOP_DUCKIES[:3]), tile_size=0.585),
 }
 
 
@@ -241,6 +249,11 @@ def get_mesh(kind: str) -> MeshData:
             parts = [_ellipsoid((0.0, 0.5, 0.0), (0.5, 0.5, 0.40625), 8, 5, (0.7, 0.7, 0.72))]
             _MESH_CACHE[key] = _finish(parts, (-0.5, 0.0, -0.40625), (0.5, 1.0, 0.40625))
     return _MESH_CACHE[key]
+
+
+def mesh_kind(kind: str) -> str:
+    """Which stand-in mesh a map object kind uses."""
+    return "duckie" if kind == "duckie" else "*"
 
 
 def mesh_extents(kinds=("duckie",)) -> dict:

@@ -121,6 +121,7 @@ class ObjectTable:
     wait_time: float = 8.0
     wiggle: float = math.pi / 15
     dyn_slot: int = -1
+    dyn_kind: int = 0            # 0 static, 1 DuckieObj, 2 DuckiebotObj
 
 
 @dataclass
@@ -169,7 +170,7 @@ class MapTables:
         for k, o in enumerate(self.objects):
             f = arr[k]
             f.mesh_id = mesh_ids.get(o.mesh_kind, -1)
-            f.dynamic = 0 if o.static else 1
+            f.dynamic = 0 if o.static else o.dyn_kind
             f.collidable = 1 if o.collidable else 0
             f.optional = 1 if o.optional else 0
             f.pos[:] = [float(v) for v in o.pos]
@@ -249,7 +250,7 @@ def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, 
         kind = desc["kind"]
         if kind == "floor_tag":                   # simulator.py:971-972
             continue
-        mesh_kind = kind if kind == "duckie" else "*"
+        mesh_kind = "duckie" if kind == "duckie" else "*"
         mesh = (meshes or {}).get(mesh_kind) or get_mesh(kind)
         # get_transform [R] (README.md:239) + weird_from_cartesian (simulator.py:1640-1652)
         Hc = W if transform_uses_width else H
@@ -277,9 +278,14 @@ def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, 
             corners=corners, norm=vect.T, safety_radius=float(SAFETY_RAD_MULT * (np.linalg.norm([ex, ez]) * scale)),
             spawn_clear=float(max(mx) * 0.5 * scale + MIN_SPAWN_OBJ_DIST), min_coords=mn, max_coords=mx)
         if not static:
-            if kind != "duckie":
-                raise InvalidMapException(f"dynamic object kind {kind!r} not supported (DuckieObj only)")
-            o.walk_distance = ts                  # simulator.py:1010
+            if kind == "duckie":
+                o.dyn_kind = 1
+                o.walk_distance = ts              # DuckieObj(..., walk_distance=road_tile_size) simulator.py:1010
+            elif kind == "duckiebot":
+                o.dyn_kind = 2                    # DuckiebotObj, non-DR defaults (objects.py:208-216)
+                o.walk_distance, o.vel, o.wait_time, o.wiggle = 0.3, 0.1, 2.0, 0.0   # follow_dist, velocity, gain, trim
+            else:
+                raise InvalidMapException(f"dynamic object kind {kind!r} not supported (duckie / duckiebot)")
             o.dyn_slot = n_dyn
             n_dyn += 1
         objs.append(o)

@@ -45,7 +45,7 @@ extern "C" {
 #define DTSIM_MAX_TILES 1024        /* grid_w * grid_h per map */
 #define DTSIM_MAX_CURVES 1024       /* per map */
 #define DTSIM_MAX_STATIC 32         /* collidable static objects per map */
-#define DTSIM_MAX_DYNAMIC 8         /* DuckieObj per map */
+#define DTSIM_MAX_DYNAMIC 8         /* dynamic objects (DuckieObj + DuckiebotObj) per map */
 #define DTSIM_MAX_OBJECTS 40        /* renderable objects per map */
 #define DTSIM_MAX_DELAY 8           /* dynamics command delay, in steps */
 #define DTSIM_MAX_TEXTURES 32
@@ -110,7 +110,7 @@ typedef struct dtsim_config {
  * (generate_corners collision.py:64-79, generate_norm collision.py:99-106). */
 typedef struct dtsim_object {
   int32_t mesh_id;       /* index into dtsim_set_assets meshes, -1 = not rendered */
-  int32_t dynamic;       /* 0 static WorldObj, 1 DuckieObj pedestrian */
+  int32_t dynamic;       /* 0 static WorldObj, 1 DuckieObj pedestrian (objects.py:339), 2 DuckiebotObj follower (objects.py:180) */
   int32_t collidable;    /* static && kind != trafficlight (simulator.py:1027-1030) */
   int32_t optional;
   double pos[3];
@@ -120,7 +120,9 @@ typedef struct dtsim_object {
   double norm[4];        /* [2][2] */
   double safety_radius;
   double spawn_clear;    /* max(max_coords)*0.5*scale + MIN_SPAWN_OBJ_DIST (simulator.py:1467) */
-  /* DuckieObj parameters (objects.py:339-365); ignored for static objects */
+  /* DuckieObj parameters (objects.py:339-365); ignored for static objects.  For a DuckiebotObj the same
+   * four slots carry follow_dist, velocity, gain, trim (objects.py:199-216); its radius / k / limit /
+   * wheel_dist / robot_width / robot_length are the reference defaults. */
   double walk_distance, vel, wait_time, wiggle;
 } dtsim_object;
 

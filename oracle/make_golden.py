@@ -143,6 +143,18 @@ def main():
             cen[t, k] = c[[0, 2]]; act[t, k] = ob.pedestrian_active; yrot[t, k] = ob.y_rot; cor[t, k] = ob.obj_corners
     np.savez_compressed(os.path.join(OUT, "ref_duckie_walk.npz"), center=cen, active=act, y_rot=yrot, corners=cor)
 
+    # DuckiebotObj followers (objects.py:180-336) on the loop_dyn_duckiebots fixture
+    md = assets.get_map("loop_dyn_duckiebots")
+    r, _ = ref_sim("loop_dyn_duckiebots", md=md)
+    bots = [ob for ob in r.objects if ob.kind == "duckiebot"]
+    T = 600
+    bpos = np.zeros((T, len(bots), 2)); bang = np.zeros((T, len(bots))); bcor = np.zeros((T, len(bots), 4, 2))
+    for t in range(T):
+        for k, ob in enumerate(bots):
+            ob.step_duckiebot(1 / 30, r.closest_curve_point, [])
+            bpos[t, k] = np.asarray(ob.pos, dtype=float)[[0, 2]]; bang[t, k] = ob.angle; bcor[t, k] = ob.obj_corners
+    np.savez_compressed(os.path.join(OUT, "ref_duckiebot_drive.npz"), pos=bpos, angle=bang, corners=bcor)
+
     # SURVEY Appendix A, re-derived
     r, ns = ref_sim("small_loop_only_duckies")
     TS = 0.585

@@ -285,10 +285,72 @@ class OracleObj:
     pedestrian_active: bool = False
     wiggle: float = math.pi / 15
     time: float = 0.0
+    # DuckiebotObj parameters (objects.py:180-228, non-DR branch)
+    follow_dist: float = 0.3
+    velocity: float = 0.1
+    gain: float = 2.0
+    trim: float = 0.0
+    radius: float = 0.0318
+    wheel_dist: float = WHEEL_DIST
+    robot_width: float = ROBOT_WIDTH
+    robot_length: float = ROBOT_LENGTH
+    k: float = 27.0
+    limit: float = 1.0
+    max_iterations: int = 1000
+
+    # objects.py:230-270 DuckiebotObj.step_duckiebot (pure pursuit on the lane curve)
+    def step_duckiebot(self, delta_time, closest_curve_point):
+        closest_point, closest_tangent = closest_curve_point(self.pos, self.angle)
+        if closest_point is None or closest_tangent is None:
+            raise Exception(f"Cannot find closest point/tangent from {self.pos}, {self.angle} ")
+        iterations = 0
+        lookup_distance = self.follow_dist
+        curve_point = None
+        while iterations < self.max_iterations:
+            follow_point = closest_point + closest_tangent * lookup_distance
+            curve_point, _ = closest_curve_point(follow_point, self.angle)
+            if curve_point is not None:
+                break
+            iterations += 1
+            lookup_distance *= 0.5
+        point_vec = curve_point - self.pos
+        point_vec /= np.linalg.norm(point_vec)
+        dot = np.dot(get_right_vec(self.angle), point_vec)
+        steering = self.gain * -dot
+        self._update_pos_bot([self.velocity, steering], delta_time)
+
+    # objects.py:283-336 DuckiebotObj._update_pos
+    def _update_pos_bot(self, action, deltaTime):
+        vel, angle = action
+        k_r_inv = (self.gain + self.trim) / self.k
+        k_l_inv = (self.gain - self.trim) / self.k
+        omega_r = (vel + 0.5 * angle * self.wheel_dist) / self.radius
+        omega_l = (vel - 0.5 * angle * self.wheel_dist) / self.radius
+        u_r = omega_r * k_r_inv
+        u_l = omega_l * k_l_inv
+        u_r_limited = max(min(u_r, self.limit), -self.limit)
+        u_l_limited = max(min(u_l, self.limit), -self.limit)
+        if u_l_limited == u_r_limited:
+            self.pos = self.pos + deltaTime * u_l_limited * get_dir_vec(self.angle)
+            return
+        w = (u_r_limited - u_l_limited) / self.wheel_dist
+        r = (self.wheel_dist * (u_l_limited + u_r_limited)) / (2 * (u_l_limited - u_r_limited))
+        rotAngle = w * deltaTime
+        r_vec = get_right_vec(self.angle)
+        px, py, pz = self.pos
+        cx = px + r * r_vec[0]
+        cz = pz + r * r_vec[2]
+        npx, npz = rotate_point(px, pz, cx, cz, rotAngle)
+        self.pos = np.array([npx, py, npz])
+        self.angle += rotAngle
+        self.y_rot += rotAngle * 180 / np.pi
+        # corners refreshed, obj_norm deliberately NOT (objects.py:333-336 vs :270)
+        self.obj_corners = agent_boundbox(self.pos, self.robot_width, self.robot_length,
+                                          get_dir_vec(self.angle), get_right_vec(self.angle))
 
     # objects.py:384-431
     def step(self, delta_time):
-        if self.static:
+        if self.static or self.kind == "duckiebot":
             return
         self.time += delta_time
         if not self.pedestrian_active:
@@ -324,6 +386,9 @@ class OracleObj:
         """objects.py:162-170 (static -> 0), :373-382 (dynamic)."""
         if self.static:
             return 0.0
+        if self.kind == "duckiebot":     # objects.py:272-281 uses self.pos
+            d = np.linalg.norm(agent_pos - self.pos)
+            return min(0, d - agent_safety_rad - self.safety_radius)
         d = np.linalg.norm(agent_pos - self.center)
         score = d - agent_safety_rad - self.safety_radius
         return min(0, score)
@@ -397,8 +462,10 @@ class OracleMap:
                 safety_radius=SAFETY_RAD_MULT * calculate_safety_radius(mn, mx, scale),
                 obj_corners=oc, obj_norm=generate_norm(oc), y_rot=float(np.rad2deg(angle)),
             )
-            if not static:
-                assert kind == "duckie", "oracle: only DuckieObj dynamics restated"
+            if not static and kind == "duckiebot":
+                pass                  # DuckiebotObj(obj_desc, ..., WHEEL_DIST, ROBOT_WIDTH, ROBOT_LENGTH) simulator.py:1005-1008
+            elif not static:
+                assert kind == "duckie", "oracle: DuckieObj / DuckiebotObj dynamics restated"
                 o.walk_distance = ts  # simulator.py:1010
                 o.heading = np.array([math.cos(angle), 0, -math.sin(angle)])  # collision.py:223
                 o.start = np.copy(pos)
@@ -780,7 +847,11 @@ class OracleSim:
         self.last_action = action
         self.speed = np.linalg.norm(self.cur_pos - prev_pos) / self.delta_time
         for obj in m.objects:
-            obj.step(self.delta_time)
+            if obj.kind == "duckiebot":
+                if not obj.static:
+                    obj.step_duckiebot(self.delta_time, self.closest_curve_point)
+            else:
+                obj.step(self.delta_time)
 
     # -- simulator.py:1685-1705
     def _compute_done_reward(self):

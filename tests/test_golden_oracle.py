@@ -75,6 +75,18 @@ def test_duckie_walk_bit_exact():
             assert np.array_equal(g["corners"][t, k], ob.obj_corners)
 
 
+def test_duckiebot_drive_bit_exact():
+    g = np.load(os.path.join(G, "ref_duckiebot_drive.npz"))
+    o = make_oracle("loop_dyn_duckiebots", do_reset=False)
+    bots = [ob for ob in o.map.objects if ob.kind == "duckiebot"]
+    for t in range(g["pos"].shape[0]):
+        for k, ob in enumerate(bots):
+            ob.step_duckiebot(1 / 30, o.closest_curve_point)
+            assert np.array_equal(g["pos"][t, k], np.asarray(ob.pos, float)[[0, 2]]) and g["angle"][t, k] == ob.angle
+            assert np.array_equal(g["corners"][t, k], ob.obj_corners)
+    assert np.abs(g["pos"][-1] - g["pos"][0]).max() > 0.5
+
+
 def test_survey_appendix_a_kat():
     k = json.load(open(os.path.join(G, "ref_kat.json")))
     o = make_oracle("small_loop_only_duckies", do_reset=False)

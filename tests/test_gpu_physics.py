@@ -177,6 +177,41 @@ def test_dynamic_duckies_match_oracle():
     sim.close()
 
 
+def test_dynamic_duckiebots_match_oracle():
+    """DuckiebotObj followers (objects.py:180-336): pure pursuit + own kinematics, stale SAT axes."""
+    N, T = 3, 900
+    sim = BatchedSimulator("loop_dyn_duckiebots", N, render=False, domain_rand=False, seed=31, max_steps=100000)
+    oracles = [make_oracle("loop_dyn_duckiebots", domain_rand=False, seed=31 + e, max_steps=100000) for e in range(N)]
+    zero = np.zeros((N, 2), np.float32)
+    rng = np.random.default_rng(4)
+    moved = 0.0
+    for t in range(T):
+        sim.step(zero)
+        for o in oracles:
+            o.step(np.zeros(2))
+        if t % 25 == 0 or t == T - 1:
+            cen, yrot = sim.read(_ffi.FIELD_OBJ_CENTER), sim.read(_ffi.FIELD_OBJ_YROT)
+            for e, o in enumerate(oracles):
+                bots = [ob for ob in o.map.objects if not ob.static]
+                for d, ob in enumerate(bots):
+                    assert np.abs(cen[e, d] - np.asarray(ob.pos, float)[[0, 2]]).max() <= 1e-9, (t, e, d)
+                    assert abs(yrot[e, d] - ob.y_rot) <= 1e-7
+            o = oracles[0]
+            ob = [x for x in o.map.objects if not x.static][t % 4]
+            poses = np.stack([ob.pos[0] + rng.uniform(-0.25, 0.25, 48), ob.pos[2] + rng.uniform(-0.25, 0.25, 48),
+                              rng.uniform(-3, 3, 48)], axis=1)
+            pr = sim.query(np.zeros(48, np.int32), poses)
+            for q, (x, z, a) in enumerate(poses):
+                pos = np.array([x, 0, z])
+                assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
+                assert bool(pr["valid"][q]) == o._valid_pose(pos, a)
+                assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
+    start = np.array([[3.5, 1.7], [1.3, 3.0], [6.7, 2.5], [2.5, 5.3]]) * 0.585
+    moved = np.abs(sim.read(_ffi.FIELD_OBJ_CENTER)[0, :4] - start).max()
+    assert moved > 0.5            # the followers actually drove along the loop
+    sim.close()
+
+
 def test_auto_reset_from_pool_and_checkpoint():
     N = 32
     sim = BatchedSimulator("small_loop", N, render=False, domain_rand=False, seed=50, auto_reset=True, max_steps=30)

@@ -97,6 +97,7 @@ def _obj_states(sim, e, scene):
     ("loop_only_duckies", 320, 240, True, False, 4),
     ("loop_only_duckies", 640, 480, False, True, 4),
     ("loop_pedestrians", 320, 240, False, False, 255),    # duckies mid-walk (wiggling y_rot)
+    ("loop_dyn_duckiebots", 320, 240, False, False, 120),  # follower bots (DuckiebotObj) + static duckies
 ])
 def test_frames_with_mesh_objects_match_oracle(map_name, W, H, distortion, dr, steps):
     """Static duckies (WorldObj) and walking pedestrians (DuckieObj): z-buffered mesh triangles
