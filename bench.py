@@ -147,9 +147,10 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, K, Wm = args.envs, args.steps, args.warmup
     sim = BatchedSimulator("small_loop", N, domain_rand=False, distortion=True, camera_width=W, camera_height=H,
@@ -172,7 +173,7 @@ def main():
     def sync_all():
         sim.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -190,14 +191,15 @@ def main():
     n_r, ms_r = sim.profile_read(_ffi.KERNEL_RENDER)
     n_s, ms_s = sim.profile_read(_ffi.KERNEL_STEP)
     tt = torch.tensor([t_local], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_max = float(tt.item())
 
     # ---- optional: frame all-gather over RCCL/xGMI (north star; link-bound, not in `value`)
     gather = None
-    if world > 1 and not args.no_gather:
+    force_gather = os.environ.get("DTSIM_BENCH_FORCE_GATHER") == "1" and dist.is_initialized()
+    if (world > 1 or force_gather) and not args.no_gather:
         frames = torch.as_tensor(sim.frames_device(), device=dev)
         try:
             out = torch.empty((world,) + tuple(frames.shape), dtype=torch.uint8, device=dev)
@@ -253,7 +255,7 @@ def main():
                                    "[BASELINE.json configs[2]]",
                        "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": False,
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_raster<false>", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "dtsim_render pass = k_cam_setup + k_raster<DR=0,OBJ=0> + k_resolve<OBJ=0> (HIP events around the three launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
                          "step_kernel_ms": ms_s / max(n_s, 1)},
@@ -264,7 +266,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     sim.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
