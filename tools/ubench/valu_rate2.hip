@@ -28,7 +28,12 @@ __global__ void k(float* out, float a, float b, unsigned m) {
     else if (MODE == 15) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a)); \
     else if (MODE == 16) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(x[i]), "v"(a) : "vcc"); \
     else if (MODE == 17) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(u[i]) : "v"(m)); \
-    else if (MODE == 18) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(u[i]) : "v"(x[i]));
+    else if (MODE == 18) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(u[i]) : "v"(x[i])); \
+    else if (MODE == 19) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(x[i]) : "v"(m), "v"(u[i])); \
+    else if (MODE == 20) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(x[i]) : "v"(m), "v"(u[i])); \
+    else if (MODE == 21) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b)); \
+    else if (MODE == 22) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(x[i]) : "v"(a)); \
+    else if (MODE == 23) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "v"(m));
     REP8(OP)
   }
   float s = 0; for (int i = 0; i < 8; ++i) s += x[i] + u[i] + (float)w[i];
@@ -51,5 +56,6 @@ int main() {
   run<16>("v_cmp_lt_f32"); run<14>("v_cvt_f32_ubyte1"); run<3>("v_cvt_flr_i32_f32"); run<2>("v_cvt_pk_u8_f32"); run<11>("v_cvt_f32_f16");
   run<18>("v_cvt_pkrtz_f16_f32"); run<1>("v_pk_fma_f16"); run<17>("v_pk_mul_f16"); run<4>("v_mul_u32_u24"); run<10>("v_mad_u32_u24");
   run<5>("v_lshl_add_u64"); run<6>("v_perm_b32"); run<9>("v_dot4_u32_u8");
+  run<19>("v_dot2_f32_f16"); run<20>("v_dot2c_f32_f16"); run<21>("v_fmac_f32"); run<22>("v_sub_f32"); run<23>("v_add_u32");
   return 0;
 }
