@@ -631,8 +631,10 @@ int dtsim_render(dtsim_t* h) {
     const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 31) / 32);
     std::vector<int32_t> qc(n_wg * 4);
     HIPCHK(hipMemcpy(qc.data(), h->d_qcount, qc.size() * 4, hipMemcpyDeviceToHost));
-    long long tot = 0, mx = 0;
-    for (int32_t v : qc) { tot += v; mx = std::max<long long>(mx, v); }
+    long long tot = 0, mx = 0, iters = 0, nonempty = 0;
+    for (int32_t v : qc) { tot += v; mx = std::max<long long>(mx, v); iters += (v + 63) / 64; nonempty += v > 0; }
+    fprintf(stderr, "[dtsim] resolve: %lld of %zu wavefront regions non-empty, %lld 64-lane iterations, lane utilisation %.1f%%\n",
+            nonempty, qc.size(), iters, iters ? 100.0 * tot / (64.0 * iters) : 0.0);
     int32_t dbg[8];
     HIPCHK(hipMemcpy(dbg, h->d_qcount + n_wg * 4, sizeof dbg, hipMemcpyDeviceToHost));
     fprintf(stderr, "[dtsim] resolve LDS triangle lists: %d (wg,env) pairs overflowed, %d fit, %d triangles staged\n", dbg[0], dbg[1], dbg[2]);

@@ -448,17 +448,72 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   const Ray rc = make_ray(nx, ny, c.tx, c.ty, c.sth, c.cth);
-  const float pcx = (nx + 1.f) * 0.5f * (float)R.W, pcy = (1.f - ny) * 0.5f * (float)R.H;   // pixel centre, px
-  float acc[3] = {0.f, 0.f, 0.f};
-  int pc = -1, pi = 0, pj = 0;
-  float col[3] = {0.f, 0.f, 0.f};
+  // 1. coverage: which primitive owns each sample.  key: 0 sky, 1 ground, 2|tj<<2|ti<<14 tile,
+  //    3|tri<<2 mesh triangle (depth func LESS against the plane hit).
+  uint32_t key[4];
+  int n_sky = 0, n_gnd = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
     const Hit hs = classify(c, m, tiles, rs);
     const float zplane = hs.cls == CLS_SKY ? 3.0e38f : hs.t;
-    if (OBJ && tbest[s] >= 0 && zbest[s] < zplane) {      // depth func LESS
-      const ScreenTri& st = tris[tbest[s]];
+    if (OBJ && tbest[s] >= 0 && zbest[s] < zplane) key[s] = 3u | ((uint32_t)tbest[s] << 2);
+    else if (hs.cls == CLS_TILE) key[s] = 2u | ((uint32_t)hs.tj << 2) | ((uint32_t)hs.ti << 14);
+    else { key[s] = (uint32_t)hs.cls; n_sky += hs.cls == CLS_SKY; n_gnd += hs.cls == CLS_GROUND; }
+  }
+  // 2. shading: once per primitive, at the pixel centre, weighted by its sample count.  Sky and the
+  //    ground quad are single primitives; tiles / triangles are walked as a list of distinct keys so
+  //    that a wavefront runs max-over-lanes(distinct) passes of the expensive code, not one per sample.
+  float acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = (float)n_sky * c.hor[k];
+  if (n_gnd > 0) {
+    float t = 0.f, wx = 0.f, wz = 0.f;
+    plane_hit(c, rc, c.Cy - GROUND_Y, t, wx, wz);    // centre ray extrapolates when it misses (yla >= 0: t < 0)
+    if (!(rc.yla < 0.f)) {                           // oracle: keep the sample's own hit in that case
+#pragma unroll
+      for (int s = 3; s >= 0; --s)
+        if (key[s] == 1u) {
+          const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
+          plane_hit(c, rs, c.Cy - GROUND_Y, t, wx, wz);
+        }
+    }
+    const float ndl = ground_ndl(c, wx, wz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c.gnd[k] * fminf(c.base[k] + c.dif[k] * ndl, 1.f));
+  }
+  uint32_t todo = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) todo |= (key[s] & 3u) >= 2u ? (1u << s) : 0u;
+  float tI[3] = {0.f, 0.f, 0.f}, twx = 0.f, twz = 0.f;
+  bool have_tile_lit = false;
+  while (todo) {
+    const int s0 = __builtin_ctz(todo);
+    const uint32_t k0 = s0 == 0 ? key[0] : s0 == 1 ? key[1] : s0 == 2 ? key[2] : key[3];
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
+    float col[3];
+    if ((k0 & 3u) == 2u) {
+      if (!have_tile_lit) {                          // tile-plane hit and light of the centre ray: shared by all tiles
+        float t = 0.f;
+        if (rc.yla < 0.f) plane_hit(c, rc, c.Cy, t, twx, twz);
+        else {                                       // centre ray misses the plane: the sample's own hit (first tile sample)
+          const int sf = s0;
+          const Ray rs = make_ray(nx + ox[sf] * sxn, ny - oy[sf] * syn, c.tx, c.ty, c.sth, c.cth);
+          plane_hit(c, rs, c.Cy, t, twx, twz);
+        }
+        const float ndl = plane_ndl(c.L, c.sth, c.cth, rc, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tI[k] = fminf(c.base[k] + c.dif[k] * ndl, 1.f);
+        have_tile_lit = true;
+      }
+      const int tj = (int)((k0 >> 2) & 4095u), ti = (int)(k0 >> 14);
+      const float fx = twx * m.its - (float)ti, fz = twz * m.its - (float)tj;
+      tile_color(R, tiles[m.tile_off + tj * m.gw + ti], fx, fz, tI, col);
+    } else if (OBJ) {
+      const ScreenTri& st = tris[k0 >> 2];
+      const float pcx = (nx + 1.f) * 0.5f * (float)R.W, pcy = (1.f - ny) * 0.5f * (float)R.H;   // pixel centre, px
       const float b0 = ((st.sx[1] - pcx) * (st.sy[2] - pcy) - (st.sx[2] - pcx) * (st.sy[1] - pcy)) * st.inv_area;
       const float b1 = ((st.sx[2] - pcx) * (st.sy[0] - pcy) - (st.sx[0] - pcx) * (st.sy[2] - pcy)) * st.inv_area;
       const float b2 = 1.f - b0 - b1;
@@ -466,15 +521,11 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float v = (b0 * st.cw[0][k] + b1 * st.cw[1][k] + b2 * st.cw[2][k]) * inv;
-        acc[k] += fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f);
+        col[k] = fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f);
       }
-      continue;
-    }
-    if (!(hs.cls == pc && (hs.cls != CLS_TILE || (hs.ti == pi && hs.tj == pj)))) {
-      shade(c, m, R, tiles, hs, rc, col);
-      pc = hs.cls; pi = hs.ti; pj = hs.tj;
-    }
-    acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
+    } else { col[0] = col[1] = col[2] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
   }
   const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
   return pack_rgb(o);
