@@ -25,7 +25,7 @@ UNITS = [
     ("render.hip", ["-ffp-contract=fast"]),
     ("dtsim_api.hip", []),
 ]
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",
           "-I" + os.path.join(HERE, "..", "include")]
 
 

@@ -346,6 +346,8 @@ __device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
   return n0 + b * (n1 - n0);
 }
 
+// max(|a|, |b|) in one instruction (source modifiers; no NaN canonicalisation needed: inputs are finite)
+__device__ inline float absmax(float a, float b) { float r; asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // floor(x) as int in one instruction
 __device__ inline int flr_i32(float x) { int r; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 // v_cvt_f32_ubyteN: one instruction per texel channel (the compiler does not pick it)
@@ -671,17 +673,18 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
     // ---- fast path: one ray per pixel, straight-line (predicated) code so that the LDS
     // tile-record reads and the 8 texel loads of the 4 pixels are all in flight together.
+    // Per-pixel predicates are kept as bools (lane masks in SGPR pairs), not as VGPR bit fields.
     uint32_t px[PPT];
-    uint32_t edge_mask = 0;
+    bool edge[PPT];
     bool any_work = false;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) any_work |= (pv[k].flags & (PF_VALID | PF_SKY)) == PF_VALID;
     if (!__ballot(any_work)) {                       // wave-uniform: all sky / border
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) px[k] = (pv[k].flags & PF_VALID) ? hor_rgb : 0u;
+      for (int k = 0; k < PPT; ++k) { px[k] = (pv[k].flags & PF_VALID) ? hor_rgb : 0u; edge[k] = false; }
     } else {
       float fx[PPT], fz[PPT], gxs[PPT], gzs[PPT];
-      bool cand[PPT], is_tile[PPT];
+      bool cand[PPT], is_tile[PPT], fast[PPT];
       TileLds tr[PPT];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
@@ -695,55 +698,53 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         const bool ingrid = cand[k] & ((p.flags & PF_TILE_OK) != 0) & ((unsigned)ti < (unsigned)f.gw) & ((unsigned)tj < (unsigned)f.gh);
         const int idx = ingrid ? f.tile_off + (int)__umul24(tj, f.gw) + ti : f.tile_off;
         tr[k] = s_tiles[idx];
-        is_tile[k] = ingrid & ((tr[k].flags & 1u) != 0);
+        // flags: 0 absent, 1 present (untextured: exact path), 3 present + textured
+        is_tile[k] = ingrid & (tr[k].flags != 0u);
+        fast[k] = ingrid & (tr[k].flags == 3u);
       }
       uint2 top2[PPT], bot2[PPT];
       float ax[PPT], ay[PPT];
+      const uint8_t* tex_bytes = reinterpret_cast<const uint8_t*>(texels);
+      const uint32_t row_bytes = (uint32_t)tw1 * 4u;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const float x = fmaf(tr[k].mxz, fz[k], fmaf(tr[k].mxx, fx[k], tr[k].ox));
         const float y = fmaf(tr[k].myz, fz[k], fmaf(tr[k].myx, fx[k], tr[k].oy));
         ax[k] = __builtin_amdgcn_fractf(x); ay[k] = __builtin_amdgcn_fractf(y);
-        const int x0 = flr_i32(x) & xmask, y0 = flr_i32(y) & ymask;
-        const uint32_t* pt = texels + (tr[k].tex_off + __umul24(y0, tw1) + x0);   // always in bounds
-        __builtin_memcpy(&top2[k], pt, 8);
-        __builtin_memcpy(&bot2[k], pt + tw1, 8);
+        const uint32_t x0 = (uint32_t)(flr_i32(x) & xmask), y0 = (uint32_t)(flr_i32(y) & ymask);
+        // 32-bit byte offset from the (uniform) pool base -> saddr-form loads; always in bounds
+        const uint32_t off = (__umul24(y0, (uint32_t)tw1) + x0 + tr[k].tex_off) << 2;
+        __builtin_memcpy(&top2[k], tex_bytes + off, 8);
+        __builtin_memcpy(&bot2[k], tex_bytes + (off + row_bytes), 8);
       }
       bool need_ground = false;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const PixInv& p = pv[k];
-        // shared camera: pv.ndl already holds the lit factor min(base + dif*ndl, 1) (all channels equal)
-        const float I0 = DR ? fminf(fmaf(dif0, p.ndl, base0), 1.f) : p.ndl;
-        const float I1 = DR ? fminf(fmaf(dif1, p.ndl, base1), 1.f) : I0;
-        const float I2 = DR ? fminf(fmaf(dif2, p.ndl, base2), 1.f) : I0;
-        // bilinear as 4 weights (lighting folded in): w00 + w10 + w01 + w11 = I
-        const float wy1 = ay[k], wy0 = 1.f - ay[k];
+        // bilinear as 4 weights.  Shared camera: pv.ndl holds the lit factor min(base + dif*ndl, 1)
+        // (all channels equal) and is folded into the weights: w00 + w10 + w01 + w11 = I.
+        const float wy1 = DR ? ay[k] : ay[k] * p.ndl, wy0 = (DR ? 1.f : p.ndl) - wy1;
         const float w10_ = ax[k] * wy0, w11_ = ax[k] * wy1;
         const float w00_ = wy0 - w10_, w01_ = wy1 - w11_;
+        float v0 = fmaf(ubyte0(bot2[k].y), w11_, fmaf(ubyte0(bot2[k].x), w01_, fmaf(ubyte0(top2[k].y), w10_, ubyte0(top2[k].x) * w00_)));
+        float v1 = fmaf(ubyte1(bot2[k].y), w11_, fmaf(ubyte1(bot2[k].x), w01_, fmaf(ubyte1(top2[k].y), w10_, ubyte1(top2[k].x) * w00_)));
+        float v2 = fmaf(ubyte2(bot2[k].y), w11_, fmaf(ubyte2(bot2[k].x), w01_, fmaf(ubyte2(top2[k].y), w10_, ubyte2(top2[k].x) * w00_)));
+        if (DR) {
+          v0 *= fminf(fmaf(dif0, p.ndl, base0), 1.f);
+          v1 *= fminf(fmaf(dif1, p.ndl, base1), 1.f);
+          v2 *= fminf(fmaf(dif2, p.ndl, base2), 1.f);
+        }
         uint32_t rgb = 0;
-        {
-          const float v = fmaf(ubyte0(bot2[k].y), w11_, fmaf(ubyte0(bot2[k].x), w01_, fmaf(ubyte0(top2[k].y), w10_, ubyte0(top2[k].x) * w00_)));
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I0, 0, rgb);
-        }
-        {
-          const float v = fmaf(ubyte1(bot2[k].y), w11_, fmaf(ubyte1(bot2[k].x), w01_, fmaf(ubyte1(top2[k].y), w10_, ubyte1(top2[k].x) * w00_)));
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I1, 1, rgb);
-        }
-        {
-          const float v = fmaf(ubyte2(bot2[k].y), w11_, fmaf(ubyte2(bot2[k].x), w01_, fmaf(ubyte2(top2[k].y), w10_, ubyte2(top2[k].x) * w00_)));
-          rgb = __builtin_amdgcn_cvt_pk_u8_f32(v * I2, 2, rgb);
-        }
-        const float d = fminf(fminf(fx[k], 1.f - fx[k]), fminf(fz[k], 1.f - fz[k]));
-        // untextured tiles and everything that is not a plain tile interior: other paths
-        const bool textured = (tr[k].flags & 2u) != 0;
-        const bool tile_fast = is_tile[k] & textured;
-        const bool tile_edge = is_tile[k] & (!(d > p.mrg * f.its) | !textured);
-        const bool gcand = cand[k] & !is_tile[k];
-        need_ground |= gcand;
+        rgb = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0, rgb);
+        rgb = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, rgb);
+        rgb = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, rgb);
+        // interior test: every MSAA sample stays inside the tile  <=>  max(|fx-.5|, |fz-.5|) < .5 - mrg/tile_size
+        const float dmax = absmax(fx[k] - 0.5f, fz[k] - 0.5f);
+        const bool inside = dmax < fmaf(-p.mrg, f.its, 0.5f);
+        const bool tile_fast = fast[k] & inside;
+        need_ground |= cand[k] & !is_tile[k];
         px[k] = tile_fast ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
-        const bool edge = (((p.flags & PF_VALID) != 0) & ((p.flags & PF_ALWAYS_EDGE) != 0)) | tile_edge;
-        edge_mask |= edge ? (1u << k) : 0u;
+        edge[k] = ((p.flags & (PF_VALID | PF_ALWAYS_EDGE)) == (PF_VALID | PF_ALWAYS_EDGE)) | (is_tile[k] & !tile_fast);
       }
       if (__ballot(need_ground)) {                   // wave-uniform: ground quad beyond the map
         const EnvCam c = cams[e];                    // colours / ground-corner light: only needed here
@@ -763,7 +764,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
           rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[1] * fminf(c.base[1] + c.dif[1] * ndl, 1.f), 1, rgb);
           rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[2] * fminf(c.base[2] + c.dif[2] * ndl, 1.f), 2, rgb);
           px[k] = gfast ? rgb : px[k];
-          edge_mask |= (gcand & !gfast) ? (1u << k) : 0u;
+          edge[k] = edge[k] | (gcand & !gfast);
         }
       }
     }
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
           if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
 #pragma unroll
           for (int k = 0; k < PPT; ++k)
-            if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge_mask |= 1u << k;
+            if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
         }
       }
     }
@@ -799,11 +800,11 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
     // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
     // register budget): append them to this wavefront's queue region.
-    if (!R.no_msaa && __ballot(edge_mask != 0)) {    // wave-uniform
+    if (!R.no_msaa && __ballot(edge[0] | edge[1] | edge[2] | edge[3])) {    // wave-uniform
       const uint32_t etag = (uint32_t)(e - e0) << 8;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {                // per pixel slot: ballot -> rank -> masked store
-        const bool ek = (edge_mask >> k) & 1u;
+        const bool ek = edge[k];
         const unsigned long long mk = __ballot(ek);
         if (ek) {
           const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
