@@ -225,8 +225,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
     if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64));   // EnvCam[N] then EnvFast[N]
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
-      const size_t npix = (size_t)cfg->cam_height * cfg->cam_width;
-      const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 31) / 32);
+      const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + 31) / 32);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * 256 * 32 * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8) * sizeof(int32_t));
     }
@@ -614,8 +613,7 @@ int dtsim_render(dtsim_t* h) {
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   if (getenv("DTSIM_DEBUG_QUEUE")) {
-    const size_t npix_ = (size_t)R.W * R.H;
-    const size_t n_wg_ = ((npix_ + 1023) / 1024) * (((size_t)h->N + 31) / 32);
+    const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + 31) / 32);
     R.dbg = h->d_qcount + n_wg_ * 4;
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
   }
@@ -628,7 +626,7 @@ int dtsim_render(dtsim_t* h) {
   if (getenv("DTSIM_DEBUG_QUEUE")) {   // profiling aid: how many pixels took the exact MSAA path
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t npix = (size_t)R.W * R.H;
-    const size_t n_wg = ((npix + 1023) / 1024) * (((size_t)h->N + 31) / 32);
+    const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + 31) / 32);
     std::vector<int32_t> qc(n_wg * 4);
     HIPCHK(hipMemcpy(qc.data(), h->d_qcount, qc.size() * 4, hipMemcpyDeviceToHost));
     long long tot = 0, mx = 0, iters = 0, nonempty = 0;

@@ -141,6 +141,13 @@ static_assert(sizeof(ScreenTri) == 96, "ScreenTri is 96 bytes");
 struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
 struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };          // screen box + triangle range of one object
 
+// raster work decomposition: a workgroup owns a DT_TILE_W x DT_TILE_H pixel tile for 32 consecutive envs
+#define DT_TILE_W 64
+#define DT_TILE_H 16
+static inline size_t dt_raster_tiles(int W, int H) {
+  return (size_t)((W + DT_TILE_W - 1) / DT_TILE_W) * (size_t)((H + DT_TILE_H - 1) / DT_TILE_H);
+}
+
 struct RenderParams {
   int32_t N, W, H, distortion;
   int32_t domain_rand, n_maps, n_tile_recs, no_msaa;   // no_msaa: profiling ablation only (DTSIM_RASTER_NO_MSAA=1)

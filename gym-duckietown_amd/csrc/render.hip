@@ -8,33 +8,37 @@
 // Structure
 //   k_cam_setup : one thread per env -> EnvCam (camera centre, yaw, colours, ground-corner
 //                 lighting; with DR also pitch / frustum / light), 128 B per env.
-//   k_raster<DR>: workgroup = 4 independent wavefronts; a wavefront owns 256 consecutive
-//                 pixels of the frame (4 adjacent pixels per lane) and loops over
-//                 ENVS_PER_BLOCK envs.  Everything that does not depend on the env -- the
-//                 LUT entry of each pixel (NDC of the rectilinear source pixel: the fisheye
-//                 remap is folded into the ray set-up, there is no second pass) and, for the
-//                 shared camera (DR=false), the whole ray / ground-plane intersection in the
-//                 yaw-local frame, the light term and the MSAA edge margin -- is computed
-//                 once and kept in REGISTERS across the env loop; per env only the 128-B
-//                 EnvCam changes (wave-uniform scalar loads) and a pixel costs one 2-D
-//                 rotation + tile lookup (LDS) + one bilinear fetch (two 8-byte loads from
-//                 the L2-resident padded texture) + lighting.
+//   k_raster<DR,OBJ>: workgroup = 4 independent wavefronts owning a 64 x 16 pixel tile of the
+//                 frame (wavefront w: rows 4w..4w+3; lane l: column l of each row), looping over
+//                 ENVS_PER_BLOCK envs.  Adjacent lanes are adjacent pixels, so one texel-load
+//                 instruction touches neighbouring texture lines (TA coalescing) and the tile's
+//                 2-D texture footprint stays in L1.  Everything that does not depend on the env
+//                 -- the LUT entry of each pixel (NDC of the rectilinear source pixel: the
+//                 fisheye remap is folded into the ray set-up, there is no second pass) and, for
+//                 the shared camera (DR=false), the whole ray / tile-plane intersection in the
+//                 yaw-local frame, the light term and the MSAA edge margin -- is computed once
+//                 and kept in REGISTERS across the env loop; per env only the 64-B EnvFast
+//                 changes (one wave-uniform scalar load) and a pixel costs one 2-D rotation +
+//                 tile lookup (LDS) + one bilinear fetch (two 8-byte loads from the L2-resident
+//                 padded texture) with the lighting folded into the filter weights.
 //                 MSAA: pixels whose 4 samples may see different primitives (horizon, map
-//                 border, tile seams; conservative test) are compacted into a per-wavefront
-//                 LDS queue and re-shaded with the exact 4-sample resolve by whichever lanes
-//                 are free -- no workgroup barrier anywhere in the env loop.
-//                 Output: 12 B (4 px) per lane, contiguous across the wavefront => every
-//                 store instruction writes 768 contiguous bytes.
+//                 border, tile seams, mesh boxes; conservative test) are appended (ballot +
+//                 mbcnt, no atomics) to a per-wavefront global queue region.
+//                 Output: px -> wavefront-private LDS transpose -> 12 B (4 px) per lane, three
+//                 dword stores, 192 contiguous bytes per tile row.
+//   k_resolve<OBJ>: drains the queues 64 entries at a time with the exact 4-sample resolve
+//                 (coverage per sample, shading once per distinct primitive at the pixel centre;
+//                 mesh triangles z-buffered from a wavefront-local LDS chunk) and patches the
+//                 3 bytes of each edge pixel; stream-ordered after k_raster.
 //
 // Roofline: HBM-write bound by construction -- algorithmic bytes per env-step = W*H*3
-// (921 600 B at 640x480), written exactly once; LUT / textures / tables are shared by all
-// envs and stay in registers / LDS / L2.  float32 shading, uint8 output.
+// (921 600 B at 640x480), written once (+ the ~1.3 % edge pixels a second time); LUT / textures /
+// tables are shared by all envs and stay in registers / LDS / L2.  float32 shading, uint8 output.
 #include "dtsim_dev.h"
 
 #define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT 4             // pixels per thread
 #define WAVE_PIX (64 * PPT)
-#define STRIP (RB * PPT)  // pixels per workgroup
 #define ENVS_PER_BLOCK 32
 
 #define CLS_SKY 0
@@ -586,7 +590,7 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 
 // Edge-pixel queue: one fixed region per (workgroup, wavefront) of the raster launch, worst-case
 // sized (every pixel of every env of the chunk), so appends need no atomics; entry =
-// (env-in-chunk << 8) | pixel-in-wavefront.  k_resolve drains the regions 64 entries at a time.
+// (env-in-chunk << 8) | (row-slot k << 6 | lane).  k_resolve drains the regions 64 entries at a time.
 #define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
 #define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
 
@@ -601,9 +605,9 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
   const int tid = threadIdx.x;
   const int npix = R.W * R.H;
-  const int n_strips = (npix + STRIP - 1) / STRIP;
-  const int strip = blockIdx.x % n_strips;
-  const int chunk = blockIdx.x / n_strips;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  const int tile = blockIdx.x % n_tiles;
+  const int chunk = blockIdx.x / n_tiles;
   const int e0 = chunk * ENVS_PER_BLOCK;
   const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
   {  // stage the raster tile records of every map once per workgroup
@@ -612,9 +616,13 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   }
   __syncthreads();
 
+  // Pixel ownership: the workgroup owns a 64 x 16 pixel tile, wavefront w its rows 4w..4w+3, lane l
+  // column l of each of those rows (slot k = row).  Adjacent lanes are adjacent pixels, so the texel
+  // addresses of one load instruction are neighbours in the texture, and the 2D footprint of the tile
+  // keeps its texture lines in L1.
   const int wave = tid >> 6, lane = tid & 63;
-  const int wbase = strip * STRIP + wave * WAVE_PIX;   // first pixel of this wavefront
-  const int p0 = wbase + lane * PPT;
+  const int px_x = (tile % tiles_x) * DT_TILE_W + lane;
+  const int px_y0 = (tile / tiles_x) * DT_TILE_H + wave * PPT;
   const float aspect = (float)R.W / (float)R.H;
   const float ex_n = 0.375f * 2.f / (float)R.W * 1.01f, ey_n = 0.375f * 2.f / (float)R.H * 1.01f;
 
@@ -623,9 +631,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   bool ok[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int p = p0 + k;
-    if (p < npix) {
-      const float4 l = lut[p];
+    if (px_x < R.W && px_y0 + k < R.H) {
+      const float4 l = lut[(px_y0 + k) * R.W + px_x];
       nx[k] = l.x; ny[k] = l.y; ok[k] = l.z != 0.f;
     } else { nx[k] = ny[k] = 0.f; ok[k] = false; }
   }
@@ -655,7 +662,14 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
   uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   int qn = 0;                                           // wave-uniform queue fill
-  const bool full_store = (p0 + PPT <= npix) && ((npix & 3) == 0);
+  // Frame stores go through a wavefront-private LDS transpose: lane l then owns the 12 bytes of the
+  // 4 consecutive pixels (row l/16, columns 4(l%16)..+3) of the tile -> three dword stores per lane,
+  // 192 contiguous bytes per tile row.
+  uint32_t* s_px = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4) + wave * WAVE_PIX;
+  const int st_x = (tile % tiles_x) * DT_TILE_W + (lane & 15) * 4, st_y = px_y0 + (lane >> 4);
+  const bool aligned_rows = (R.W & 3) == 0;
+  const bool st_ok = aligned_rows && st_x < R.W && st_y < R.H;
+  const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
   const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
 
   for (int e = e0; e < e1; ++e) {
@@ -785,17 +799,23 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
       }
     }
 
-    uint8_t* dst = frames + ((size_t)e * npix + p0) * 3;
-    const uint32_t w0 = px[0] | (px[1] << 24);
-    const uint32_t w1 = (px[1] >> 8) | (px[2] << 16);
-    const uint32_t w2 = (px[2] >> 16) | (px[3] << 8);
-    if (full_store) {
-      uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);    // 12-byte aligned: p0 % 4 == 0
-      d32[0] = w0; d32[1] = w1; d32[2] = w2;
-    } else {
-      const uint32_t ws[3] = {w0, w1, w2};
-      for (int k = 0; k < PPT * 3; ++k)
-        if (p0 + k / 3 < npix) dst[k] = (uint8_t)(ws[k >> 2] >> (8 * (k & 3)));
+    if (aligned_rows) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) s_px[k * 64 + lane] = px[k];
+      const uint4 q = *reinterpret_cast<const uint4*>(s_px + lane * 4);   // same wavefront: DS ops are ordered
+      if (st_ok) {
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)e * npix * 3 + st_off);   // 12-byte aligned
+        d32[0] = q.x | (q.y << 24);
+        d32[1] = (q.y >> 8) | (q.z << 16);
+        d32[2] = (q.z >> 16) | (q.w << 8);
+      }
+    } else {                                           // odd widths: bytes, straight from the owning lane
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        if (px_x < R.W && px_y0 + k < R.H) {
+          uint8_t* dst = frames + ((size_t)e * npix + (size_t)(px_y0 + k) * R.W + px_x) * 3;
+          dst[0] = (uint8_t)px[k]; dst[1] = (uint8_t)(px[k] >> 8); dst[2] = (uint8_t)(px[k] >> 16);
+        }
     }
 
     // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         const unsigned long long mk = __ballot(ek);
         if (ek) {
           const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-          w_queue[qn + rank] = (uint16_t)(etag | (uint32_t)(lane * PPT + k));
+          w_queue[qn + rank] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
         }
         qn += __popcll(mk);
       }
@@ -828,8 +848,8 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
   EnvCam* s_cams = reinterpret_cast<EnvCam*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4));
   const int tid = threadIdx.x;
   const int npix = R.W * R.H;
-  const int n_strips = (npix + STRIP - 1) / STRIP;
-  const int strip = blockIdx.x % n_strips, chunk = blockIdx.x / n_strips;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  const int tile = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
   const int e0 = chunk * ENVS_PER_BLOCK, e1 = min(e0 + ENVS_PER_BLOCK, R.N);
   const int wave = tid >> 6, lane = tid & 63;
   const int total_wg = qcount[blockIdx.x * (RB / 64)] + qcount[blockIdx.x * (RB / 64) + 1] +
@@ -843,7 +863,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
     for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
   }
   __syncthreads();
-  const int wbase = strip * STRIP + wave * WAVE_PIX;
+  const int tile_x0 = (tile % tiles_x) * DT_TILE_W, wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * PPT;
   const int n = qcount[blockIdx.x * (RB / 64) + wave];
   const uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_cams + ENVS_PER_BLOCK) + wave * TRI_CAP;    // wavefront-local
@@ -851,7 +871,8 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
     const bool have = q0 + lane < n;
     const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
     const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
-    const float4 l = reinterpret_cast<const float4*>(R.lut)[wbase + lp];
+    const int pix = (wave_y0 + (lp >> 6)) * R.W + tile_x0 + (lp & 63);      // entries only exist for in-image pixels
+    const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
     const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
     float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
     int tbest[4] = {-1, -1, -1, -1};
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
       const MapU m = map_u(R.maps[c.map_id]);
       const ScreenTri* tris = OBJ ? R.stris + (size_t)(e0 + el) * R.max_tris : nullptr;
       const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
-      uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + wbase + lp) * 3;
+      uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + pix) * 3;
       dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
     }
   }
@@ -930,15 +951,14 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand,
                      (float)R.W / (float)R.H, cams, fasts, R.maps);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
-  const int npix = R.W * R.H;
-  const int n_strips = (npix + STRIP - 1) / STRIP;
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
+  const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
   const size_t lds2 = lds + ENVS_PER_BLOCK * sizeof(EnvCam);
   const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
-  const dim3 grid(n_strips * n_chunks);
+  const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
-  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds, s, R, cams, fasts, R.frames, R.texels,               \
+  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   const bool obj = R.max_tris > 0;
   if (R.domain_rand) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }
