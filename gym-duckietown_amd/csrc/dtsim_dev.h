@@ -142,8 +142,11 @@ struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2];
 struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };          // screen box + triangle range of one object
 
 // raster work decomposition: a workgroup owns a DT_TILE_W x DT_TILE_H pixel tile for 32 consecutive envs
-#define DT_TILE_W 64
-#define DT_TILE_H 16
+#ifndef DT_WAVE_W
+#define DT_WAVE_W 64                       // pixel columns of a wavefront's 256-pixel block (256x1 ... 32x8)
+#endif
+#define DT_TILE_W DT_WAVE_W
+#define DT_TILE_H (4 * (256 / DT_WAVE_W))  // 4 wavefronts stacked vertically
 static inline size_t dt_raster_tiles(int W, int H) {
   return (size_t)((W + DT_TILE_W - 1) / DT_TILE_W) * (size_t)((H + DT_TILE_H - 1) / DT_TILE_H);
 }

@@ -38,6 +38,10 @@
 
 #define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT 4             // pixels per thread
+#define WAVE_W DT_WAVE_W  // pixel columns per wavefront block (dtsim_dev.h)
+// pixel slot k of lane l is pixel number k*64 + l of the block, row-major: adjacent lanes = adjacent pixels
+#define SLOT_X(k, l) (((k) * 64 + (l)) % WAVE_W)
+#define SLOT_Y(k, l) (((k) * 64 + (l)) / WAVE_W)
 #define WAVE_PIX (64 * PPT)
 #define ENVS_PER_BLOCK 32
 
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   // addresses of one load instruction are neighbours in the texture, and the 2D footprint of the tile
   // keeps its texture lines in L1.
   const int wave = tid >> 6, lane = tid & 63;
-  const int px_x = (tile % tiles_x) * DT_TILE_W + lane;
-  const int px_y0 = (tile / tiles_x) * DT_TILE_H + wave * PPT;
+  const int tile_x0 = (tile % tiles_x) * DT_TILE_W;
+  const int wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
   const float aspect = (float)R.W / (float)R.H;
   const float ex_n = 0.375f * 2.f / (float)R.W * 1.01f, ey_n = 0.375f * 2.f / (float)R.H * 1.01f;
 
@@ -631,8 +635,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   bool ok[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    if (px_x < R.W && px_y0 + k < R.H) {
-      const float4 l = lut[(px_y0 + k) * R.W + px_x];
+    if (tile_x0 + SLOT_X(k, lane) < R.W && wave_y0 + SLOT_Y(k, lane) < R.H) {
+      const float4 l = lut[(wave_y0 + SLOT_Y(k, lane)) * R.W + tile_x0 + SLOT_X(k, lane)];
       nx[k] = l.x; ny[k] = l.y; ok[k] = l.z != 0.f;
     } else { nx[k] = ny[k] = 0.f; ok[k] = false; }
   }
@@ -663,10 +667,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   int qn = 0;                                           // wave-uniform queue fill
   // Frame stores go through a wavefront-private LDS transpose: lane l then owns the 12 bytes of the
-  // 4 consecutive pixels (row l/16, columns 4(l%16)..+3) of the tile -> three dword stores per lane,
-  // 192 contiguous bytes per tile row.
+  // 4 consecutive pixels 4l..4l+3 (row-major in the wavefront's block) -> three dword stores per lane,
+  // 3*WAVE_W contiguous bytes per block row.
   uint32_t* s_px = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4) + wave * WAVE_PIX;
-  const int st_x = (tile % tiles_x) * DT_TILE_W + (lane & 15) * 4, st_y = px_y0 + (lane >> 4);
+  const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
   const bool aligned_rows = (R.W & 3) == 0;
   const bool st_ok = aligned_rows && st_x < R.W && st_y < R.H;
   const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
@@ -812,8 +816,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     } else {                                           // odd widths: bytes, straight from the owning lane
 #pragma unroll
       for (int k = 0; k < PPT; ++k)
-        if (px_x < R.W && px_y0 + k < R.H) {
-          uint8_t* dst = frames + ((size_t)e * npix + (size_t)(px_y0 + k) * R.W + px_x) * 3;
+        if (tile_x0 + SLOT_X(k, lane) < R.W && wave_y0 + SLOT_Y(k, lane) < R.H) {
+          uint8_t* dst = frames + ((size_t)e * npix + (size_t)(wave_y0 + SLOT_Y(k, lane)) * R.W + tile_x0 + SLOT_X(k, lane)) * 3;
           dst[0] = (uint8_t)px[k]; dst[1] = (uint8_t)(px[k] >> 8); dst[2] = (uint8_t)(px[k] >> 16);
         }
     }
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
     for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
   }
   __syncthreads();
-  const int tile_x0 = (tile % tiles_x) * DT_TILE_W, wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * PPT;
+  const int tile_x0 = (tile % tiles_x) * DT_TILE_W, wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
   const int n = qcount[blockIdx.x * (RB / 64) + wave];
   const uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_cams + ENVS_PER_BLOCK) + wave * TRI_CAP;    // wavefront-local
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
     const bool have = q0 + lane < n;
     const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
     const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
-    const int pix = (wave_y0 + (lp >> 6)) * R.W + tile_x0 + (lp & 63);      // entries only exist for in-image pixels
+    const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;      // entries only exist for in-image pixels
     const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
     const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
     float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
