@@ -703,6 +703,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     } else {
       float fx[PPT], fz[PPT], gxs[PPT], gzs[PPT];
       bool cand[PPT], is_tile[PPT], fast[PPT];
+      bool need_ground = false;
       TileLds tr[PPT];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
@@ -718,7 +719,12 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         tr[k] = s_tiles[idx];
         // flags: 0 absent, 1 present (untextured: exact path), 3 present + textured
         is_tile[k] = ingrid & (tr[k].flags != 0u);
-        fast[k] = ingrid & (tr[k].flags == 3u);
+        // interior test: every MSAA sample stays inside the tile  <=>  max(|fx-.5|, |fz-.5|) < .5 - mrg/tile_size
+        const float dmax = absmax(fx[k] - 0.5f, fz[k] - 0.5f);
+        const bool inside = dmax < fmaf(-p.mrg, f.its, 0.5f);
+        fast[k] = ingrid & (tr[k].flags == 3u) & inside;       // plain textured tile interior: the one-ray result is exact
+        need_ground |= cand[k] & !is_tile[k];
+        edge[k] = ((p.flags & (PF_VALID | PF_ALWAYS_EDGE)) == (PF_VALID | PF_ALWAYS_EDGE)) | (is_tile[k] & !fast[k]);
       }
       uint2 top2[PPT], bot2[PPT];
       float ax[PPT], ay[PPT];
@@ -735,7 +741,6 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         __builtin_memcpy(&top2[k], tex_bytes + off, 8);
         __builtin_memcpy(&bot2[k], tex_bytes + (off + row_bytes), 8);
       }
-      bool need_ground = false;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const PixInv& p = pv[k];
@@ -756,13 +761,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0, rgb);
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, rgb);
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, rgb);
-        // interior test: every MSAA sample stays inside the tile  <=>  max(|fx-.5|, |fz-.5|) < .5 - mrg/tile_size
-        const float dmax = absmax(fx[k] - 0.5f, fz[k] - 0.5f);
-        const bool inside = dmax < fmaf(-p.mrg, f.its, 0.5f);
-        const bool tile_fast = fast[k] & inside;
-        need_ground |= cand[k] & !is_tile[k];
-        px[k] = tile_fast ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
-        edge[k] = ((p.flags & (PF_VALID | PF_ALWAYS_EDGE)) == (PF_VALID | PF_ALWAYS_EDGE)) | (is_tile[k] & !tile_fast);
+        px[k] = fast[k] ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
       }
       if (__ballot(need_ground)) {                   // wave-uniform: ground quad beyond the map
         const EnvCam c = cams[e];                    // colours / ground-corner light: only needed here
