@@ -306,6 +306,10 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
       memcpy(td.v, ms.verts + (size_t)t * 9, 36);
       memcpy(td.n, ms.normals + (size_t)t * 9, 36);
       memcpy(td.c, ms.colors + (size_t)t * 9, 36);
+      if (ms.uvs) memcpy(td.uv, ms.uvs + (size_t)t * 6, 24); else memset(td.uv, 0, 24);
+      td.tex = (ms.uvs && ms.tri_tex) ? ms.tri_tex[t] : -1; td.pad = 0;
+      if (td.tex >= n_textures) return fail(DTSIM_E_INVALID, "mesh %d triangle %d: texture %d not loaded", m, t, td.tex);
+      if (td.tex < 0) td.tex = -1;
       tris.push_back(td);
     }
     h->h_meshes.push_back(d);

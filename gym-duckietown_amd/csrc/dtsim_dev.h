@@ -106,7 +106,7 @@ void dt_launch_query(hipStream_t s, const SimArrays& A, const MapSet& M, const S
 // ---- raster -----------------------------------------------------------------
 struct TexDev { int32_t w, h, off, pad; };   // off: texel offset into the texel pool; storage is (h+1) x (w+1), padded for REPEAT
 struct MeshDev { int32_t n_tris, off; float mn[3], mx[3]; };   // off: triangle offset into the pool; model-space AABB
-struct TriDev { float v[3][3]; float n[3][3]; float c[3][3]; };
+struct TriDev { float v[3][3]; float n[3][3]; float c[3][3]; float uv[3][2]; int32_t tex, pad; };   // tex: texture index or -1
 
 struct RenderMapDev {       // per map, raster view of the grid + objects
   int32_t grid_w, grid_h, n_obj, n_tris;   // n_tris: total mesh triangles of the map's objects
@@ -136,8 +136,10 @@ struct alignas(16) ScreenTri {
   float cw[3][3];            // per-vertex lit colour (0..255) divided by w
   float inv_area;            // 0 => culled (behind the near plane / degenerate / invisible)
   int32_t index;             // position in the env's triangle order (z-buffer tie break)
+  float uw[3], vw[3];        // per-vertex texture coordinates divided by w
+  int32_t tex, pad;          // texture index of the material chunk, -1 = untextured
 };
-static_assert(sizeof(ScreenTri) == 96, "ScreenTri is 96 bytes");
+static_assert(sizeof(ScreenTri) == 128, "ScreenTri is 128 bytes");
 struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
 struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };          // screen box + triangle range of one object
 

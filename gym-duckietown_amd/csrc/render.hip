@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         st.cw[v][k] = fminf(td.c[v][k] * (c.base[k] + c.dif[k] * ndl), 1.f) * 255.f * iw;
+      st.uw[v] = td.uv[v][0] * iw; st.vw[v] = td.uv[v][1] * iw;
     }
+    st.tex = td.tex; st.pad = 0;
     const float area = (st.sx[1] - st.sx[0]) * (st.sy[2] - st.sy[0]) - (st.sx[2] - st.sx[0]) * (st.sy[1] - st.sy[0]);
     ok = ok && (area != 0.f);
     st.inv_area = ok ? 1.f / area : 0.f;
@@ -343,6 +345,25 @@ __device__ inline void tile_color(const RenderParams& R, const TileLds& tr, floa
     const float c01 = (float)((bot2.x >> (8 * k)) & 255u), c11 = (float)((bot2.y >> (8 * k)) & 255u);
     const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
     out[k] = (top + ay * (bot - top)) * I[k];
+  }
+}
+
+// GL_LINEAR / GL_REPEAT fetch of a mesh texture at (u, v) in texture coordinates; out in 0..1.
+// Any power-of-two size; storage is the padded (h+1) x (w+1) layout of the texel pool.
+__device__ inline void mesh_texel(const RenderParams& R, int tex, float u, float v, float out[3]) {
+  const TexDev td = R.tex[tex];
+  const float x = u * (float)td.w - 0.5f, y = v * (float)td.h - 0.5f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float ax = x - x0f, ay = y - y0f;
+  const int x0 = ((int)x0f) & (td.w - 1), y0 = ((int)y0f) & (td.h - 1);
+  const uint32_t* pt = R.texels + td.off + y0 * (td.w + 1) + x0;
+  const uint32_t t00 = pt[0], t10 = pt[1], t01 = pt[td.w + 1], t11 = pt[td.w + 2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
+    const float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
+    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
+    out[k] = (top + ay * (bot - top)) * (1.f / 255.f);
   }
 }
 
@@ -528,10 +549,16 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
       const float b1 = ((st.sx[2] - pcx) * (st.sy[0] - pcy) - (st.sx[0] - pcx) * (st.sy[2] - pcy)) * st.inv_area;
       const float b2 = 1.f - b0 - b1;
       const float inv = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
+      float tx[3] = {1.f, 1.f, 1.f};                   // GL_MODULATE with the chunk's texture (objmesh.py:360-375)
+      if (st.tex >= 0) {
+        const float u = (b0 * st.uw[0] + b1 * st.uw[1] + b2 * st.uw[2]) * inv;
+        const float v = (b0 * st.vw[0] + b1 * st.vw[1] + b2 * st.vw[2]) * inv;
+        mesh_texel(R, st.tex, u == u ? u : 0.f, v == v ? v : 0.f, tx);
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float v = (b0 * st.cw[0][k] + b1 * st.cw[1][k] + b2 * st.cw[2][k]) * inv;
-        col[k] = fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f);
+        col[k] = fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f) * tx[k];
       }
     } else { col[0] = col[1] = col[2] = 0.f; }
 #pragma unroll

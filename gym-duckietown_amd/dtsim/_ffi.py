@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 32, 8, 40
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 8, 32, 16
@@ -89,7 +89,7 @@ class Texture(C.Structure):
 
 class Mesh(C.Structure):
     _fields_ = [("n_tris", C.c_int32), ("verts", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
-                ("colors", C.POINTER(C.c_float))]
+                ("colors", C.POINTER(C.c_float)), ("uvs", C.POINTER(C.c_float)), ("tri_tex", C.POINTER(C.c_int32))]
 
 
 class InitState(C.Structure):

@@ -200,21 +200,7 @@ def _cone(base_c, tip, r, n, color):
     return tris, nrms, cols
 
 
-class MeshData:
-    """What ObjMesh exposes to the hot path (objmesh.py:181-232): float32 triangle soup
-    [T,3,3] verts / normals / per-vertex Kd colours, and min_coords / max_coords."""
-
-    def __init__(self, verts, normals, colors):
-        self.verts = np.ascontiguousarray(verts, dtype=np.float32)
-        self.normals = np.ascontiguousarray(normals, dtype=np.float32)
-        self.colors = np.ascontiguousarray(colors, dtype=np.float32)
-        # objmesh.py:230-232
-        self.min_coords = self.verts.min(axis=0).min(axis=0)
-        self.max_coords = self.verts.max(axis=0).max(axis=0)
-
-    @property
-    def n_tris(self):
-        return self.verts.shape[0]
+from .objmesh import MeshData, load_obj  # noqa: E402  (MeshData: what ObjMesh exposes to the hot path)
 
 
 def _finish(parts, lo, hi):
@@ -263,3 +249,138 @@ def mesh_extents(kinds=("duckie",)) -> dict:
         m = get_mesh(k)
         out[k] = (m.min_coords, m.max_coords)
     return out
+
+
+# ------------------------------------------------------------ asset library ----
+def load_image_rgba(path: str) -> np.ndarray:
+    """Image file -> RGBA8 [h,w,4] in GL row order (row 0 = bottom, graphics.py:69-169).  Alpha is
+    carried but unused (the reference never enables blending for tiles / meshes)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        arr = np.asarray(im.convert("RGBA"), dtype=np.uint8)
+    return gl_rows(arr)
+
+
+def _pow2_near(n: int) -> int:
+    return 1 << max(0, int(round(math.log2(max(int(n), 1)))))
+
+
+def to_pow2(tex: np.ndarray, size=None) -> np.ndarray:
+    """The raster wraps texel indices with a mask: textures must be power-of-two sized (and all
+    tile textures of one simulator share one size).  Other sizes are resampled (bilinear); the
+    reference would upload them as they are, so this is the one place where a real asset can
+    render differently -- power-of-two assets (the duckietown ones are 512 / 1024) are untouched."""
+    h, w = tex.shape[:2]
+    th, tw = (size, size) if size else (_pow2_near(h), _pow2_near(w))
+    if (h, w) == (th, tw):
+        return np.ascontiguousarray(tex)
+    from PIL import Image
+    im = Image.fromarray(tex[::-1]).resize((tw, th), Image.BILINEAR)
+    return gl_rows(np.asarray(im, dtype=np.uint8))
+
+
+class AssetLibrary:
+    """Resolves maps, tile textures and meshes the way the reference asks `duckietown_world` for them
+    (by basename / by `tiles-processed/<style>/<kind>/texture`, simulator.py:638,779; objmesh.py:37),
+    from a directory tree `root` (e.g. a checkout of duckietown-world's `data/`), falling back to the
+    deterministic fixtures of this module for anything that is not found.  `root=None` (and no
+    `DTSIM_ASSET_ROOT` in the environment) => fixtures only."""
+
+    IMG_EXT = (".jpg", ".jpeg", ".png")
+
+    def __init__(self, root: str | None = None, style: str = "photos"):
+        import os
+        root = root if root is not None else os.environ.get("DTSIM_ASSET_ROOT")
+        self.root = os.path.abspath(root) if root else None
+        self.style = style
+        self._by_name: dict = {}
+        self._files: list = []
+        if self.root:
+            if not os.path.isdir(self.root):
+                raise FileNotFoundError(f"asset root {self.root!r} is not a directory")
+            for d, _sub, fs in sorted(os.walk(self.root)):
+                for f in sorted(fs):
+                    p = os.path.join(d, f)
+                    self._files.append(p)
+                    self._by_name.setdefault(f, p)          # first hit wins (get_resource_path)
+        self._meshes: dict = {}
+        self._tex: dict = {}
+
+    # get_resource_path(basename)
+    def resolve(self, basename: str):
+        return self._by_name.get(basename)
+
+    def map_data(self, name: str) -> dict:
+        import os
+        if name in MAPS or os.path.isfile(name):
+            return get_map(name)
+        p = self.resolve(f"{name}.yaml")
+        if p is None:
+            raise KeyError(f"unknown map {name!r}: not a fixture {sorted(MAPS)}, not a file, not under the asset root")
+        import yaml
+        with open(p) as f:
+            return yaml.safe_load(f)
+
+    def tile_texture_file(self, kind: str):
+        """get_texture_file(f"tiles-processed/{style}/{kind}/texture")[0] (simulator.py:638)."""
+        import os
+        tail = os.path.join("tiles-processed", self.style, kind, "texture")
+        for p in self._files:
+            stem, ext = os.path.splitext(p)
+            if ext.lower() in self.IMG_EXT and stem.endswith(tail):
+                return p
+        return None
+
+    def tile_texture(self, kind: str) -> np.ndarray:
+        if kind not in self._tex:
+            p = self.tile_texture_file(kind) if self.root else None
+            self._tex[kind] = to_pow2(load_image_rgba(p)) if p else get_texture(kind)
+        return self._tex[kind]
+
+    def mesh(self, kind: str) -> MeshData:
+        """get_mesh(kind) (objmesh.py:28-52): `<kind>.obj` by basename; stand-in mesh otherwise."""
+        if kind not in self._meshes:
+            p = self.resolve(f"{kind}.obj") if self.root else None
+            if p:
+                m = load_obj(p, self.resolve, name=kind)
+                m.textures = [to_pow2(load_image_rgba(t)) for t in m.texture_files]
+            else:
+                m = get_mesh(kind)
+            self._meshes[kind] = m
+        return self._meshes[kind]
+
+    # chassis colours by name (duckietown_world.get_duckiebot_color_from_colorname is not available
+    # offline; these are the usual RGB triples -- parity unpinned)
+    BOT_COLORS = {"red": (1.0, 0.0, 0.0), "green": (0.0, 0.5, 0.0), "blue": (0.0, 0.0, 1.0), "yellow": (1.0, 1.0, 0.0),
+                  "grey": (0.3, 0.3, 0.3), "gray": (0.3, 0.3, 0.3), "white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0),
+                  "orange": (1.0, 0.5, 0.0), "purple": (0.5, 0.0, 0.5), "pink": (1.0, 0.4, 0.7), "cyan": (0.0, 1.0, 1.0)}
+
+    def object_mesh(self, desc: dict):
+        """(cache key, mesh) of one map object, following simulator.py:958-974: duckiebots use the
+        `duckiebot` mesh with the chassis materials recoloured, `sign*` kinds use `sign_generic` with
+        the `April_Tag` material's texture replaced by `<kind>.png`, everything else `<kind>.obj`."""
+        import os
+        kind = desc["kind"]
+        if not self.root:
+            return ("duckie" if kind == "duckie" else "*"), get_mesh(kind)
+        if kind == "duckiebot":
+            cname = desc.get("color", "red")
+            key, base, p = f"duckiebot:{cname}", "duckiebot", self.resolve("duckiebot.obj")
+            col = np.array(self.BOT_COLORS.get(cname, self.BOT_COLORS["red"]))
+            change = {"gkmodel0_chassis_geom0_mat_001-material": {"Kd": col},
+                      "gkmodel0_chassis_geom0_mat_001-material.001": {"Kd": col}}
+        elif kind.startswith("sign"):
+            key, base, p = kind, "sign_generic", self.resolve("sign_generic.obj")
+            change = {"April_Tag": {"map_Kd": f"{kind}.png"}}
+        else:
+            key, base, p, change = kind, kind, self.resolve(f"{kind}.obj"), None
+        if p is None:
+            return ("duckie" if kind == "duckie" else "*"), get_mesh(kind)
+        if key not in self._meshes:
+            m = load_obj(p, self.resolve, name=key, change_materials=change)
+            m.textures = [to_pow2(load_image_rgba(t)) for t in m.texture_files]
+            self._meshes[key] = m
+        return key, self._meshes[key]
+
+    def mesh_extents(self, kinds) -> dict:
+        return {k: (self.mesh(k).min_coords, self.mesh(k).max_coords) for k in kinds}

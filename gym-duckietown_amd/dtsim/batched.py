@@ -40,7 +40,7 @@ class BatchedSimulator:
                  render: bool = True, auto_reset: bool = False, delay_steps: int = 5, device: int = 0,
                  stream: Optional[int] = None, profile: bool = False, actions_f64: bool = False,
                  map_cycle: bool = False, transform_uses_width: bool = False, map_data: Optional[dict] = None,
-                 do_reset: bool = True):
+                 asset_root: Optional[str] = None, style: str = "photos", do_reset: bool = True):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
         self._device = int(device)
@@ -82,25 +82,40 @@ class BatchedSimulator:
         _ffi.check(self._lib, self._lib.dtsim_create(C.byref(cfg), C.byref(self._h)))
 
         # ---- maps + assets (one-time host prep)
+        # Assets come from `asset_root` (or $DTSIM_ASSET_ROOT: a duckietown-world style data tree with
+        # MapFormat1 YAML maps, tiles-processed/<style>/<kind>/texture.* and <kind>.obj/.mtl meshes)
+        # with the deterministic fixtures of dtsim/assets.py as the fallback.
+        self.library = assets.AssetLibrary(asset_root, style)
+        use_lib = self.library if self.library.root else None
         names = [map_name] if isinstance(map_name, str) else list(map_name)
-        datas = [map_data] if (map_data is not None) else [assets.get_map(n) for n in names]
+        datas = [map_data] if (map_data is not None) else [self.library.map_data(n) for n in names]
         self.map_names = [assets.map_basename(n) for n in names]
         self.meshes: Dict[str, assets.MeshData] = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
-        mesh_order = ["duckie", "*"]
-        first = [maps.interpret_map(d, n, self.meshes, transform_uses_width) for d, n in zip(datas, self.map_names)]
+        first = [maps.interpret_map(d, n, self.meshes, transform_uses_width, library=use_lib)
+                 for d, n in zip(datas, self.map_names)]
+        mesh_order = list(self.meshes)                 # "duckie", "*", then every object mesh the library loaded
         tex_kinds: List[str] = []
         for mt in first:
             for kd in mt.texture_kinds:
                 if kd not in tex_kinds:
                     tex_kinds.append(kd)
         self.texture_kinds = tex_kinds
-        self.textures = [assets.get_texture(kd) for kd in tex_kinds]
+        tile_tex = [self.library.tile_texture(kd) for kd in tex_kinds]
+        if tile_tex:                                   # the raster needs one size for all tile textures
+            side = max(max(t.shape[0], t.shape[1]) for t in tile_tex)
+            tile_tex = [assets.to_pow2(t, side) if t.shape[:2] != (side, side) else t for t in tile_tex]
+        self.textures = list(tile_tex)
+        mesh_tex_base: Dict[str, int] = {}             # mesh key -> index of its first texture
+        for mk in mesh_order:
+            mesh_tex_base[mk] = len(self.textures)
+            self.textures.extend(self.meshes[mk].textures)
         tex_ids = {kd: i for i, kd in enumerate(tex_kinds)} if render else None
         self.maps: List[maps.MapTables] = [
-            maps.interpret_map(d, n, self.meshes, transform_uses_width, texture_ids=tex_ids)
+            maps.interpret_map(d, n, self.meshes, transform_uses_width, texture_ids=tex_ids, library=use_lib)
             for d, n in zip(datas, self.map_names)]
         if render:
-            tarr = (_ffi.Texture * len(self.textures))()
+            keep = []
+            tarr = (_ffi.Texture * max(len(self.textures), 1))()
             for i, t in enumerate(self.textures):
                 tarr[i].width, tarr[i].height = t.shape[1], t.shape[0]
                 tarr[i].rgba = t.ctypes.data_as(C.POINTER(C.c_uint8))
@@ -111,6 +126,11 @@ class BatchedSimulator:
                 marr[i].verts = m.verts.ctypes.data_as(C.POINTER(C.c_float))
                 marr[i].normals = m.normals.ctypes.data_as(C.POINTER(C.c_float))
                 marr[i].colors = m.colors.ctypes.data_as(C.POINTER(C.c_float))
+                if m.textures:
+                    gt = np.where(m.tri_tex >= 0, m.tri_tex + mesh_tex_base[mk], -1).astype(np.int32)
+                    keep.append(gt)
+                    marr[i].uvs = m.uvs.ctypes.data_as(C.POINTER(C.c_float))
+                    marr[i].tri_tex = gt.ctypes.data_as(C.POINTER(C.c_int32))
             _ffi.check(self._lib, self._lib.dtsim_set_assets(self._h, tarr, len(self.textures), marr, len(mesh_order)))
         mesh_ids = {mk: i for i, mk in enumerate(mesh_order)} if render else {}
         farr = (_ffi.Map * len(self.maps))()

@@ -187,7 +187,8 @@ class MapTables:
 
 
 def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, MeshData]] = None,
-                  transform_uses_width: bool = False, texture_ids: Optional[Dict[str, int]] = None) -> MapTables:
+                  transform_uses_width: bool = False, texture_ids: Optional[Dict[str, int]] = None,
+                  library=None) -> MapTables:
     """MapFormat1 dict -> MapTables.  `texture_ids` maps tile kind -> texture index
     (filled in by the caller after it decided which textures to upload)."""
     if "tile_size" not in map_data:
@@ -250,8 +251,13 @@ def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, 
         kind = desc["kind"]
         if kind == "floor_tag":                   # simulator.py:971-972
             continue
-        mesh_kind = "duckie" if kind == "duckie" else "*"
-        mesh = (meshes or {}).get(mesh_kind) or get_mesh(kind)
+        if library is not None:                   # real assets: one mesh per object kind / variant
+            mesh_kind, mesh = library.object_mesh(desc)
+            if meshes is not None:
+                meshes.setdefault(mesh_kind, mesh)
+        else:
+            mesh_kind = "duckie" if kind == "duckie" else "*"
+            mesh = (meshes or {}).get(mesh_kind) or get_mesh(kind)
         # get_transform [R] (README.md:239) + weird_from_cartesian (simulator.py:1640-1652)
         Hc = W if transform_uses_width else H
         px, pz = desc["pos"][0], desc["pos"][1]

@@ -134,7 +134,7 @@ class Simulator(_EnvBase):
                 accept_start_angle_deg=accept_start_angle_deg, user_tile_start=user_tile_start, seed=seed,
                 distortion=self.distortion, dynamics_rand=dynamics_rand, num_tris_distractors=num_tris_distractors,
                 color_ground=color_ground, color_sky=color_sky, action_mode=self._ACTION_MODE, actions_f64=True,
-                device=device, do_reset=False, **env_kwargs)
+                device=device, style=style, do_reset=False, **env_kwargs)
         except KeyError as e:
             raise InvalidMapException("Cannot load map data", map_name=map_name) from e
         mt = self._sim.maps[0]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 1
+#define DTSIM_ABI_VERSION 2
 
 /* error codes */
 #define DTSIM_OK 0
@@ -155,6 +155,10 @@ typedef struct dtsim_mesh {
   const float* verts;              /* [n_tris][3][3] */
   const float* normals;            /* [n_tris][3][3] */
   const float* colors;             /* [n_tris][3][3] per-vertex Kd */
+  const float* uvs;                /* [n_tris][3][2] texture coordinates (objmesh.py:199-207), or NULL */
+  const int32_t* tri_tex;          /* [n_tris] texture index of the triangle's material chunk (map_Kd,
+                                      objmesh.py:268-275: GL_LINEAR / GL_REPEAT, MODULATE with the lit
+                                      vertex colour), -1 = untextured; NULL = all untextured */
 } dtsim_mesh;
 
 /* Everything Simulator.reset() decides for one env (simulator.py:528-763).  Drawn on

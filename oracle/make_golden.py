@@ -38,6 +38,16 @@ EXT = assets.mesh_extents(("duckie",))
 MAPS = ["small_loop", "small_loop_only_duckies", "loop_only_duckies"]
 
 
+# (tag, obj stem, change_materials) -- the variants simulator.py:958-974 / 2091-2099 build
+OBJ_CASES = [
+    ("cone", "cone", None),
+    ("sign_stop", "sign_generic", {"April_Tag": {"map_Kd": "sign_stop.png"}}),
+    ("tree", "tree", None),
+    ("duckiebot_blue", "duckiebot", {"gkmodel0_chassis_geom0_mat_001-material": {"Kd": np.array([0.0, 0.0, 1.0])},
+                                    "gkmodel0_chassis_geom0_mat_001-material.001": {"Kd": np.array([0.0, 0.0, 1.0])}}),
+]
+
+
 def ref_sim(map_name, domain_rand=False, seed=None, md=None):
     md = md if md is not None else assets.get_map(map_name)
     sim, ns = refstub.make_simulator(copy.deepcopy(md), domain_rand=domain_rand, mesh_extents=EXT)
@@ -178,6 +188,16 @@ def main():
         dout[f"sx_{w}x{h}"] = np.rint(rx.astype(np.float64)).astype(np.int16)
         dout[f"sy_{w}x{h}"] = np.rint(ry.astype(np.float64)).astype(np.int16)
     np.savez_compressed(os.path.join(OUT, "ref_distortion.npz"), **dout)
+    # ObjMesh parser (objmesh.py:55-358, the reference's own code) on the procedural asset tree of
+    # tests/golden/make_assets.py: triangle soup in draw order, extents, per-chunk textures
+    lib = assets.AssetLibrary(os.path.join(OUT, "assets"))
+    om = {}
+    for tag, stem, change in OBJ_CASES:
+        r = refstub.ref_objmesh(lib.resolve(stem + ".obj"), stem, lib.resolve, change)
+        for k in ("verts", "uvs", "normals", "colors", "chunk_sizes", "min_coords", "max_coords"):
+            om[f"{tag}_{k}"] = r[k]
+        om[f"{tag}_textures"] = np.array(["" if t is None else os.path.basename(t) for t in r["textures"]])
+    np.savez_compressed(os.path.join(OUT, "ref_objmesh.npz"), **om)
     print("golden fixtures written to", OUT)
 
 

@@ -216,7 +216,8 @@ def _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc):
 
 def _object_instances(scene, obj_states):
     """World-space lit-ready triangles of all visible objects: list of
-    (verts [T,3,3], normals [T,3,3], colors [T,3,3])."""
+    (verts [T,3,3], normals [T,3,3], colors [T,3,3], uvs [T,3,2], per-triangle texture image or None
+    -- the chunk's map_Kd texture, objmesh.py:268-275)."""
     out = []
     for k, o in enumerate(scene.m.objects):
         st = obj_states[k] if obj_states is not None else None
@@ -235,7 +236,12 @@ def _object_instances(scene, obj_states):
         Vw = np.stack([V[..., 0] * c + V[..., 2] * s, V[..., 1], -V[..., 0] * s + V[..., 2] * c], axis=-1) + pos
         Nn = mesh.normals.astype(np.float64)
         Nw = np.stack([Nn[..., 0] * c + Nn[..., 2] * s, Nn[..., 1], -Nn[..., 0] * s + Nn[..., 2] * c], axis=-1)
-        out.append((Vw, Nw, mesh.colors.astype(np.float64)))
+        T = Vw.shape[0]
+        uvs = np.asarray(getattr(mesh, "uvs", np.zeros((T, 3, 2))), dtype=np.float64)
+        texs = getattr(mesh, "textures", None) or []
+        tri_tex = np.asarray(getattr(mesh, "tri_tex", np.full(T, -1)))
+        tri_img = [texs[t] if (t >= 0 and t < len(texs)) else None for t in tri_tex]
+        out.append((Vw, Nw, mesh.colors.astype(np.float64), uvs, tri_img))
     return out
 
 
@@ -250,7 +256,7 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
 
     # objects: eye-space vertices, per-vertex lit colours, screen coordinates
     tris = []
-    for Vw, Nw, Cc in _object_instances(scene, obj_states):
+    for Vw, Nw, Cc, UV, TI in _object_instances(scene, obj_states):
         Pe = cam.to_eye(Vw)
         Ne = cam.normal_to_eye(Nw)
         Ne = Ne / np.linalg.norm(Ne, axis=-1, keepdims=True)
@@ -261,7 +267,7 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
             sx = (Pe[..., 0] / w / cam.tx + 1) * 0.5 * W       # pixel coords, x right
             sy = (1 - Pe[..., 1] / w / cam.ty) * 0.5 * H       # y down
         for k in np.flatnonzero(ok):
-            tris.append((sx[k], sy[k], w[k], lit[k]))
+            tris.append((sx[k], sy[k], w[k], lit[k], UV[k], TI[k]))
 
     acc = np.zeros((H, W, 3))
     for (ox, oy) in SAMPLE_OFFSETS:
@@ -291,7 +297,7 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
         depth[tok] = tt[tok]; t_s[tok] = tt[tok]; wx_s[tok] = wxt[tok]; wz_s[tok] = wzt[tok]
         col = _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc)
         # objects: z-buffered triangles, coverage at the sample, colour at the pixel centre
-        for (sx, sy, w, lit) in tris:
+        for (sx, sy, w, lit, uv, timg) in tris:
             x0 = max(int(math.floor(sx.min() - 1)), 0); x1 = min(int(math.ceil(sx.max() + 1)), W - 1)
             y0 = max(int(math.floor(sy.min() - 1)), 0); y1 = min(int(math.ceil(sy.max() + 1)), H - 1)
             if x0 > x1 or y0 > y1:
@@ -323,6 +329,13 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
             with np.errstate(divide="ignore", invalid="ignore"):
                 colc = (c0[..., None] * lit[0] / w[0] + c1[..., None] * lit[1] / w[1] + c2[..., None] * lit[2] / w[2]) / iwc[..., None]
             colc = np.clip(np.nan_to_num(colc, nan=0.0, posinf=255.0, neginf=0.0), 0.0, 255.0)
+            if timg is not None:               # GL_MODULATE with the material's texture (GL_LINEAR / GL_REPEAT)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    uc = (c0 * uv[0, 0] / w[0] + c1 * uv[1, 0] / w[1] + c2 * uv[2, 0] / w[2]) / iwc
+                    vc = (c0 * uv[0, 1] / w[0] + c1 * uv[1, 1] / w[1] + c2 * uv[2, 1] / w[2]) / iwc
+                uc, vc = np.nan_to_num(uc, nan=0.0, posinf=0.0, neginf=0.0), np.nan_to_num(vc, nan=0.0, posinf=0.0, neginf=0.0)
+                uc, vc = np.where(win, uc, 0.0), np.where(win, vc, 0.0)
+                colc = colc * (_bilinear_repeat(timg, uc, vc) / 255.0)
             sub[win] = d[win]
             csub = col[y0:y1 + 1, x0:x1 + 1]
             csub[win] = colc[win]

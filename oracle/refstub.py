@@ -159,6 +159,7 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
         ns.graphics = importlib.import_module("gym_duckietown.graphics")
         ns.objects = importlib.import_module("gym_duckietown.objects")
         ns.distortion = importlib.import_module("gym_duckietown.distortion")
+        ns.objmesh = importlib.import_module("gym_duckietown.objmesh")
         ns.randomizer = importlib.import_module("gym_duckietown.randomization.randomizer")
     finally:
         sys.path.remove(REFERENCE_SRC)
@@ -188,6 +189,36 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
     ns.simulator.logger = MagicMock()
     _loaded = ns
     return ns
+
+
+def ref_objmesh(obj_path: str, mesh_name: str, resolve, change_materials=None):
+    """Run the reference's own ObjMesh parser (objmesh.py:55-358) on `obj_path`.  pyglet's vertex
+    lists are captured instead of created, `get_resource_path` is `resolve` (basename -> path or
+    None => KeyError, like duckietown_world), textures are recorded by path.  Returns
+    dict(verts, uvs, normals, colors [T,3,*] in draw order, chunk_sizes, textures, min_coords, max_coords)."""
+    ns = load()
+    om = ns.objmesh
+    chunks = []
+
+    def vertex_list(n, *attrs):
+        chunks.append({a[0]: np.array(a[1], dtype=np.float32) for a in attrs})
+        return len(chunks) - 1
+
+    def get_resource_path(bn):
+        p = resolve(bn)
+        if p is None:
+            raise KeyError(bn)
+        return p
+
+    om.pyglet.graphics.vertex_list = vertex_list
+    om.get_resource_path = get_resource_path
+    om.load_texture = lambda path, **kw: path
+    om.logger = MagicMock()
+    mesh = om.ObjMesh(obj_path, mesh_name, False, change_materials)
+    cat = lambda key, w: np.concatenate([c[key].reshape(-1, 3, w) for c in chunks], axis=0)
+    return dict(verts=cat("v3f", 3), uvs=cat("t2f", 2), normals=cat("n3f", 3), colors=cat("c3f", 3),
+                chunk_sizes=np.array([c["v3f"].size // 9 for c in chunks]), textures=list(mesh.textures),
+                min_coords=np.asarray(mesh.min_coords), max_coords=np.asarray(mesh.max_coords))
 
 
 def make_simulator(map_data: dict, domain_rand: bool = False, max_steps: int = 1500,

@@ -1,0 +1,100 @@
+"""Real-asset ingestion, host side: OBJ/MTL parser pinned against the reference's
+own ObjMesh (golden recorded by oracle/make_golden.py; live comparison when /root/reference is
+present), asset resolution by basename, texture preparation, MapFormat1 YAML -> tables."""
+import os
+
+import numpy as np
+import pytest
+
+from dtsim import assets, maps, objmesh
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ASSETS = os.path.join(HERE, "golden", "assets")
+CASES = [
+    ("cone", "cone", None),
+    ("sign_stop", "sign_generic", {"April_Tag": {"map_Kd": "sign_stop.png"}}),
+    ("tree", "tree", None),
+    ("duckiebot_blue", "duckiebot", {"gkmodel0_chassis_geom0_mat_001-material": {"Kd": np.array([0.0, 0.0, 1.0])},
+                                    "gkmodel0_chassis_geom0_mat_001-material.001": {"Kd": np.array([0.0, 0.0, 1.0])}}),
+]
+
+
+def _chunk_textures(m, chunk_sizes):
+    out, i = [], 0
+    for n in chunk_sizes:
+        t = int(m.tri_tex[i])
+        assert (m.tri_tex[i:i + n] == t).all()
+        out.append("" if t < 0 else os.path.basename(m.texture_files[t]))
+        i += n
+    return out
+
+
+@pytest.mark.parametrize("tag,stem,change", CASES)
+def test_obj_parser_matches_reference_golden(tag, stem, change):
+    lib = assets.AssetLibrary(ASSETS)
+    g = np.load(os.path.join(HERE, "golden", "ref_objmesh.npz"))
+    m = objmesh.load_obj(lib.resolve(stem + ".obj"), lib.resolve, change_materials=change)
+    for k, mine in (("verts", m.verts), ("uvs", m.uvs), ("normals", m.normals), ("colors", m.colors),
+                    ("min_coords", m.min_coords), ("max_coords", m.max_coords)):
+        assert np.array_equal(g[f"{tag}_{k}"], mine), k          # bit-exact float32
+    assert _chunk_textures(m, g[f"{tag}_chunk_sizes"]) == [str(t) for t in g[f"{tag}_textures"]]
+
+
+def test_obj_parser_matches_reference_live():
+    from oracle import refstub
+    if not refstub.available():
+        pytest.skip("reference tree not present")
+    lib = assets.AssetLibrary(ASSETS)
+    for tag, stem, change in CASES:
+        r = refstub.ref_objmesh(lib.resolve(stem + ".obj"), stem, lib.resolve, change)
+        m = objmesh.load_obj(lib.resolve(stem + ".obj"), lib.resolve, change_materials=change)
+        assert np.array_equal(r["verts"], m.verts) and np.array_equal(r["colors"], m.colors)
+        assert np.array_equal(r["min_coords"], m.min_coords) and np.array_equal(r["max_coords"], m.max_coords)
+
+
+def test_recentring_quirk_is_reproduced():
+    # objmesh.py:217 centres on (min + max(axis=0).min(axis=0)) / 2, not on the true mid-point
+    m = assets.AssetLibrary(ASSETS).mesh("tree")
+    assert m.min_coords[1] == 0.0
+    assert abs(m.min_coords[0] + m.max_coords[0]) > 0.05
+
+
+def test_library_resolution_and_fallback():
+    lib = assets.AssetLibrary(ASSETS)
+    assert lib.resolve("cone.obj").endswith(os.path.join("meshes", "cone.obj"))
+    assert lib.resolve("nope.obj") is None
+    assert lib.tile_texture_file("4way").endswith(os.path.join("photos", "4way", "texture.png"))
+    assert lib.tile_texture("grass").shape == (128, 128, 4)
+    key, m = lib.object_mesh({"kind": "sign_stop"})
+    assert key == "sign_stop" and [os.path.basename(t) for t in m.texture_files] == ["sign_stop.png"]
+    key, m = lib.object_mesh({"kind": "duckiebot", "color": "blue"})
+    assert key == "duckiebot:blue" and (m.colors == np.array([0, 0, 1], np.float32)).all(-1).any()   # recoloured chassis
+    key, m = lib.object_mesh({"kind": "duckie"})                    # no duckie.obj in the tree: stand-in
+    assert key == "duckie" and m.n_tris == assets.get_mesh("duckie").n_tris
+    none = assets.AssetLibrary(None)
+    assert none.root is None and none.tile_texture("grass").shape == (256, 256, 4)
+    assert none.object_mesh({"kind": "cone"})[0] == "*"
+
+
+def test_map_yaml_to_tables():
+    lib = assets.AssetLibrary(ASSETS)
+    md = lib.map_data("test_town")
+    meshes = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
+    mt = maps.interpret_map(md, "test_town", meshes, library=lib)
+    assert (mt.grid_w, mt.grid_h) == (5, 4) and len(mt.objects) == 6
+    assert [o.mesh_kind for o in mt.objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone"]
+    cone = lib.mesh("cone")
+    assert np.isclose(mt.objects[0].scale, 0.1 / float(cone.max_coords[1])) and mt.objects[5].scale == 0.2
+    assert mt.objects[2].optional and all(o.static for o in mt.objects)
+    # the same YAML through a file path
+    md2 = assets.get_map(os.path.join(ASSETS, "maps", "test_town.yaml"))
+    assert md2 == md
+
+
+def test_non_power_of_two_textures_are_resampled():
+    t = np.zeros((100, 60, 4), np.uint8)
+    t[..., 0] = np.arange(60)[None, :]
+    r = assets.to_pow2(t)
+    assert r.shape == (128, 64, 4)
+    assert assets.to_pow2(r) is not None and assets.to_pow2(r).shape == r.shape
+    assert assets.to_pow2(t, 256).shape == (256, 256, 4)

@@ -52,6 +52,39 @@ def test_query_matches_oracle(map_name):
     sim.close()
 
 
+def test_query_matches_oracle_on_real_assets():
+    """Collision / safety-circle / spawn geometry with OBB extents that come from parsed OBJ meshes
+    (non-symmetric after ObjMesh's recentring quirk, `height` and `scale` forms, an `optional` object)."""
+    import os
+    from dtsim import assets
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
+    lib = assets.AssetLibrary(root)
+    md = lib.map_data("test_town")
+    ext = {"*": (assets.get_mesh("*").min_coords, assets.get_mesh("*").max_coords)}
+    for desc in md["objects"]:
+        m = lib.object_mesh(desc)[1]
+        ext[desc["kind"]] = (m.min_coords, m.max_coords)
+    sim = BatchedSimulator("test_town", 2, asset_root=root, render=False, domain_rand=False, seed=3)
+    o = osim.OracleSim(md, ext, do_reset=False)
+    m = o.map
+    rng = np.random.default_rng(12)
+    cents = np.array([[ob.pos[0], ob.pos[2]] for ob in m.objects])
+    poses = random_poses(rng, m.grid_width, m.grid_height, m.tile_size, 3000, cents)
+    pr = sim.query(np.zeros(len(poses), np.int32), poses, safety_factor=1.0)
+    nflag = 0
+    for q, (x, z, a) in enumerate(poses):
+        pos = np.array([x, 0, z])
+        assert (pr["tile_i"][q], pr["tile_j"][q]) == tuple(m.get_grid_coords(pos))
+        assert bool(pr["drivable"][q]) == o._drivable_pos(pos)
+        assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
+        assert bool(pr["valid"][q]) == o._valid_pose(pos, a, 1.0)
+        assert bool(pr["inconvenient"][q]) == o._inconvenient_spawn(pos)
+        assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
+        nflag += int(pr["collision"][q])
+    assert nflag > 10
+    sim.close()
+
+
 @pytest.mark.parametrize("map_name,dr", [("small_loop", False), ("small_loop_only_duckies", True),
                                          ("loop_only_duckies", False), ("loop_only_duckies", True)])
 def test_reset_rng_order_matches_oracle(map_name, dr):

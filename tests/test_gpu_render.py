@@ -8,6 +8,8 @@ float64.  Against the oracle in the SAME lighting mode ("pixel"):
 Against the oracle's GL-faithful per-vertex ("gouraud") tile lighting (SURVEY's proposal):
     >= 99 % of pixels within +-2/255, mean abs error <= 0.5/255.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ from oracle import raster, sim as osim
 from util import EXT
 
 pytestmark = pytest.mark.gpu
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
 
 
 def _scene(map_name):
@@ -122,6 +125,53 @@ def test_frames_with_mesh_objects_match_oracle(map_name, W, H, distortion, dr, s
         s = _stats(frames[e], ref_px)
         assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, s)
     assert n_obj_px > 200, n_obj_px          # the duckies are actually in view in this sample
+    sim.close()
+
+
+def _asset_scene():
+    """Oracle scene of the real-asset fixture (tests/golden/assets): per-kind meshes with textures."""
+    lib = assets.AssetLibrary(ASSETS)
+    md = lib.map_data("test_town")
+    meshes = {"*": assets.get_mesh("*")}
+    for desc in md["objects"]:
+        meshes[desc["kind"]] = lib.object_mesh(desc)[1]
+    ext = {k: (m.min_coords, m.max_coords) for k, m in meshes.items()}
+    om = osim.OracleMap(md, ext)
+    kinds = {t["kind"] for t in om.grid if t is not None}
+    return raster.Scene(om, {k: lib.tile_texture(k) for k in kinds}, meshes), md, ext
+
+
+@pytest.mark.parametrize("W,H,distortion,dr", [(320, 240, False, False), (640, 480, True, False), (320, 240, False, True)])
+def test_real_assets_match_oracle(W, H, distortion, dr):
+    """MapFormat1 YAML + tile texture files + OBJ/MTL meshes (multi-material, textured
+    chunks: GL_MODULATE of the material texture with the lit vertex colour, sign / duckiebot material
+    overrides) loaded from an asset tree, rendered by the HIP raster and by the oracle."""
+    scene, md, ext = _asset_scene()
+    N = 8
+    sim = BatchedSimulator("test_town", N, asset_root=ASSETS, camera_width=W, camera_height=H, distortion=distortion,
+                           domain_rand=dr, seed=5, max_steps=100000)
+    assert [o.mesh_kind for o in sim.maps[0].objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone"]
+    # look at the objects: place the agents around them, facing them
+    objs = sim.maps[0].objects
+    for e in range(N):
+        o = objs[e % len(objs)]
+        a = 0.7 * e
+        sim.init_states[e].pos[:] = [float(o.pos[0] - 0.45 * np.cos(a)), 0.0, float(o.pos[2] + 0.45 * np.sin(a))]
+        sim.init_states[e].angle = float(a)
+    sim.reset(states=sim.init_states)
+    sim.render()
+    frames = sim.frames_host()
+    rmap = pdist.distortion_maps(W, H) if distortion else None
+    n_obj_px = 0
+    for e in range(N):
+        cam = _camera(sim, e, W, H, dr)
+        st = _obj_states(sim, e, scene)
+        ref_px = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
+        no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
+        n_obj_px += int((np.abs(ref_px.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
+        s = _stats(frames[e], ref_px)
+        assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, s)
+    assert n_obj_px > 2000, n_obj_px
     sim.close()
 
 
