@@ -91,6 +91,7 @@ struct dtsim {
   ObjBox* d_objbox = nullptr;
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
+  uint32_t* d_items = nullptr;
   int max_tris = 0;
   int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
@@ -227,7 +228,8 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + 31) / 32);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * 256 * 32 * sizeof(uint16_t));
-      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8) * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
+      if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * DT_ITEMS_PER_WG * sizeof(uint32_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
     if (!(cfg->flags & DTSIM_F_DISTORTION)) {
@@ -250,7 +252,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -616,8 +618,9 @@ int dtsim_render(dtsim_t* h) {
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
+  const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + 31) / 32);
+  R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items;
   if (getenv("DTSIM_DEBUG_QUEUE")) {
-    const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + 31) / 32);
     R.dbg = h->d_qcount + n_wg_ * 4;
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
   }
@@ -639,7 +642,9 @@ int dtsim_render(dtsim_t* h) {
             nonempty, qc.size(), iters, iters ? 100.0 * tot / (64.0 * iters) : 0.0);
     int32_t dbg[8];
     HIPCHK(hipMemcpy(dbg, h->d_qcount + n_wg * 4, sizeof dbg, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[dtsim] resolve LDS triangle lists: %d (wg,env) pairs overflowed, %d fit, %d triangles staged\n", dbg[0], dbg[1], dbg[2]);
+    unsigned long long pairs; memcpy(&pairs, dbg + 6, 8);
+    fprintf(stderr, "[dtsim] resolve mesh pass: %d (batch,env) pairs, %d objects streamed, %d z-buffer calls (%d triangle-parallel), "
+                    "%d triangles staged, %d pixels, %llu pixel x triangle tests\n", dbg[0], dbg[1], dbg[4], dbg[5], dbg[2], dbg[3], pairs);
     fprintf(stderr, "[dtsim] exact-path pixels: %lld of %zu (%.2f%%), max per wavefront region %lld\n", tot, npix * h->N,
             100.0 * tot / (double)(npix * h->N), mx);
   }

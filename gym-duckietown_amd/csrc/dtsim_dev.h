@@ -131,13 +131,16 @@ static_assert(sizeof(TileLds) == 32, "TileLds is 32 bytes");
 // One mesh triangle of one env after model/view/projection and per-vertex lighting
 // (objects.py:123-148, objmesh.py:360-375): rectilinear pixel coordinates, 1/w, lit colour/w.
 struct alignas(16) ScreenTri {
+  // first 64 bytes: coverage / depth (all k_resolve's z-buffer pass reads; same layout as render.hip TriCov)
   float bx0, bx1, by0, by1;  // pixel bounding box (+-1 px); empty (bx0 > bx1) when culled
   float sx[3], sy[3], iw[3];
-  float cw[3][3];            // per-vertex lit colour (0..255) divided by w
   float inv_area;            // 0 => culled (behind the near plane / degenerate / invisible)
   int32_t index;             // position in the env's triangle order (z-buffer tie break)
+  int32_t pad;
+  // second 64 bytes: shading attributes, read only for the winning triangle of a sample
+  float cw[3][3];            // per-vertex lit colour (0..255) divided by w
   float uw[3], vw[3];        // per-vertex texture coordinates divided by w
-  int32_t tex, pad;          // texture index of the material chunk, -1 = untextured
+  int32_t tex;               // texture index of the material chunk, -1 = untextured
 };
 static_assert(sizeof(ScreenTri) == 128, "ScreenTri is 128 bytes");
 struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
@@ -149,6 +152,8 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 #endif
 #define DT_TILE_W DT_WAVE_W
 #define DT_TILE_H (4 * (256 / DT_WAVE_W))  // 4 wavefronts stacked vertically
+#define DT_ITEM_B 8                          // 64-entry edge batches per k_resolve work item
+#define DT_ITEMS_PER_WG (4 * 128 / DT_ITEM_B) // worst case: 4 regions x (256 px x 32 envs / 64) batches
 static inline size_t dt_raster_tiles(int W, int H) {
   return (size_t)((W + DT_TILE_W - 1) / DT_TILE_W) * (size_t)((H + DT_TILE_H - 1) / DT_TILE_H);
 }
@@ -176,6 +181,8 @@ struct RenderParams {
   uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
   int32_t* qcount;              // [workgroups][4]
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
+  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor; zeroed per render
+  uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

@@ -84,7 +84,7 @@ static_assert(sizeof(EnvFast) == 64, "EnvFast is 64 bytes");
 
 // coverage-only part of a ScreenTri kept in LDS by k_resolve<true>; the winner's colours are fetched
 // from global memory.
-struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; float pad; };
+struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; int32_t pad; };   // == first half of ScreenTri
 static_assert(sizeof(TriCov) == 64, "TriCov is 64 bytes");
 
 namespace {
@@ -468,6 +468,62 @@ __device__ inline void test_tri(const Tri& st, float pcx, float pcy, float zbest
   }
 }
 
+// z-buffer the `fill` staged triangles of the wavefront-local LDS chunk against the pixels of the
+// lanes with `mine` set.  Two schedules, picked per call from a cost estimate (wave-uniform):
+//   pixel-parallel    every `mine` lane walks all staged triangles (dense blocks: many pixels, few tris);
+//   triangle-parallel for each `mine` pixel in turn, the 64 lanes test 64 staged triangles at once and
+//                     the per-sample winners are reduced across the wavefront (a handful of pixels of a
+//                     small / distant object, where the pixel-parallel loop would idle most lanes).
+// Depth func LESS with the draw-order tie break, identical in both schedules.
+__device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, int lane, float pcx, float pcy,
+                                     float zbest[4], int tbest[4], int32_t* dbg) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long mm = __ballot(mine);
+  const int n_mine = __popcll(mm);
+  const int n_chunks = (fill + 63) >> 6;
+  const bool tri_parallel = n_mine * (n_chunks * 110 + 110) < fill * 25;
+  if (dbg && lane == 0) {                            // DTSIM_DEBUG_QUEUE statistics
+    atomicAdd(dbg + 2, fill); atomicAdd(dbg + 3, n_mine); atomicAdd(dbg + 4, 1); atomicAdd(dbg + 5, tri_parallel ? 1 : 0);
+    atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 6), (unsigned long long)fill * (unsigned long long)n_mine);
+  }
+  if (tri_parallel) {
+    unsigned long long todo = mm;
+    while (todo) {                                   // wave-uniform
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const float qx = __shfl(pcx, src), qy = __shfl(pcy, src);
+      float zb[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+      int tb[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+      for (int k = lane; k < fill; k += 64) {
+        int tl[4] = {-1, -1, -1, -1};
+        float zl[4] = {zb[0], zb[1], zb[2], zb[3]};
+        test_tri(w_tris[k], qx, qy, zl, tl);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (tl[s] >= 0 && (zl[s] < zb[s] || (zl[s] == zb[s] && tl[s] < tb[s]))) { zb[s] = zl[s]; tb[s] = tl[s]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float zmin = zb[s];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d));
+        int tmin = zb[s] == zmin ? tb[s] : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tmin = min(tmin, __shfl_xor(tmin, d));
+        if (lane == src && tmin != 0x7fffffff && (zmin < zbest[s] || (zmin == zbest[s] && tmin < tbest[s]))) {
+          zbest[s] = zmin; tbest[s] = tmin;
+        }
+      }
+    }
+  } else if (mine) {
+    for (int k = 0; k < fill; ++k) test_tri(w_tris[k], pcx, pcy, zbest, tbest);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // exact 4-sample resolve of one pixel (centre NDC nx, ny): coverage and depth per sample,
 // shading once per primitive at the pixel centre; zbest/tbest = nearest mesh triangle per sample
 // (from the mesh pass), z-buffered against the planes here.
@@ -624,6 +680,9 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 // (env-in-chunk << 8) | (row-slot k << 6 | lane).  k_resolve drains the regions 64 entries at a time.
 #define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
 #define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
+#define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
+#define ITEMS_PER_WG DT_ITEMS_PER_WG
+#define GRAB_MAX 16       // work items per cursor atomic, at most
 
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
@@ -865,110 +924,168 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     }
   }
   if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
+  // Work items for k_resolve: the workgroup's 64-entry batches (four regions, flattened), ITEM_B at a
+  // time, appended to a global list so that the resolve launch can spread hot tiles (close-up meshes,
+  // horizon band) over the whole chip.  The append order is arbitrary; items touch disjoint pixels.
+  __shared__ int s_nb[RB / 64];
+  if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
+  __syncthreads();
+  if (tid == 0 && !R.no_msaa) {
+    int nb = 0;
+#pragma unroll
+    for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
+    if (nb > 0) {
+      const int ni = (nb + ITEM_B - 1) / ITEM_B;
+      const int pos = atomicAdd(R.work, ni);
+      for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)blockIdx.x * ITEMS_PER_WG + (uint32_t)i;
+    }
+  }
 }
 
-// Exact 4-sample resolve of the queued edge pixels; same grid as the raster launch
-// (workgroup <-> strip x env-chunk, wavefront <-> 256-pixel span), stream-ordered after it,
-// so the byte patches land after the fast-path stores.
+// Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
+// land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
+// batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
 template <bool OBJ>
 __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
                                                 const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
-  EnvCam* s_cams = reinterpret_cast<EnvCam*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4));
   const int tid = threadIdx.x;
   const int npix = R.W * R.H;
   const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
-  const int tile = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
-  const int e0 = chunk * ENVS_PER_BLOCK, e1 = min(e0 + ENVS_PER_BLOCK, R.N);
   const int wave = tid >> 6, lane = tid & 63;
-  const int total_wg = qcount[blockIdx.x * (RB / 64)] + qcount[blockIdx.x * (RB / 64) + 1] +
-                       qcount[blockIdx.x * (RB / 64) + 2] + qcount[blockIdx.x * (RB / 64) + 3];
-  if (total_wg == 0) return;                         // workgroup-uniform
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(R.tile_recs);
     for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
-    const uint32_t* csrc = reinterpret_cast<const uint32_t*>(cams + e0);
-    uint32_t* cdst = reinterpret_cast<uint32_t*>(s_cams);
-    for (int i = tid; i < (e1 - e0) * (int)(sizeof(EnvCam) / 4); i += RB) cdst[i] = csrc[i];
   }
   __syncthreads();
-  const int tile_x0 = (tile % tiles_x) * DT_TILE_W, wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
-  const int n = qcount[blockIdx.x * (RB / 64) + wave];
-  const uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
-  TriCov* w_tris = reinterpret_cast<TriCov*>(s_cams + ENVS_PER_BLOCK) + wave * TRI_CAP;    // wavefront-local
-  for (int q0 = 0; q0 < n; q0 += 64) {               // wave-uniform
-    const bool have = q0 + lane < n;
-    const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
-    const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
-    const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;      // entries only exist for in-image pixels
-    const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
-    const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
-    float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-    int tbest[4] = {-1, -1, -1, -1};
-    if (OBJ) {
-      // ---- mesh pass.  Queue entries are in env order, so these 64 pixels belong to a few
-      // consecutive envs.  Per env: stream its triangles 64 at a time (one per lane), keep those whose
-      // screen box meets the bounding box of this env's pixels, compact them into a wavefront-local
-      // LDS chunk and let every pixel of that env z-buffer the chunk.  No cap, no barrier: DS
-      // operations of one wavefront execute in program order.
-      int el_lo = have ? el : 0x7fffffff, el_hi = el;
+  uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
+  EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * ENVS_PER_BLOCK;                    // wavefront-local
+  TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * ENVS_PER_BLOCK * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
+  const int n_items = R.work[0];                     // written by the raster launch
+  // One atomic buys `grab` items, taken with stride n_grabs through the list: same-address atomics are
+  // serialised by the L2 (~0.2 ms per 100 k of them), and the stride keeps the consecutive items of one hot
+  // raster workgroup on different wavefronts.  Granularity: ~4 grabs per resident wavefront, <= GRAB_MAX items.
+  const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
+  const int n_grabs = (n_items + grab - 1) / grab;
+  while (true) {
+    int g = 0;
+    if (lane == 0) g = atomicAdd(R.work + 1, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= n_grabs) break;
+    for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
+      const uint32_t item = R.items[it];
+      const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
+      const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
+      const int e0 = chunk * ENVS_PER_BLOCK;
+      {  // the chunk's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
+        static_assert(ENVS_PER_BLOCK * sizeof(EnvCam) == 64 * 64, "one 64-byte slice per lane");
+        const int ne = min(ENVS_PER_BLOCK, R.N - e0);
+        const uint4* src = reinterpret_cast<const uint4*>(cams + e0) + lane * 4;
+        uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
+        if (lane * 64 < ne * (int)sizeof(EnvCam)) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
+      }
+      const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
+      static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
+      int rn[4], rb[5];
+      rb[0] = 0;
 #pragma unroll
-      for (int d = 32; d > 0; d >>= 1) { el_lo = min(el_lo, __shfl_xor(el_lo, d)); el_hi = max(el_hi, __shfl_xor(el_hi, d)); }
-      for (int ee = el_lo; ee <= el_hi; ++ee) {      // wave-uniform
-        const bool mine = el == ee;
-        if (!__ballot(mine)) continue;
-        const ObjEnv oe = R.objenv[e0 + ee];
-        if (oe.n_tris == 0) continue;
-        float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
+      for (int r = 0; r < 4; ++r) { rn[r] = qcount[rwg * 4 + r]; rb[r + 1] = rb[r] + ((rn[r] + 63) >> 6); }
+      const int b_end = min(rb[4], (part + 1) * ITEM_B);
+      for (int b = part * ITEM_B; b < b_end; ++b) {  // wave-uniform
+        const int reg = (b >= rb[1]) + (b >= rb[2]) + (b >= rb[3]);
+        const int q0 = (b - (reg == 0 ? rb[0] : reg == 1 ? rb[1] : reg == 2 ? rb[2] : rb[3])) * 64;
+        const int n = reg == 0 ? rn[0] : reg == 1 ? rn[1] : reg == 2 ? rn[2] : rn[3];
+        const uint16_t* w_queue = queue + ((size_t)rwg * 4 + reg) * QREGION;
+        const int wave_y0 = tile_y0 + reg * (WAVE_PIX / WAVE_W);
+        const bool have = q0 + lane < n;
+        const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
+        const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
+        const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;      // entries only exist for in-image pixels
+        const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
+        const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
+        float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        int tbest[4] = {-1, -1, -1, -1};
+        if (OBJ) {
+          // ---- mesh pass.  Queue entries are in env order, so these 64 pixels belong to a few
+          // consecutive envs.  Per env, and per object whose screen box meets the env's pixels here:
+          // stream the object's triangles 64 at a time (one per lane), keep those whose screen box meets
+          // the bounding box of these pixels, compact them into a wavefront-local LDS chunk and z-buffer
+          // the chunk.  No cap, no barrier: DS operations of one wavefront execute in program order.
+          int el_lo = have ? el : 0x7fffffff, el_hi = el;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-          x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
-          y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+          for (int d = 32; d > 0; d >>= 1) { el_lo = min(el_lo, __shfl_xor(el_lo, d)); el_hi = max(el_hi, __shfl_xor(el_hi, d)); }
+          for (int ee = el_lo; ee <= el_hi; ++ee) {  // wave-uniform
+            const bool mine = el == ee;
+            if (!__ballot(mine)) continue;
+            const ObjEnv oe = R.objenv[e0 + ee];
+            if (oe.n_tris == 0) continue;
+            float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+              x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
+              y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+            }
+            if (oe.bx0 > x1 || oe.bx1 < x0 || oe.by0 > y1 || oe.by1 < y0) continue;
+            if (R.dbg && lane == 0) atomicAdd(R.dbg + 0, 1);                   // (batch, env) pairs that look at objects
+            const ScreenTri* base = R.stris + (size_t)(e0 + ee) * R.max_tris;
+            // object screen boxes: one vector load (lane o <-> object o)
+            static_assert(DTSIM_MAX_OBJECTS <= 64, "one lane per object");
+            int ob_first = 0, ob_count = 0;
+            bool ob_hit = false;
+            if (lane < oe.n_obj) {
+              const ObjBox ob = R.objbox[(size_t)(e0 + ee) * DTSIM_MAX_OBJECTS + lane];
+              ob_first = ob.first; ob_count = ob.count;
+              ob_hit = ob.count > 0 && !(ob.bx0 > x1 || ob.bx1 < x0 || ob.by0 > y1 || ob.by1 < y0);
+            }
+            unsigned long long hm = __ballot(ob_hit);  // wave-uniform
+            if (R.dbg && lane == 0) atomicAdd(R.dbg + 1, __popcll(hm));
+            // flat sequence of 64-triangle chunks over the hit objects; the coverage half (64 B) of the
+            // next chunk's ScreenTri is loaded while the current one is filtered and staged
+            int first = 0, count = 0, t0 = 0;
+            auto advance = [&]() -> bool {             // wave-uniform: next (object, t0); false when exhausted
+              t0 += 64;
+              while (t0 >= count) {
+                if (!hm) return false;
+                const int o = __builtin_ctzll(hm);
+                hm &= hm - 1ull;
+                first = __shfl(ob_first, o); count = __shfl(ob_count, o); t0 = 0;
+              }
+              return true;
+            };
+            auto fetch = [&](TriCov& tc) -> bool {     // this lane's triangle of the current chunk
+              const bool in = t0 + lane < count;
+              if (in) tc = *reinterpret_cast<const TriCov*>(base + first + t0 + lane);
+              return in;
+            };
+            int fill = 0;
+            TriCov cur, nxt;
+            bool more = advance();
+            bool cur_in = more ? fetch(cur) : false;
+            while (more) {
+              const bool has_next = advance();
+              const bool nxt_in = has_next ? fetch(nxt) : false;
+              const bool pass = cur_in && !(cur.bx0 > x1 || cur.bx1 < x0 || cur.by0 > y1 || cur.by1 < y0);
+              const unsigned long long pm = __ballot(pass);
+              if (pass) w_tris[fill + __popcll(pm & ((1ull << lane) - 1ull))] = cur;
+              fill += __popcll(pm);
+              if (fill > TRI_CAP - 64 || (!has_next && fill > 0)) {   // chunk full, or the last one: z-buffer it
+                zbuffer_chunk(w_tris, fill, mine, lane, pcx, pcy, zbest, tbest, R.dbg);
+                fill = 0;
+              }
+              cur = nxt; cur_in = nxt_in; more = has_next;
+            }
+          }
         }
-        if (oe.bx0 > x1 || oe.bx1 < x0 || oe.by0 > y1 || oe.by1 < y0) continue;
-        const ScreenTri* base = R.stris + (size_t)(e0 + ee) * R.max_tris;
-        int fill = 0;
-        for (int t0 = 0; t0 < oe.n_tris; t0 += 64) {
-          const int t = t0 + lane;
-          bool pass = false;
-          if (t < oe.n_tris) {
-            const float4 bb = *reinterpret_cast<const float4*>(base + t);     // bx0, bx1, by0, by1
-            pass = !(bb.x > x1 || bb.y < x0 || bb.z > y1 || bb.w < y0);
-          }
-          const unsigned long long pm = __ballot(pass);
-          if (pass) {
-            const int slot = fill + __popcll(pm & ((1ull << lane) - 1ull));
-            const ScreenTri st = base[t];
-            TriCov tc;
-            tc.bx0 = st.bx0; tc.bx1 = st.bx1; tc.by0 = st.by0; tc.by1 = st.by1;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { tc.sx[k] = st.sx[k]; tc.sy[k] = st.sy[k]; tc.iw[k] = st.iw[k]; }
-            tc.inv_area = st.inv_area; tc.index = st.index; tc.pad = 0.f;
-            w_tris[slot] = tc;
-          }
-          fill += __popcll(pm);
-          const bool last = t0 + 64 >= oe.n_tris;
-          if (fill > TRI_CAP - 64 || (last && fill > 0)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (mine)
-              for (int k = 0; k < fill; ++k) test_tri(w_tris[k], pcx, pcy, zbest, tbest);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            fill = 0;
-          }
+        if (have) {
+          const EnvCam c = w_cams[el];
+          const MapU m = map_u(R.maps[c.map_id]);
+          const ScreenTri* tris = OBJ ? R.stris + (size_t)(e0 + el) * R.max_tris : nullptr;
+          const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
+          uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + pix) * 3;
+          dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
       }
-    }
-    if (have) {
-      const EnvCam c = s_cams[el];
-      const MapU m = map_u(R.maps[c.map_id]);
-      const ScreenTri* tris = OBJ ? R.stris + (size_t)(e0 + el) * R.max_tris : nullptr;
-      const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
-      uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + pix) * 3;
-      dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
     }
   }
 }
@@ -981,10 +1098,11 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand,
                      (float)R.W / (float)R.H, cams, fasts, R.maps);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
+  (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
   const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
-  const size_t lds2 = lds + ENVS_PER_BLOCK * sizeof(EnvCam);
+  const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
   const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
@@ -995,7 +1113,9 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
   if (!R.no_msaa) {
-    if (obj) hipLaunchKernelGGL(k_resolve<true>, grid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount);
-    else hipLaunchKernelGGL(k_resolve<false>, grid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
+    const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
+    if (obj) hipLaunchKernelGGL(k_resolve<true>, rgrid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount);
+    else hipLaunchKernelGGL(k_resolve<false>, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
   }
 }

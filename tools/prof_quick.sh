@@ -10,4 +10,4 @@ K=3 N=${N:-1024} rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 K=3 N=${N:-1024} rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE -d $OUT/pmc3 -o pmc3 -- python $GRAFT_REPO_ROOT/tools/time_render.py > $OUT/pmc3.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocpd_summary.py "$OUT/*/*.db" > $OUT/summary.txt 2>&1
-grep -E "pmc\] .*k_raster" -A9 $OUT/summary.txt | head -60
+grep -E "pmc\] .*${KPAT:-k_raster}" -A9 $OUT/summary.txt | head -60
