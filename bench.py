@@ -129,9 +129,11 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cpu-steps", type=int, default=8, help="oracle env-steps for cpu_baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2"],
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5"],
                     help="c3 (default, the headline): raster + fisheye; c2: dynamics+collision only, render off "
-                         "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch")
+                         "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch; "
+                         "c4: loop_pedestrians + domain randomisation (configs[3]); c5: MultiMap, two maps alternating "
+                         "per env slot (configs[4])")
     ap.add_argument("--fuse", type=int, default=32, help="c2: physics steps fused per dtsim_step launch")
     args = ap.parse_args()
     if args.config == "c2":
@@ -153,9 +155,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, K, Wm = args.envs, args.steps, args.warmup
-    sim = BatchedSimulator("small_loop", N, domain_rand=False, distortion=True, camera_width=W, camera_height=H,
+    variant = {
+        "c3": dict(maps="small_loop", dr=False, label="Duckietown-small_loop-v0 (fixture)", ref="configs[2]",
+                   kern="k_raster<DR=0,OBJ=0> + k_resolve<OBJ=0>", extra={}),
+        "c4": dict(maps="loop_pedestrians", dr=True, label="Duckietown-loop_pedestrians-v0 (stand-in: loop_only_duckies with "
+                   "static: False, 8 walking duckies), dynamic obstacles + domain randomisation", ref="configs[3]",
+                   kern="k_obj_setup + k_raster<DR=1,OBJ=1> + k_resolve<OBJ=1>", extra={}),
+        "c5": dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, label="MultiMap-v0 (loop_only_duckies / "
+                   "small_loop_only_duckies alternating per env slot, multimap_env.py:17,44-49)", ref="configs[4]",
+                   kern="k_obj_setup + k_raster<DR=0,OBJ=1> + k_resolve<OBJ=1>", extra=dict(map_cycle=True)),
+    }[args.config]
+    sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=True, camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
-                           device=local_rank, do_reset=False)
+                           device=local_rank, do_reset=False, **variant["extra"])
     t_setup = time.perf_counter()
     sim.make_spawn_pool(N)                     # reference-order resets, geometry evaluated on the GPU
     sim.reset(states=sim._pool)                # start from the first pool entry of each env
@@ -222,7 +234,7 @@ def main():
 
     done_frac = float(sim.read(_ffi.FIELD_EPISODE).mean())
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_steps > 0:
+    if rank == 0 and world == 1 and args.cpu_steps > 0 and args.config == "c3":
         cpu = cpu_baseline(args.cpu_steps)
 
     if rank == 0:
@@ -233,7 +245,7 @@ def main():
         if os.path.exists(pj):
             try:
                 d = json.load(open(pj))
-                if d.get("envs") == N:
+                if d.get("envs") == N and args.config == "c3":
                     traffic = d.get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -250,12 +262,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 raster -> u8 frames; f64 physics",
             "data": "synthetic",
-            "config": {"workload": "Duckietown-small_loop-v0 (fixture), 4096 batched envs per GPU, 640x480 RGB raster + fisheye "
-                                   "distortion, domain_rand off, random (vel, steer) actions, auto-reset from spawn pool "
-                                   "[BASELINE.json configs[2]]",
-                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": False,
+            "config": {"workload": f"{variant['label']}, {N} batched envs per GPU, 640x480 RGB raster + fisheye "
+                                   f"distortion, domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
+                                   f"auto-reset from spawn pool [BASELINE.json {variant['ref']}]",
+                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "dtsim_render pass = k_cam_setup + k_raster<DR=0,OBJ=0> + k_resolve<OBJ=0> (HIP events around the three launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
+            "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
                          "step_kernel_ms": ms_s / max(n_s, 1)},
