@@ -23,6 +23,7 @@ ARCH = "gfx950"
 UNITS = [
     ("physics.hip", ["-ffp-contract=off"]),
     ("render.hip", ["-ffp-contract=fast"]),
+    ("observe.hip", []),
     ("dtsim_api.hip", []),
 ]
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",

@@ -92,6 +92,9 @@ struct dtsim {
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
   uint32_t* d_items = nullptr;
+  int32_t* d_obs_tab = nullptr;   // dtsim_observe resampling tables (cached per output size)
+  int obs_h = 0, obs_w = 0, obs_kx = 0, obs_ky = 0, obs_rpb = 0, obs_rows_in = 0;
+  size_t obs_off_by = 0;
   int max_tris = 0;
   int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
@@ -252,7 +255,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -658,6 +661,73 @@ int dtsim_bind_frames(dtsim_t* h, void* devptr) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
   if (!h->frames_own) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
   h->frames = devptr ? (uint8_t*)devptr : h->frames_own;
+  return DTSIM_OK;
+}
+
+int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
+                  const int32_t* bounds_x, const int32_t* taps_x, int ksize_x,
+                  const int32_t* bounds_y, const int32_t* taps_y, int ksize_y) {
+  if (!h || !out) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  const int W = h->cfg.cam_width, H = h->cfg.cam_height;
+  if (out_h <= 0 || out_w <= 0) return fail(DTSIM_E_INVALID, "output size %dx%d", out_w, out_h);
+  if ((out_w != W && (!bounds_x || !taps_x || ksize_x <= 0)) || (out_h != H && (!bounds_y || !taps_y || ksize_y <= 0)))
+    return fail(DTSIM_E_INVALID, "resampling tables missing for a resized axis");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  // tables: cached per (out_h, out_w); [bx | kkx | by | kky] in one device buffer
+  if (h->obs_h != out_h || h->obs_w != out_w || !h->d_obs_tab) {
+    std::vector<int32_t> tab;
+    std::vector<int32_t> by(2 * (size_t)out_h);
+    if (out_w != W) { tab.insert(tab.end(), bounds_x, bounds_x + 2 * (size_t)out_w); tab.insert(tab.end(), taps_x, taps_x + (size_t)out_w * ksize_x); }
+    else ksize_x = 0;
+    h->obs_off_by = tab.size();
+    if (out_h != H) for (int i = 0; i < 2 * out_h; ++i) by[i] = bounds_y[i];
+    else { for (int i = 0; i < out_h; ++i) { by[2 * i] = i; by[2 * i + 1] = 1; } ksize_y = 0; }
+    for (int i = 0; i < out_h; ++i)
+      if (by[2 * i] < 0 || by[2 * i + 1] <= 0 || by[2 * i] + by[2 * i + 1] > H || (i && by[2 * i] < by[2 * i - 2]))
+        return fail(DTSIM_E_INVALID, "bounds_y[%d] = (%d, %d) out of range / not monotone", i, by[2 * i], by[2 * i + 1]);
+    if (out_w != W)
+      for (int i = 0; i < out_w; ++i)
+        if (bounds_x[2 * i] < 0 || bounds_x[2 * i + 1] <= 0 || bounds_x[2 * i + 1] > ksize_x || bounds_x[2 * i] + bounds_x[2 * i + 1] > W)
+          return fail(DTSIM_E_INVALID, "bounds_x[%d] = (%d, %d) out of range", i, bounds_x[2 * i], bounds_x[2 * i + 1]);
+    tab.insert(tab.end(), by.begin(), by.end());
+    if (out_h != H) {
+      for (int i = 0; i < out_h; ++i) if (by[2 * i + 1] > ksize_y) return fail(DTSIM_E_INVALID, "bounds_y[%d] count > ksize_y", i);
+      tab.insert(tab.end(), taps_y, taps_y + (size_t)out_h * ksize_y);
+    }
+    // rows per workgroup: as many output rows as keep the uint8 intermediate (+ staging) within 48 KB of LDS
+    const size_t stage = 4 * (((size_t)W * 3 + 3) / 4) * 4, budget = 48 * 1024 - stage - 16;
+    const int max_rows = (int)std::min<size_t>((size_t)H, budget / ((size_t)out_w * 3));
+    int rpb = 0, need = 0;
+    for (int cand = 1; cand <= out_h; ++cand) {
+      int worst = 0;
+      for (int o0 = 0; o0 < out_h; o0 += cand) {
+        const int o1 = std::min(o0 + cand, out_h) - 1;
+        worst = std::max(worst, by[2 * o1] + by[2 * o1 + 1] - by[2 * o0]);
+      }
+      if (worst > max_rows) break;
+      rpb = cand; need = worst;
+      if (cand >= 16) break;                        // enough rows per workgroup; keep the grid large
+    }
+    if (rpb == 0) return fail(DTSIM_E_LIMIT, "observation %dx%d: one output row needs more input rows than fit in LDS", out_w, out_h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_obs_tab) { (void)hipFree(h->d_obs_tab); h->d_obs_tab = nullptr; }
+    HIPCHK(hipMalloc(&h->d_obs_tab, tab.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(h->d_obs_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->obs_h = out_h; h->obs_w = out_w; h->obs_kx = ksize_x; h->obs_ky = ksize_y; h->obs_rpb = rpb; h->obs_rows_in = need;
+  }
+  ObserveParams P{};
+  P.N = h->N; P.H = H; P.W = W; P.oh = out_h; P.ow = out_w; P.kx = h->obs_kx; P.ky = h->obs_ky;
+  P.rows_per_block = h->obs_rpb; P.max_rows_in = h->obs_rows_in;
+  P.chw = (flags & DTSIM_OBS_CHW) ? 1 : 0; P.f32 = (flags & DTSIM_OBS_F32) ? 1 : 0;
+  P.frames = h->frames; P.out = out;
+  P.bx = h->d_obs_tab; P.kkx = h->d_obs_tab + (out_w != W ? 2 * (size_t)out_w : 0);
+  P.by = h->d_obs_tab + h->obs_off_by; P.kky = P.by + 2 * (size_t)out_h;
+  {
+    ProfScope ps(h, DTSIM_KERNEL_OBSERVE);
+    dt_launch_observe(h->stream, P);
+  }
+  HIPCHK(hipGetLastError());
   return DTSIM_OK;
 }
 

@@ -186,3 +186,20 @@ struct RenderParams {
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);
+
+// observation post-processing (observe.hip): Pillow-exact bilinear resize + layout + normalisation
+struct ObserveParams {
+  int32_t N, H, W, oh, ow;
+  int32_t kx, ky;               // taps per output column / row in the tables
+  int32_t rows_per_block;       // output rows per workgroup
+  int32_t max_rows_in;          // input rows any workgroup needs (sizes the LDS intermediate)
+  int32_t chw, f32;             // layout (0: [N,h,w,3], 1: [N,3,h,w]) and dtype (0: uint8, 1: float32 / 255)
+  const uint8_t* frames;        // [N,H,W,3]
+  void* out;
+  const int32_t* bx;            // [ow][2] first tap, tap count   (dtsim/resample.py coeffs)
+  const int32_t* kkx;           // [ow][kx] 22-bit fixed-point taps
+  const int32_t* by;            // [oh][2]
+  const int32_t* kky;           // [oh][ky]
+};
+size_t dt_observe_lds_bytes(const ObserveParams& P);
+void dt_launch_observe(hipStream_t s, const ObserveParams& P);

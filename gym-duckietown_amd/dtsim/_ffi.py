@@ -30,13 +30,14 @@ TILE_OTHER = 10
  FIELD_LANE, FIELD_IN_LANE, FIELD_PROX, FIELD_SPEED, FIELD_TIMESTAMP, FIELD_WHEELS, FIELD_MAP_ID,
  FIELD_OBJ_CENTER, FIELD_OBJ_ACTIVE, FIELD_OBJ_YROT, FIELD_OBJ_PARAMS, FIELD_OBJ_VISIBLE,
  FIELD_EPISODE, FIELD_STATE_BLOB) = range(21)
-KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY = range(4)
+KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
+OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 
 EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_observe", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -152,6 +153,7 @@ def load(path: str | None = None):
         "dtsim_frames_devptr": (vp, [vp]),
         "dtsim_frames_bytes": (sz, [vp]),
         "dtsim_bind_frames": (ci, [vp, vp]),
+        "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),
         "dtsim_query": (ci, [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double, C.POINTER(Probe)]),
         "dtsim_read": (ci, [vp, ci, vp, sz]),
         "dtsim_write": (ci, [vp, ci, vp, sz]),

@@ -308,6 +308,36 @@ class BatchedSimulator:
     def bind_frames(self, devptr: Optional[int]):
         _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
 
+    def observe(self, height: int, width: int, chw: bool = False, normalize: bool = False, out=None):
+        """Learner-side observation of the last rendered batch, on the device: PIL-exact bilinear resize
+        (learning/utils/wrappers.py ResizeWrapper), optional HWC->CHW (ImgWrapper) and /255 float32
+        (NormalizeWrapper).  Returns a device array ([N,h,w,3] or [N,3,h,w]); `out` may be any object with
+        __cuda_array_interface__ of that shape/dtype (e.g. the send buffer of the frame all-gather)."""
+        import torch
+        from . import resample
+        h, w = int(height), int(width)
+        shape = (self.num_envs, 3, h, w) if chw else (self.num_envs, h, w, 3)
+        if out is None:
+            key = (h, w, chw, normalize)
+            if getattr(self, "_obs_key", None) != key:
+                self._obs_buf = torch.empty(shape, dtype=torch.float32 if normalize else torch.uint8,
+                                            device=f"cuda:{self.device_index}")
+                self._obs_key = key
+            out = self._obs_buf
+        ptr = out.__cuda_array_interface__["data"][0]
+        ip = C.POINTER(C.c_int32)
+        bx = kx = by = ky = None
+        nkx = nky = 0
+        if w != self.camera_width:
+            b, k = resample.coeffs(self.camera_width, w)
+            bx, kx, nkx = b.ctypes.data_as(ip), k.ctypes.data_as(ip), k.shape[1]
+        if h != self.camera_height:
+            b, k = resample.coeffs(self.camera_height, h)
+            by, ky, nky = b.ctypes.data_as(ip), k.ctypes.data_as(ip), k.shape[1]
+        flags = (_ffi.OBS_CHW if chw else 0) | (_ffi.OBS_F32 if normalize else 0)
+        _ffi.check(self._lib, self._lib.dtsim_observe(self._h, C.c_void_p(ptr), h, w, flags, bx, kx, nkx, by, ky, nky))
+        return out
+
     def frames_host(self) -> np.ndarray:
         """Synchronous copy of the frame batch to the host (tests / N=1 facade)."""
         import torch

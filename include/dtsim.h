@@ -226,7 +226,7 @@ enum {
 };
 
 /* kernels for dtsim_profile_read */
-enum { DTSIM_KERNEL_STEP = 0, DTSIM_KERNEL_RENDER = 1, DTSIM_KERNEL_RESET = 2, DTSIM_KERNEL_QUERY = 3, DTSIM_KERNEL__COUNT = 4 };
+enum { DTSIM_KERNEL_STEP = 0, DTSIM_KERNEL_RENDER = 1, DTSIM_KERNEL_RESET = 2, DTSIM_KERNEL_QUERY = 3, DTSIM_KERNEL_OBSERVE = 4, DTSIM_KERNEL__COUNT = 5 };
 
 int dtsim_abi_version(void);
 const char* dtsim_last_error(void);
@@ -267,6 +267,19 @@ size_t dtsim_frames_bytes(const dtsim_t* h);
 /* Render into caller-owned device memory instead (e.g. a torch tensor that is the
  * send buffer of the RCCL all-gather). NULL restores the internal buffer. */
 int dtsim_bind_frames(dtsim_t* h, void* devptr);
+
+/* Learner-side observation of the rendered frame batch, on the device (what the reference's learners do
+ * per env on the host): ResizeWrapper (learning/utils/wrappers.py:38-54, scipy imresize == PIL
+ * Image.resize BILINEAR, reproduced bit-exactly: Pillow's two-pass 22-bit fixed-point resampler with its
+ * uint8 intermediate), optionally ImgWrapper (HWC -> CHW, :72-86) and NormalizeWrapper (/ 255 -> float32,
+ * :57-69).  `taps_*` are Pillow's per-output-coordinate tables (first tap, tap count / fixed-point taps)
+ * as built by dtsim/resample.py; pass NULL tables for an axis whose size does not change.
+ * out: device pointer to [num_envs][out_h][out_w][3] (DTSIM_OBS_HWC) or [num_envs][3][out_h][out_w]
+ * (DTSIM_OBS_CHW), uint8 or float32 (DTSIM_OBS_F32).  Asynchronous, stream-ordered after dtsim_render. */
+enum { DTSIM_OBS_HWC = 0, DTSIM_OBS_CHW = 1, DTSIM_OBS_F32 = 2 };
+int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
+                  const int32_t* bounds_x, const int32_t* taps_x, int ksize_x,
+                  const int32_t* bounds_y, const int32_t* taps_y, int ksize_y);
 
 /* Geometry queries of the reference at arbitrary poses, evaluated on the device against
  * env env_idx[q]'s world (its map, dynamic objects and visibility): _valid_pose,
