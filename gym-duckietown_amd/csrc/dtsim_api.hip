@@ -696,7 +696,8 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
       tab.insert(tab.end(), taps_y, taps_y + (size_t)out_h * ksize_y);
     }
     // rows per workgroup: as many output rows as keep the uint8 intermediate (+ staging) within 48 KB of LDS
-    const size_t stage = 4 * (((size_t)W * 3 + 3) / 4) * 4, budget = 48 * 1024 - stage - 16;
+    const size_t stage = 4 * (((size_t)W * 3 + 3) / 4) * 4 + 32, tabs = (out_w != W && ksize_x <= 9) ? (size_t)out_w * 11 * 4 : 0;
+    const size_t budget = 48 * 1024 - stage - tabs - 32;
     const int max_rows = (int)std::min<size_t>((size_t)H, budget / ((size_t)out_w * 3));
     int rpb = 0, need = 0;
     for (int cand = 1; cand <= out_h; ++cand) {

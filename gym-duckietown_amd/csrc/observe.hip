@@ -32,8 +32,14 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   const int rows_in = y_last - y_first;
   const int in_row_bytes = P.W * 3, in_row_words = (in_row_bytes + 3) >> 2;
   const int tmp_row_bytes = P.ow * 3;
-  uint8_t* s_row = reinterpret_cast<uint8_t*>(s_mem);                               // [OBS_STAGE_ROWS][in_row_words * 4]
-  uint8_t* s_tmp = s_row + (size_t)OBS_STAGE_ROWS * in_row_words * 4;               // [rows_in][ow * 3]
+  uint8_t* s_row = reinterpret_cast<uint8_t*>(s_mem);                               // [OBS_STAGE_ROWS][in_row_words * 4] (+32 B slack)
+  uint8_t* s_tmp = s_row + (size_t)OBS_STAGE_ROWS * in_row_words * 4 + 32;          // [max_rows_in][ow * 3]
+  int32_t* s_bx = reinterpret_cast<int32_t*>(s_tmp + (((size_t)P.max_rows_in * tmp_row_bytes + 3) & ~(size_t)3));   // [ow][2]
+  int32_t* s_kx = s_bx + 2 * P.ow;                                                  // [ow][9] (fast path only)
+  if (P.ow != P.W && P.kx <= 9) {
+    for (int i = tid; i < 2 * P.ow; i += OB) s_bx[i] = P.bx[i];
+    for (int i = tid; i < 9 * P.ow; i += OB) s_kx[i] = (i % 9) < P.kx ? P.kkx[(i / 9) * P.kx + (i % 9)] : 0;
+  }
   const uint8_t* frame = P.frames + (size_t)e * P.H * in_row_bytes;
   const bool aligned = (in_row_bytes & 3) == 0;
 
@@ -53,42 +59,90 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
       }
     }
     __syncthreads();
-    for (int i = tid; i < nr * P.ow; i += OB) {
-      const int rr = i / P.ow, ox = i % P.ow;
-      const uint8_t* src = s_row + rr * in_row_words * 4;
-      uint8_t* dst = s_tmp + (size_t)(r0 + rr) * tmp_row_bytes + ox * 3;
-      if (P.ow == P.W) { dst[0] = src[ox * 3]; dst[1] = src[ox * 3 + 1]; dst[2] = src[ox * 3 + 2]; continue; }
-      const int x0 = P.bx[2 * ox], n = P.bx[2 * ox + 1];
-      const int32_t* k = P.kkx + ox * P.kx;
-      int32_t a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
-      const uint8_t* p = src + x0 * 3;
-      for (int t = 0; t < n; ++t) {
-        const int32_t kt = k[t];
-        a0 += (int32_t)p[3 * t] * kt; a1 += (int32_t)p[3 * t + 1] * kt; a2 += (int32_t)p[3 * t + 2] * kt;
+    if (P.ow != P.W && P.kx <= 9) {
+      // fast path (e.g. 640 -> 160: 8 taps): the 27 bytes of the 9-tap window come from 8 dword LDS reads,
+      // are byte-aligned with v_alignbyte and multiplied out with 24-bit integer MADs
+      for (int i = tid; i < nr * P.ow; i += OB) {
+        const int rr = i / P.ow, ox = i % P.ow;
+        const int x0 = s_bx[2 * ox];
+        const int32_t* k = s_kx + ox * 9;
+        const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(s_row + rr * in_row_words * 4);
+        const int b0 = x0 * 3, w0 = b0 >> 2;
+        const uint32_t sh = (uint32_t)(b0 & 3);
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = wsrc[w0 + q];               // may run past the row: those taps are 0
+        uint32_t a[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) a[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh);   // bytes b0+4q .. b0+4q+3
+        int32_t acc[3] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int32_t kt = k[t];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int b = 3 * t + c;
+            acc[c] += (int32_t)__umul24((a[b >> 2] >> (8 * (b & 3))) & 255u, (uint32_t)kt);
+          }
+        }
+        uint8_t* dst = s_tmp + (size_t)(r0 + rr) * tmp_row_bytes + ox * 3;
+        dst[0] = (uint8_t)clip8(acc[0]); dst[1] = (uint8_t)clip8(acc[1]); dst[2] = (uint8_t)clip8(acc[2]);
       }
-      dst[0] = (uint8_t)clip8(a0); dst[1] = (uint8_t)clip8(a1); dst[2] = (uint8_t)clip8(a2);
+    } else {
+      for (int i = tid; i < nr * P.ow; i += OB) {
+        const int rr = i / P.ow, ox = i % P.ow;
+        const uint8_t* src = s_row + rr * in_row_words * 4;
+        uint8_t* dst = s_tmp + (size_t)(r0 + rr) * tmp_row_bytes + ox * 3;
+        if (P.ow == P.W) { dst[0] = src[ox * 3]; dst[1] = src[ox * 3 + 1]; dst[2] = src[ox * 3 + 2]; continue; }
+        const int x0 = P.bx[2 * ox], n = P.bx[2 * ox + 1];
+        const int32_t* k = P.kkx + ox * P.kx;
+        int32_t a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
+        const uint8_t* p = src + x0 * 3;
+        for (int t = 0; t < n; ++t) {
+          const int32_t kt = k[t];
+          a0 += (int32_t)p[3 * t] * kt; a1 += (int32_t)p[3 * t + 1] * kt; a2 += (int32_t)p[3 * t + 2] * kt;
+        }
+        dst[0] = (uint8_t)clip8(a0); dst[1] = (uint8_t)clip8(a1); dst[2] = (uint8_t)clip8(a2);
+      }
     }
     __syncthreads();
   }
 
-  // ---- vertical pass + layout / normalisation
-  const int n_out = (oy1 - oy0) * tmp_row_bytes;
+  // ---- vertical pass + layout / normalisation (4 consecutive bytes per thread when the rows are dword-sized)
+  const bool vec4 = (tmp_row_bytes & 3) == 0;
+  const int per = vec4 ? 4 : 1;
+  const int n_out = (oy1 - oy0) * (tmp_row_bytes / per);
   for (int i = tid; i < n_out; i += OB) {
-    const int oy = oy0 + i / tmp_row_bytes, j = i % tmp_row_bytes;
-    uint32_t v;
-    if (P.oh == P.H) v = s_tmp[(size_t)(oy - y_first) * tmp_row_bytes + j];
-    else {
+    const int oy = oy0 + i / (tmp_row_bytes / per), j0 = (i % (tmp_row_bytes / per)) * per;
+    uint32_t v[4] = {0, 0, 0, 0};
+    if (P.oh == P.H) {
+      for (int q = 0; q < per; ++q) v[q] = s_tmp[(size_t)(oy - y_first) * tmp_row_bytes + j0 + q];
+    } else {
       const int y0 = P.by[2 * oy], n = P.by[2 * oy + 1];
       const int32_t* k = P.kky + oy * P.ky;
-      const uint8_t* p = s_tmp + (size_t)(y0 - y_first) * tmp_row_bytes + j;
-      int32_t a = 1 << (PREC - 1);
-      for (int t = 0; t < n; ++t) a += (int32_t)p[(size_t)t * tmp_row_bytes] * k[t];
-      v = clip8(a);
+      const uint8_t* p = s_tmp + (size_t)(y0 - y_first) * tmp_row_bytes + j0;
+      int32_t a[4] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
+      if (vec4) {
+        for (int t = 0; t < n; ++t) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)t * tmp_row_bytes);
+          const uint32_t kt = (uint32_t)k[t];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] += (int32_t)__umul24((w >> (8 * q)) & 255u, kt);
+        }
+      } else {
+        for (int t = 0; t < n; ++t) a[0] += (int32_t)p[(size_t)t * tmp_row_bytes] * k[t];
+      }
+      for (int q = 0; q < per; ++q) v[q] = clip8(a[q]);
     }
-    const int ox = j / 3, c = j % 3;
-    const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : ((size_t)e * P.oh + oy) * tmp_row_bytes + j;
-    if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v / 255.0f;     // NormalizeWrapper: (obs - 0) / (255 - 0)
-    else reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v;
+    for (int q = 0; q < per; ++q) {
+      const int j = j0 + q, ox = j / 3, c = j % 3;
+      const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : ((size_t)e * P.oh + oy) * tmp_row_bytes + j;
+      if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v[q] / 255.0f;     // NormalizeWrapper: (obs - 0) / (255 - 0)
+      else if (!vec4 || P.chw) reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v[q];
+    }
+    if (vec4 && !P.chw && !P.f32)                      // HWC uint8: one dword store
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.out) + ((size_t)e * P.oh + oy) * tmp_row_bytes + j0) =
+          v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
   }
 }
 
@@ -96,7 +150,8 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
 
 size_t dt_observe_lds_bytes(const ObserveParams& P) {
   const size_t in_row_words = ((size_t)P.W * 3 + 3) >> 2;
-  return OBS_STAGE_ROWS * in_row_words * 4 + (size_t)P.max_rows_in * P.ow * 3 + 16;
+  const size_t tabs = (P.ow != P.W && P.kx <= 9) ? (size_t)P.ow * (2 + 9) * 4 : 0;
+  return OBS_STAGE_ROWS * in_row_words * 4 + 32 + (((size_t)P.max_rows_in * P.ow * 3 + 3) & ~(size_t)3) + tabs + 16;
 }
 
 void dt_launch_observe(hipStream_t s, const ObserveParams& P) {
