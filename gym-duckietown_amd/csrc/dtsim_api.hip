@@ -696,8 +696,8 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
       tab.insert(tab.end(), taps_y, taps_y + (size_t)out_h * ksize_y);
     }
     // rows per workgroup: as many output rows as keep the uint8 intermediate (+ staging) within 48 KB of LDS
-    const size_t stage = 4 * (((size_t)W * 3 + 3) / 4) * 4 + 32, tabs = (out_w != W && ksize_x <= 9) ? (size_t)out_w * 11 * 4 : 0;
-    const size_t budget = 48 * 1024 - stage - tabs - 32;
+    const size_t stage = DT_OBS_STAGE_ROWS * (((size_t)W * 3 + 3) / 4) * 4 + 32, tabs = (out_w != W && ksize_x <= 9) ? (size_t)out_w * 11 * 4 : 0;
+    const size_t budget = DT_OBS_LDS_KB * 1024 - stage - tabs - 32;
     const int max_rows = (int)std::min<size_t>((size_t)H, budget / ((size_t)out_w * 3));
     int rpb = 0, need = 0;
     for (int cand = 1; cand <= out_h; ++cand) {
@@ -708,7 +708,7 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
       }
       if (worst > max_rows) break;
       rpb = cand; need = worst;
-      if (cand >= 16) break;                        // enough rows per workgroup; keep the grid large
+      if (cand >= DT_OBS_MAX_RPB) break;            // enough rows per workgroup; keep the grid large
     }
     if (rpb == 0) return fail(DTSIM_E_LIMIT, "observation %dx%d: one output row needs more input rows than fit in LDS", out_w, out_h);
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -187,6 +187,15 @@ struct RenderParams {
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);
 
+#ifndef DT_OBS_STAGE_ROWS
+#define DT_OBS_STAGE_ROWS 8
+#endif
+#ifndef DT_OBS_LDS_KB
+#define DT_OBS_LDS_KB 48
+#endif
+#ifndef DT_OBS_MAX_RPB
+#define DT_OBS_MAX_RPB 8
+#endif
 // observation post-processing (observe.hip): Pillow-exact bilinear resize + layout + normalisation
 struct ObserveParams {
   int32_t N, H, W, oh, ow;

@@ -14,7 +14,9 @@
 namespace {
 
 #define OB 256                 // threads per workgroup
-#define OBS_STAGE_ROWS 4       // input rows staged in LDS per horizontal step
+#ifndef OBS_STAGE_ROWS
+#define OBS_STAGE_ROWS DT_OBS_STAGE_ROWS   // input rows staged in LDS per horizontal step
+#endif
 #define PREC 22                // Pillow PRECISION_BITS (32 - 8 - 2)
 
 __device__ inline uint32_t clip8(int32_t acc) {
