@@ -229,6 +229,25 @@ def main():
             gather = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "steps": ks,
                       "collective": "all_gather_into_tensor(uint8 frames)", "bytes_per_rank_per_step": int(frames.numel())}
             del out
+            # the same exchange on what learners consume: 160x120 observations made on the device
+            # (dtsim_observe, PIL-exact bilinear): 16x fewer bytes over xGMI
+            obs = torch.as_tensor(sim.observe(120, 160), device=dev)
+            out = torch.empty((world,) + tuple(obs.shape), dtype=torch.uint8, device=dev)
+            sync_all()
+            tg = time.perf_counter()
+            for t in range(ks):
+                one_step(Wm + t)
+                sim.observe(120, 160)
+                sim.sync()
+                dist.all_gather_into_tensor(out, obs)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+            dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+            gather["observations"] = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "shape": [120, 160, 3],
+                                      "collective": "all_gather_into_tensor(uint8 160x120 observations from dtsim_observe)",
+                                      "bytes_per_rank_per_step": int(obs.numel())}
+            del out
         except Exception as ex:  # e.g. OOM on small-memory parts
             gather = {"error": repr(ex)[:200]}
 
