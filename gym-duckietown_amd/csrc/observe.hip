@@ -45,10 +45,33 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   const uint8_t* frame = P.frames + (size_t)e * P.H * in_row_bytes;
   const bool aligned = (in_row_bytes & 3) == 0;
 
-  // ---- horizontal pass (skipped when the width is unchanged: Pillow then resamples rows only)
+  // ---- horizontal pass (skipped when the width is unchanged: Pillow then resamples rows only).
+  // The rows of stage s+1 are prefetched into registers while stage s is filtered from LDS, so the
+  // global-load latency is off the critical path (one stage = OBS_STAGE_ROWS rows).
+  constexpr int PF = 16;                               // prefetch registers per thread
+  const bool pipelined = aligned && OBS_STAGE_ROWS * in_row_words <= PF * OB;
+  uint32_t pf[PF];
+  auto prefetch = [&](int r0) {
+    const int nr = min(OBS_STAGE_ROWS, rows_in - r0);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int i = tid + q * OB;
+      if (i < nr * in_row_words) {
+        const int rr = i / in_row_words, wd = i % in_row_words;
+        pf[q] = reinterpret_cast<const uint32_t*>(frame + (size_t)(y_first + r0 + rr) * in_row_bytes)[wd];
+      }
+    }
+  };
+  if (pipelined && rows_in > 0) prefetch(0);
   for (int r0 = 0; r0 < rows_in; r0 += OBS_STAGE_ROWS) {
     const int nr = min(OBS_STAGE_ROWS, rows_in - r0);
-    if (aligned) {                                   // coalesced dword loads of whole rows
+    if (pipelined) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int i = tid + q * OB;
+        if (i < nr * in_row_words) reinterpret_cast<uint32_t*>(s_row)[i] = pf[q];    // rows are contiguous: i == rr * in_row_words + wd
+      }
+    } else if (aligned) {                            // coalesced dword loads of whole rows
       for (int i = tid; i < nr * in_row_words; i += OB) {
         const int rr = i / in_row_words, wd = i % in_row_words;
         reinterpret_cast<uint32_t*>(s_row)[rr * in_row_words + wd] =
@@ -61,6 +84,7 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
       }
     }
     __syncthreads();
+    if (pipelined && r0 + OBS_STAGE_ROWS < rows_in) prefetch(r0 + OBS_STAGE_ROWS);
     if (P.ow != P.W && P.kx <= 9) {
       // fast path (e.g. 640 -> 160: 8 taps): the 27 bytes of the 9-tap window come from 8 dword LDS reads,
       // are byte-aligned with v_alignbyte and multiplied out with 24-bit integer MADs
