@@ -92,6 +92,8 @@ struct dtsim {
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
   uint32_t* d_items = nullptr;
+  dtsim_reset_sampler* d_sampler = nullptr;   // device copy when a reset sampler is installed
+  int map_w[DTSIM_MAX_MAPS] = {0}, map_h[DTSIM_MAX_MAPS] = {0};
   int32_t* d_obs_tab = nullptr;   // dtsim_observe resampling tables (cached per output size)
   int obs_h = 0, obs_w = 0, obs_kx = 0, obs_ky = 0, obs_rpb = 0, obs_rows_in = 0;
   size_t obs_off_by = 0;
@@ -147,8 +149,9 @@ StepParams step_params(const dtsim* h, int n_steps) {
   P.delay_steps = h->cfg.delay_steps;
   P.action_mode = h->cfg.action_mode;
   P.actions_f64 = (h->cfg.flags & DTSIM_F_ACTIONS_F64) ? 1 : 0;
-  P.auto_reset = ((h->cfg.flags & DTSIM_F_AUTO_RESET) && h->n_pool > 0) ? 1 : 0;
+  P.auto_reset = ((h->cfg.flags & DTSIM_F_AUTO_RESET) && (h->n_pool > 0 || h->d_sampler)) ? 1 : 0;
   P.n_pool = h->n_pool;
+  P.sampler = h->d_sampler;
   P.delta_time = h->cfg.delta_time;
   P.robot_speed = h->cfg.robot_speed;
   P.gain = h->cfg.gain; P.trim = h->cfg.trim; P.radius = h->cfg.radius; P.k = h->cfg.k; P.limit = h->cfg.limit;
@@ -255,7 +258,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -368,6 +371,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     if (n_static > DTSIM_MAX_STATIC) return fail(DTSIM_E_LIMIT, "map %d: %d static collidables > %d", mi, n_static, DTSIM_MAX_STATIC);
     if (n_dyn > DTSIM_MAX_DYNAMIC) return fail(DTSIM_E_LIMIT, "map %d: %d dynamic objects > %d", mi, n_dyn, DTSIM_MAX_DYNAMIC);
     MapHdr hd{};
+    h->map_w[mi] = mp.grid_w; h->map_h[mi] = mp.grid_h;
     hd.grid_w = mp.grid_w; hd.grid_h = mp.grid_h; hd.n_curves = mp.n_curves; hd.n_static = n_static;
     hd.n_dyn = n_dyn; hd.n_obj = mp.n_objects; hd.tile_size = mp.tile_size;
     int w = MAPHDR_WORDS;
@@ -450,7 +454,8 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
         r[12] = ob_.pos[0]; r[13] = ob_.pos[2]; r[14] = ob_.safety_radius;
       }
       ob[o * OBJ_WORDS + 0] = ob_.pos[0]; ob[o * OBJ_WORDS + 1] = ob_.pos[2];
-      ob[o * OBJ_WORDS + 2] = ob_.spawn_clear; ob[o * OBJ_WORDS + 3] = (double)slot;
+      ob[o * OBJ_WORDS + 2] = ob_.spawn_clear;
+      ob[o * OBJ_WORDS + 3] = (double)(slot >= 0 ? slot : (ob_.optional ? -2 : -1));   // -2: optional static object
       ObjInstDev oi{};
       oi.x = (float)ob_.pos[0]; oi.y = (float)ob_.pos[1]; oi.z = (float)ob_.pos[2];
       oi.scale = (float)ob_.scale; oi.yrot_deg = (float)(ob_.angle * (180.0 / 3.141592653589793));
@@ -541,10 +546,43 @@ static int check_states(const dtsim* h, const dtsim_init_state* st, int n, const
   return DTSIM_OK;
 }
 
+int dtsim_set_reset_sampler(dtsim_t* h, const dtsim_reset_sampler* sampler) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!sampler) {
+    if (h->d_sampler) { (void)hipFree(h->d_sampler); h->d_sampler = nullptr; }
+    return DTSIM_OK;
+  }
+  if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_set_reset_sampler before dtsim_set_maps");
+  if (sampler->max_attempts <= 0 || !(sampler->accept_start_angle_deg > 0))
+    return fail(DTSIM_E_INVALID, "sampler: max_attempts %d, accept_start_angle_deg %g", sampler->max_attempts, sampler->accept_start_angle_deg);
+  for (int m = 0; m < h->M.n_maps; ++m) {
+    const int i = sampler->start_tile[m][0], j = sampler->start_tile[m][1];
+    if (i < 0) continue;
+    if (i >= h->map_w[m] || j < 0 || j >= h->map_h[m]) return fail(DTSIM_E_INVALID, "sampler: start tile (%d,%d) outside map %d", i, j, m);
+  }
+  if (!h->d_sampler) HIPCHK(hipMalloc(&h->d_sampler, sizeof(dtsim_reset_sampler)));
+  HIPCHK(hipMemcpy(h->d_sampler, sampler, sizeof(dtsim_reset_sampler), hipMemcpyHostToDevice));
+  return DTSIM_OK;
+}
+
 int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states) {
-  if (!h || !states) return fail(DTSIM_E_INVALID, "null argument");
+  if (!h) return fail(DTSIM_E_INVALID, "null argument");
   if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_reset before dtsim_set_maps");
-  if (!mask && false) {}
+  if (!states) {                                     // device-side sampling
+    if (!h->d_sampler) return fail(DTSIM_E_STATE, "dtsim_reset(states = NULL) needs dtsim_set_reset_sampler");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (mask) HIPCHK(hipMemcpyAsync(h->d_mask, mask, (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+    {
+      ProfScope ps(h, DTSIM_KERNEL_RESET);
+      dt_launch_reset(h->stream, h->A, h->M, step_params(h, 0), mask ? h->d_mask : nullptr, nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_reset = true;
+    return DTSIM_OK;
+  }
   int rc = check_states(h, states, h->N, mask);
   if (rc) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));

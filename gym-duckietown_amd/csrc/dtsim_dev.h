@@ -82,6 +82,7 @@ struct SimArrays {
 struct StepParams {
   int32_t n_steps, frame_skip, max_steps, delay_steps;
   int32_t action_mode, actions_f64, auto_reset, n_pool;
+  const dtsim_reset_sampler* sampler;   // device copy, or null: device-side reset sampling (N2)
   double delta_time, robot_speed;
   double gain, trim, radius, k, limit;
 };

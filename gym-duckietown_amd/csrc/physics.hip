@@ -433,6 +433,143 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
   (void)delay_steps;
 }
 
+// _inconvenient_spawn simulator.py:1461-1471 (uses obj.pos; for a DuckieObj that is its current centre,
+// objects.py:408)
+__device__ inline bool inconvenient_spawn(const MapView& m, const SimArrays& A, int e, double px, double pz) {
+  bool inc = false;
+  const int N = A.N;
+  for (int o = 0; o < m.h->n_obj; ++o) {
+    if (!A.ob_visible[(size_t)o * N + e]) continue;
+    const double* ob = m.objs + o * OBJ_WORDS;
+    double ox = ob[0], oz = ob[1];
+    const int slot = (int)ob[3];
+    if (slot >= 0) { ox = A.ob_cx[(size_t)slot * N + e]; oz = A.ob_cz[(size_t)slot * N + e]; }
+    const double ddx = ox - px, ddz = oz - pz;
+    inc = inc || (sqrt((ddx * ddx + 0.0) + ddz * ddz) < ob[2]);
+  }
+  return inc;
+}
+
+// ---- device-side reset sampler (dtsim_reset_sampler) ----------------------------------
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so an env's draws for episode k depend only on
+// (seed, env, k) -- reproducible regardless of which step the reset happens in or how envs are sharded.
+struct Philox {
+  uint32_t key[2], ctr[4], out[4];
+  int left;
+};
+__device__ inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ inline void philox_refill(Philox& g) {
+  uint32_t c[4] = {g.ctr[0], g.ctr[1], g.ctr[2], g.ctr[3]}, k[2] = {g.key[0], g.key[1]};
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  for (int i = 0; i < 4; ++i) g.out[i] = c[i];
+  g.left = 4;
+  if (++g.ctr[0] == 0) ++g.ctr[1];
+}
+__device__ inline Philox philox_init(uint64_t seed, uint32_t env, uint32_t episode) {
+  Philox g;
+  g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32) ^ (env * 0x9E3779B1u + 0x7F4A7C15u);
+  g.ctr[0] = 0; g.ctr[1] = 0; g.ctr[2] = episode; g.ctr[3] = env;
+  g.left = 0;
+  return g;
+}
+__device__ inline uint32_t rng_u32(Philox& g) {
+  if (g.left == 0) philox_refill(g);
+  return g.out[--g.left];
+}
+__device__ inline double rng_double(Philox& g) {     // [0,1) with 53 random bits (numpy's construction)
+  const uint32_t a = rng_u32(g) >> 5, b = rng_u32(g) >> 6;
+  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+__device__ inline double rng_uniform(Philox& g, double lo, double hi) { return lo + (hi - lo) * rng_double(g); }
+__device__ inline int rng_below(Philox& g, int n) { return (int)(((uint64_t)rng_u32(g) * (uint64_t)n) >> 32); }
+__device__ inline double rng_normal(Philox& g, double loc, double scale) {   // Box-Muller
+  const double u1 = 1.0 - rng_double(g), u2 = rng_double(g);
+  return loc + scale * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+// _perturb simulator.py:1065-1085: val * U(1 - scale, 1 + scale) per component
+__device__ inline void perturb3(Philox& g, bool on, const double v[3], double scale, double out[3]) {
+  for (int k = 0; k < 3; ++k) out[k] = on ? v[k] * rng_uniform(g, 1.0 - scale, 1.0 + scale) : v[k];
+}
+
+// What Simulator.reset() decides for one env (simulator.py:546-738), drawn on the device: the same
+// distributions and acceptance test as dtsim/reset.py + the host spawn loop, from the Philox stream.
+__device__ inline dtsim_init_state sample_init(const SimArrays& A, const MapSet& M, const uint64_t* blobs,
+                                               const dtsim_reset_sampler& rs, int e, int episode, int map_id) {
+  const int N = A.N;
+  Philox g = philox_init(rs.seed, (uint32_t)e, (uint32_t)episode);
+  dtsim_init_state st;
+  st.map_id = map_id;
+  const bool dr = rs.domain_rand != 0;
+  // randomizer.py:36-91 (all seven keys are always drawn) -- sorted-key order kept for readability only
+  const double cam_angle_f = rng_uniform(g, 0.8, 1.2), cam_fov_f = rng_uniform(g, 0.8, 1.2), cam_height_f = rng_uniform(g, 0.92, 1.08);
+  for (int k = 0; k < 3; ++k) st.camera_noise[k] = rng_uniform(g, -0.005, 0.005);
+  const int horz_mode = rng_below(g, 4);
+  const double lp[3] = {rng_uniform(g, -150, 150), rng_uniform(g, 170, 220), rng_uniform(g, -150, 150)};
+  const double trim = rng_normal(g, 0.0, 0.02);
+  const double sky[3] = {rs.color_sky[0], rs.color_sky[1], rs.color_sky[2]};
+  const double wall[3] = {0.64, 0.71, 0.28}, dark[3] = {0.15, 0.15, 0.15}, light[3] = {0.9, 0.9, 0.9};
+  if (dr) {                                          // simulator.py:551-571
+    if (horz_mode == 0) perturb3(g, true, sky, 0.1, st.horizon_color);
+    else if (horz_mode == 1) perturb3(g, true, wall, 0.1, st.horizon_color);
+    else if (horz_mode == 2) perturb3(g, true, dark, 0.4, st.horizon_color);
+    else perturb3(g, true, light, 0.4, st.horizon_color);
+    st.light_pos[0] = lp[0]; st.light_pos[1] = lp[1]; st.light_pos[2] = lp[2]; st.light_pos[3] = 0.0;
+  } else {
+    for (int k = 0; k < 3; ++k) st.horizon_color[k] = sky[k];
+    st.light_pos[0] = 0.0; st.light_pos[1] = 3.0; st.light_pos[2] = 0.0; st.light_pos[3] = 1.0;
+  }
+  const double amb[3] = {0.25, 0.25, 0.25}, dif[3] = {0.35, 0.35, 0.35};
+  const double gnd[3] = {rs.color_ground[0], rs.color_ground[1], rs.color_ground[2]};
+  perturb3(g, dr, amb, 0.3, st.light_ambient);
+  perturb3(g, dr, dif, 0.99, st.light_diffuse);
+  perturb3(g, dr, gnd, 0.3, st.ground_color);
+  st.wheel_dist = dr ? 0.102 * rng_uniform(g, 0.9, 1.1) : 0.102;
+  st.cam_height = 0.108 * (dr ? cam_height_f : 1.0);
+  st.cam_angle_deg = 19.15 * (dr ? cam_angle_f : 1.0);
+  st.cam_fov_y_deg = 75.0 * (dr ? cam_fov_f : 1.0);
+  st.dynamics_trim_on = rs.dynamics_rand ? 1 : 0;
+  st.dynamics_trim = trim;
+  const MapView m = map_view(blobs + M.blob_off[map_id]);
+  const DynInit* dyn = M.dyn + (size_t)map_id * DTSIM_MAX_DYNAMIC;
+  // optional objects: visible with probability 1/2 under domain randomisation (simulator.py:653-656)
+  for (int o = 0; o < m.h->n_obj; ++o) {
+    const bool optional = m.objs[o * OBJ_WORDS + 3] < -1.5;       // dyn_slot word: -2 marks an optional static object
+    A.ob_visible[(size_t)o * N + e] = (optional && dr) ? (uint8_t)(rng_below(g, 2) == 0) : (uint8_t)1;
+  }
+  // start tile (simulator.py:659-676)
+  int ti = rs.start_tile[map_id][0], tj = rs.start_tile[map_id][1];
+  if (ti < 0) {
+    const int n_tiles = m.h->grid_w * m.h->grid_h;
+    for (int tries = 0; tries < 4096; ++tries) {     // uniform over the drivable tiles by rejection
+      const int t = rng_below(g, n_tiles);
+      if (m.tiles[t].drivable) { ti = t % m.h->grid_w; tj = t / m.h->grid_w; break; }
+    }
+    if (ti < 0) { ti = 0; tj = 0; }
+  }
+  // spawn loop (simulator.py:692-738)
+  const double ts = m.h->tile_size, M_deg = rs.accept_start_angle_deg;
+  st.pos[0] = 1.0; st.pos[1] = 0.0; st.pos[2] = 1.0; st.angle = 1.0;                 // fallback pose :732-736
+  for (int a = 0; a < rs.max_attempts; ++a) {
+    const double x = rng_uniform(g, ti, ti + 1) * ts, z = rng_uniform(g, tj, tj + 1) * ts;
+    const double ang = rng_uniform(g, 0.0, 6.283185307179586);
+    if (inconvenient_spawn(m, A, e, x, z)) continue;
+    if (!valid_pose(m, A, dyn, e, x, z, ang, 1.3, nullptr)) continue;
+    const Lane L = lane_pos(m, x, z, ang);
+    if (!L.in_lane) continue;
+    if (!(-M_deg < L.angle_deg && L.angle_deg < M_deg)) continue;
+    st.pos[0] = x; st.pos[2] = z; st.angle = ang;
+    break;
+  }
+  return st;
+}
+
 // Fill tile / lane / prox info for the current pose (what get_agent_info reports,
 // simulator.py:1586-1627).
 __device__ inline void fill_info(const SimArrays& A, const MapView& m, const DynInit* dyn, int e) {
@@ -469,8 +606,15 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     if (P.auto_reset && A.done[e]) {
       const int ep = A.episode[e] + 1;
       A.episode[e] = ep;
-      const long long slot = ((long long)e + (long long)ep * N) % P.n_pool;
-      apply_init(A, M, e, pool[slot], P.delay_steps);
+      if (P.sampler) {                               // device-side sampling (takes precedence over the pool)
+        const int cur = A.map_id[e];
+        const int nm = P.sampler->map_cycle ? (cur + 1) % M.n_maps : cur;
+        const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
+        apply_init(A, M, e, st, P.delay_steps);
+      } else {
+        const long long slot = ((long long)e + (long long)ep * N) % P.n_pool;
+        apply_init(A, M, e, pool[slot], P.delay_steps);
+      }
     }
     const int mid = A.map_id[e];
     const MapView m = map_view(blobs + M.blob_off[mid]);
@@ -557,6 +701,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, Ste
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= A.N) return;
   if (mask != nullptr && !mask[e]) return;
+  if (states == nullptr) {                           // device sampler (dtsim_reset(h, mask, NULL))
+    const int ep = A.episode[e] + 1;
+    A.episode[e] = ep;
+    const int cur = A.map_id[e] < 0 ? (P.sampler->map_cycle ? e % M.n_maps : 0) : A.map_id[e];
+    const int nm = (A.map_id[e] >= 0 && P.sampler->map_cycle) ? (cur + 1) % M.n_maps : cur;
+    // objects of a fresh env must exist before the spawn test looks at them
+    if (A.map_id[e] != nm) { dtsim_init_state z{}; z.map_id = nm; z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps); }
+    const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
+    apply_init(A, M, e, st, P.delay_steps);
+  } else
   apply_init(A, M, e, states[e], P.delay_steps);
   const int mid = A.map_id[e];
   fill_info(A, map_view(blobs + M.blob_off[mid]), M.dyn + (size_t)mid * DTSIM_MAX_DYNAMIC, e);
@@ -590,19 +744,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_query(SimArrays A, MapSet M, Ste
   r.dist = L.dist; r.dot_dir = L.dot_dir; r.angle_deg = L.angle_deg; r.angle_rad = L.angle_rad;
   r.prox = proximity(m, A, dyn, e, px, pz, ang);
   r.reward = compute_reward(L, r.prox, P.robot_speed);
-  // _inconvenient_spawn simulator.py:1461-1471 (uses obj.pos; for a DuckieObj that is its
-  // current centre, objects.py:408)
-  bool inc = false;
-  const int N = A.N;
-  for (int o = 0; o < m.h->n_obj; ++o) {
-    if (!A.ob_visible[(size_t)o * N + e]) continue;
-    const double* ob = m.objs + o * OBJ_WORDS;
-    double ox = ob[0], oz = ob[1];
-    const int slot = (int)ob[3];
-    if (slot >= 0) { ox = A.ob_cx[(size_t)slot * N + e]; oz = A.ob_cz[(size_t)slot * N + e]; }
-    const double ddx = ox - px, ddz = oz - pz;
-    inc = inc || (sqrt((ddx * ddx + 0.0) + ddz * ddz) < ob[2]);
-  }
+  const bool inc = inconvenient_spawn(m, A, e, px, pz);
   r.inconvenient = inc;
   r.pad[0] = r.pad[1] = r.pad[2] = 0;
   out[qi] = r;

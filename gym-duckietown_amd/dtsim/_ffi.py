@@ -37,7 +37,7 @@ EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_observe", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -91,6 +91,14 @@ class Texture(C.Structure):
 class Mesh(C.Structure):
     _fields_ = [("n_tris", C.c_int32), ("verts", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
                 ("colors", C.POINTER(C.c_float)), ("uvs", C.POINTER(C.c_float)), ("tri_tex", C.POINTER(C.c_int32))]
+
+
+class ResetSampler(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("domain_rand", C.c_int32), ("dynamics_rand", C.c_int32), ("map_cycle", C.c_int32),
+        ("max_attempts", C.c_int32), ("accept_start_angle_deg", C.c_double),
+        ("color_sky", C.c_double * 3), ("color_ground", C.c_double * 3), ("start_tile", (C.c_int32 * 2) * 8),
+    ]
 
 
 class InitState(C.Structure):
@@ -153,6 +161,7 @@ def load(path: str | None = None):
         "dtsim_frames_devptr": (vp, [vp]),
         "dtsim_frames_bytes": (sz, [vp]),
         "dtsim_bind_frames": (ci, [vp, vp]),
+        "dtsim_set_reset_sampler": (ci, [vp, C.POINTER(ResetSampler)]),
         "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),
         "dtsim_query": (ci, [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double, C.POINTER(Probe)]),
         "dtsim_read": (ci, [vp, ci, vp, sz]),

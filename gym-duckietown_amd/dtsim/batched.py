@@ -40,7 +40,8 @@ class BatchedSimulator:
                  render: bool = True, auto_reset: bool = False, delay_steps: int = 5, device: int = 0,
                  stream: Optional[int] = None, profile: bool = False, actions_f64: bool = False,
                  map_cycle: bool = False, transform_uses_width: bool = False, map_data: Optional[dict] = None,
-                 asset_root: Optional[str] = None, style: str = "photos", do_reset: bool = True):
+                 asset_root: Optional[str] = None, style: str = "photos", device_reset: bool = False,
+                 do_reset: bool = True):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
         self._device = int(device)
@@ -148,10 +149,37 @@ class BatchedSimulator:
         self.env_map = np.zeros(self.num_envs, np.int32)
         self.init_states = (_ffi.InitState * self.num_envs)()
         self._have_reset = False
+        self.device_reset = bool(device_reset)
+        if self.device_reset:
+            self.install_reset_sampler()
         if do_reset:
             self.reset()
 
     # ------------------------------------------------------------------ reset --
+    def install_reset_sampler(self, seed: Optional[int] = None):
+        """Device-side reset sampling (dtsim_reset_sampler): reset() and auto-reset then draw DR values and
+        spawn poses on the GPU (the reference's distributions and acceptance test, Philox stream) instead
+        of on the host in numpy's RNG order."""
+        rs = _ffi.ResetSampler()
+        sv = self.seed_value if seed is None else seed
+        rs.seed = int(sv if sv is not None else np.random.SeedSequence().entropy) & 0xFFFFFFFFFFFFFFFF
+        rs.domain_rand, rs.dynamics_rand = int(self.domain_rand), int(self.dynamics_rand)
+        rs.map_cycle = int(self.map_cycle and len(self.maps) > 1)
+        rs.max_attempts = R.MAX_SPAWN_ATTEMPTS
+        rs.accept_start_angle_deg = float(self.accept_start_angle_deg)
+        rs.color_sky[:] = [float(v) for v in self.color_sky]
+        rs.color_ground[:] = [float(v) for v in self.color_ground]
+        for m in range(_ffi.MAX_MAPS):
+            tile = (-1, -1)
+            if m < len(self.maps):
+                if self.user_tile_start:
+                    tile = tuple(int(v) for v in self.user_tile_start)
+                elif self.maps[m].start_tile is not None:
+                    tile = tuple(int(v) for v in self.maps[m].start_tile)
+            rs.start_tile[m][0], rs.start_tile[m][1] = tile
+        _ffi.check(self._lib, self._lib.dtsim_set_reset_sampler(self._h, C.byref(rs)))
+        self._sampler = rs
+
     def _map_for_reset(self, e: int) -> int:
         if len(self.maps) == 1:
             return 0
@@ -256,6 +284,13 @@ class BatchedSimulator:
         ctypes array / list of _ffi.InitState to use instead of sampling (parity mode)."""
         if not self._have_reset:
             mask = None                        # the first reset creates every env's world
+        if self.device_reset and states is None:
+            m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+            mp = m.ctypes.data_as(C.POINTER(C.c_uint8)) if m is not None else None
+            _ffi.check(self._lib, self._lib.dtsim_reset(self._h, mp, None))
+            self.env_map[:] = self.read(_ffi.FIELD_MAP_ID)
+            self._have_reset = True
+            return
         sel = list(range(self.num_envs)) if mask is None else [int(e) for e in np.flatnonzero(mask)]
         if states is not None:
             for e in sel:

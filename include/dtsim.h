@@ -248,7 +248,28 @@ int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy)
 
 /* Simulator.reset() for the envs with mask[e] != 0 (mask NULL = all): state taken from
  * states[e] (array of num_envs entries). */
-int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states);
+int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states);   /* states == NULL: device sampler */
+/* Device-side reset sampler.  The reference's reset() draws, per env, the domain-
+ * randomisation values (simulator.py:546-614, randomizer.py:36-91), the visibility of optional objects
+ * (:648-656), a start tile (:659-676) and then poses until one is accepted (:692-738: not an
+ * inconvenient spawn, valid at safety factor 1.3, within accept_start_angle_deg of the lane).  With a
+ * sampler installed the same *distributions* and acceptance test run on the device from a counter-based
+ * generator (Philox4x32-10 keyed by seed and env index, counter = episode) -- the stream differs from
+ * numpy's PCG64, so this mode is for throughput, not for RNG-order parity (dtsim_reset with host states
+ * / the spawn pool keep that).  Used by DTSIM_F_AUTO_RESET when installed (it takes precedence over the
+ * pool) and by dtsim_reset(h, mask, NULL). */
+typedef struct dtsim_reset_sampler {
+  uint64_t seed;
+  int32_t domain_rand;              /* draw camera / light / colour / wheel_dist perturbations */
+  int32_t dynamics_rand;            /* apply the drawn trim (simulator.py:744-750) */
+  int32_t map_cycle;                /* MultiMapEnv: switch to the next map at every reset (multimap_env.py:44-49) */
+  int32_t max_attempts;             /* MAX_SPAWN_ATTEMPTS, 5000 */
+  double accept_start_angle_deg;    /* simulator.py:724-728 */
+  double color_sky[3], color_ground[3];
+  int32_t start_tile[DTSIM_MAX_MAPS][2];  /* user_tile_start / the map's start_tile; -1 = a random drivable tile */
+} dtsim_reset_sampler;
+int dtsim_set_reset_sampler(dtsim_t* h, const dtsim_reset_sampler* sampler);   /* NULL uninstalls */
+
 /* Pool of spawn states used by DTSIM_F_AUTO_RESET: env e starts episode k from
  * pool[(e + k * num_envs) % n_pool]. */
 int dtsim_set_spawn_pool(dtsim_t* h, const dtsim_init_state* pool, int n_pool);

@@ -31,14 +31,16 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header(tmp_path):
     prog = tmp_path / "sz.c"
-    prog.write_text('#include "dtsim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include "dtsim.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(dtsim_config),sizeof(dtsim_object),sizeof(dtsim_map),sizeof(dtsim_init_state),sizeof(dtsim_probe),'
-                    'sizeof(dtsim_texture),sizeof(dtsim_mesh),offsetof(dtsim_probe,prox),offsetof(dtsim_init_state,light_pos));return 0;}\n')
+                    'sizeof(dtsim_texture),sizeof(dtsim_mesh),offsetof(dtsim_probe,prox),offsetof(dtsim_init_state,light_pos),'
+                    'sizeof(dtsim_reset_sampler),offsetof(dtsim_reset_sampler,start_tile));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(_ffi.Config), C.sizeof(_ffi.Object), C.sizeof(_ffi.Map), C.sizeof(_ffi.InitState), C.sizeof(_ffi.Probe),
-            C.sizeof(_ffi.Texture), C.sizeof(_ffi.Mesh), _ffi.Probe.prox.offset, _ffi.InitState.light_pos.offset]
+            C.sizeof(_ffi.Texture), C.sizeof(_ffi.Mesh), _ffi.Probe.prox.offset, _ffi.InitState.light_pos.offset,
+            C.sizeof(_ffi.ResetSampler), _ffi.ResetSampler.start_tile.offset]
     assert got == want
     assert _ffi.probe_dtype().itemsize == C.sizeof(_ffi.Probe)
     # header constants mirrored in Python
