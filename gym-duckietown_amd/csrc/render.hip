@@ -183,6 +183,10 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
 // One workgroup per env.  WorldObj.render (objects.py:123-148): T(pos) S(scale) Ry(y_rot), mesh
 // chunks with per-vertex Kd colour (objmesh.py:241-293), GL per-vertex lighting (unit normals,
 // DESIGN.md "Render spec"), projected to rectilinear pixel coordinates.
+// order-preserving float <-> int map (for integer atomics on floats)
+__device__ inline int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ inline float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
 __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
@@ -191,6 +195,13 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   const RenderMapDev m = R.maps[c.map_id];
   ScreenTri* out = R.stris + (size_t)e * R.max_tris;
   float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;
+  // per-object screen boxes: LDS min / max through the order-preserving float -> int map
+  __shared__ int s_obox[DTSIM_MAX_OBJECTS][4];
+  if (tid < DTSIM_MAX_OBJECTS) {
+    s_obox[tid][0] = s_obox[tid][2] = 0x7fffffff;    // min slots
+    s_obox[tid][1] = s_obox[tid][3] = (int)0x80000000;   // max slots
+  }
+  __syncthreads();
   int obj = 0, obj_first = 0;              // walk the object list as t grows (t is monotone per thread)
   for (int t = tid; t < m.n_tris; t += 256) {
     ObjInstDev oi = R.objs[m.obj_off + obj];
@@ -252,20 +263,23 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     if (!ok) { st.bx0 = 1e30f; st.bx1 = -1e30f; st.by0 = 1e30f; st.by1 = -1e30f; }
     st.index = t;
     out[t] = st;
-    if (ok) { bx0 = fminf(bx0, st.bx0); bx1 = fmaxf(bx1, st.bx1); by0 = fminf(by0, st.by0); by1 = fmaxf(by1, st.by1); }
+    if (ok) {
+      bx0 = fminf(bx0, st.bx0); bx1 = fmaxf(bx1, st.bx1); by0 = fminf(by0, st.by0); by1 = fmaxf(by1, st.by1);
+      atomicMin(&s_obox[obj][0], f2ord(st.bx0)); atomicMax(&s_obox[obj][1], f2ord(st.bx1));
+      atomicMin(&s_obox[obj][2], f2ord(st.by0)); atomicMax(&s_obox[obj][3], f2ord(st.by1));
+    }
   }
-  __syncthreads();                          // the env's ScreenTris are written (workgroup scope)
+  __syncthreads();
   if (tid < m.n_obj) {                      // per-object screen box = union of its live triangles' boxes
     ObjBox ob;
-    ob.bx0 = 1e30f; ob.bx1 = -1e30f; ob.by0 = 1e30f; ob.by1 = -1e30f; ob.first = 0; ob.count = 0; ob.pad[0] = ob.pad[1] = 0;
+    ob.first = 0; ob.pad[0] = ob.pad[1] = 0;
     for (int o = 0; o < tid; ++o) { const int mid = R.objs[m.obj_off + o].mesh_id; ob.first += mid >= 0 ? R.meshes[mid].n_tris : 0; }
     const int mid = R.objs[m.obj_off + tid].mesh_id;
     const int cnt = mid >= 0 ? R.meshes[mid].n_tris : 0;
-    for (int t = ob.first; t < ob.first + cnt; ++t) {
-      const float4 bb = *reinterpret_cast<const float4*>(out + t);
-      if (bb.x <= bb.y) { ob.bx0 = fminf(ob.bx0, bb.x); ob.bx1 = fmaxf(ob.bx1, bb.y); ob.by0 = fminf(ob.by0, bb.z); ob.by1 = fmaxf(ob.by1, bb.w); }
-    }
-    ob.count = ob.bx0 <= ob.bx1 ? cnt : 0;
+    const bool live = s_obox[tid][0] != 0x7fffffff;
+    ob.bx0 = live ? ord2f(s_obox[tid][0]) : 1e30f; ob.bx1 = live ? ord2f(s_obox[tid][1]) : -1e30f;
+    ob.by0 = live ? ord2f(s_obox[tid][2]) : 1e30f; ob.by1 = live ? ord2f(s_obox[tid][3]) : -1e30f;
+    ob.count = live ? cnt : 0;
     R.objbox[(size_t)e * DTSIM_MAX_OBJECTS + tid] = ob;
   }
   __shared__ float red[4][256];
