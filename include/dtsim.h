@@ -44,12 +44,12 @@ extern "C" {
 #define DTSIM_MAX_MAPS 8
 #define DTSIM_MAX_TILES 1024        /* grid_w * grid_h per map */
 #define DTSIM_MAX_CURVES 1024       /* per map */
-#define DTSIM_MAX_STATIC 32         /* collidable static objects per map */
+#define DTSIM_MAX_STATIC 56         /* collidable static objects per map */
 #define DTSIM_MAX_DYNAMIC 8         /* dynamic objects (DuckieObj + DuckiebotObj) per map */
-#define DTSIM_MAX_OBJECTS 40        /* renderable objects per map */
+#define DTSIM_MAX_OBJECTS 64        /* renderable objects per map */
 #define DTSIM_MAX_DELAY 8           /* dynamics command delay, in steps */
-#define DTSIM_MAX_TEXTURES 32
-#define DTSIM_MAX_MESHES 16
+#define DTSIM_MAX_TEXTURES 96
+#define DTSIM_MAX_MESHES 64
 
 /* dtsim_config.flags */
 #define DTSIM_F_RENDER 1u        /* allocate the [N,H,W,3] frame buffer */
