@@ -250,6 +250,17 @@ class Simulator(_EnvBase):
             return None
         return self.grid[j * self.grid_width + i]
 
+    def _get_curve(self, i, j):
+        """simulator.py:1151: the Bezier control points [C,4,3] of a drivable tile."""
+        tile = self._get_tile(i, j)
+        assert tile is not None
+        return tile["curves"]
+
+    def _perturb(self, val, scale=0.1):
+        """simulator.py:1065-1085 (consumes the env's RNG exactly like the reference)."""
+        from dtsim import reset as _R
+        return _R._perturb(self.np_random, self.domain_rand, val, scale)
+
     def _drivable_pos(self, pos) -> bool:
         return bool(self._probe(pos, 0.0)["drivable"])
 
