@@ -138,6 +138,8 @@ size_t layout_arrays(SimArrays& A, int N, char* base) {
   A.done = carve<uint8_t>(p, n); A.done_code = carve<uint8_t>(p, n); A.in_lane = carve<uint8_t>(p, n);
   A.ob_active = carve<uint8_t>(p, n * DTSIM_MAX_DYNAMIC);
   A.ob_visible = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
+  A.ob_light = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
+  A.tl_time = carve<double>(p, n);
   return (size_t)(p - base);
 }
 
@@ -373,6 +375,8 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     MapHdr hd{};
     h->map_w[mi] = mp.grid_w; h->map_h[mi] = mp.grid_h;
     hd.grid_w = mp.grid_w; hd.grid_h = mp.grid_h; hd.n_curves = mp.n_curves; hd.n_static = n_static;
+    hd.n_lights = 0;
+    for (int o = 0; o < mp.n_objects; ++o) hd.n_lights += mp.objects[o].light_freq > 0 ? 1 : 0;
     hd.n_dyn = n_dyn; hd.n_obj = mp.n_objects; hd.tile_size = mp.tile_size;
     int w = MAPHDR_WORDS;
     hd.off_tiles = w; w += nt;
@@ -456,10 +460,15 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
       ob[o * OBJ_WORDS + 0] = ob_.pos[0]; ob[o * OBJ_WORDS + 1] = ob_.pos[2];
       ob[o * OBJ_WORDS + 2] = ob_.spawn_clear;
       ob[o * OBJ_WORDS + 3] = (double)(slot >= 0 ? slot : (ob_.optional ? -2 : -1));   // -2: optional static object
+      ob[o * OBJ_WORDS + 4] = (double)ob_.light_freq; ob[o * OBJ_WORDS + 5] = (double)(ob_.light_pattern & 1);
+      if (ob_.light_freq < 0) return fail(DTSIM_E_INVALID, "map %d object %d: light_freq %d", mi, o, ob_.light_freq);
       ObjInstDev oi{};
       oi.x = (float)ob_.pos[0]; oi.y = (float)ob_.pos[1]; oi.z = (float)ob_.pos[2];
       oi.scale = (float)ob_.scale; oi.yrot_deg = (float)(ob_.angle * (180.0 / 3.141592653589793));
       oi.mesh_id = ob_.mesh_id; oi.dyn_slot = slot;
+      oi.light_tris = ob_.light_freq > 0 ? ob_.light_tris : 0; oi.light_tex0 = ob_.light_tex[0]; oi.light_tex1 = ob_.light_tex[1];
+      if (oi.light_tris > 0 && (oi.light_tex0 >= h->n_tex || oi.light_tex1 >= h->n_tex))
+        return fail(DTSIM_E_INVALID, "map %d object %d: light texture not loaded", mi, o);
       robjs.push_back(oi);
     }
     h->map_n_dyn[mi] = n_dyn; h->map_n_obj[mi] = mp.n_objects;
@@ -825,6 +834,7 @@ bool field_desc(dtsim* h, int field, FieldDesc& d) {
     case DTSIM_FIELD_OBJ_ACTIVE: d = {A.ob_active, 1, DTSIM_MAX_DYNAMIC, N, true}; return true;
     case DTSIM_FIELD_OBJ_YROT: d = {A.ob_yrot, 8, DTSIM_MAX_DYNAMIC, N, true}; return true;
     case DTSIM_FIELD_OBJ_VISIBLE: d = {A.ob_visible, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
+    case DTSIM_FIELD_OBJ_LIGHT: d = {A.ob_light, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
     case DTSIM_FIELD_EPISODE: d = {A.episode, 4, 1, N, true}; return true;
     default: return false;
   }

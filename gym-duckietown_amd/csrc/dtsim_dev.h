@@ -30,7 +30,8 @@ struct MapHdr {            // 8-byte words; offsets are in words from the blob s
   int32_t n_dyn, n_obj;
   int32_t off_tiles, off_curves;   // tiles: 1 word each; curves: 8 words each (P0x,P0z..P3x,P3z)
   int32_t off_heads, off_static;   // heads: 2 words per curve; static: 15 words each
-  int32_t off_objs, total_words;   // objs: 4 words each (x, z, spawn_clear, dyn_slot(as double, -1 static))
+  int32_t off_objs, total_words;   // objs: OBJ_WORDS words each
+  int32_t n_lights, pad_l;         // traffic lights among the objects (0: k_step skips the light clock)
   double tile_size;
 };
 static_assert(sizeof(MapHdr) % 8 == 0, "MapHdr must be whole words");
@@ -44,7 +45,7 @@ static_assert(sizeof(TileRec) == 8, "TileRec is one word");
 
 // static collidable record: corners[8] norms[4] center[2] radius[1]
 #define STATIC_WORDS 15
-#define OBJ_WORDS 4
+#define OBJ_WORDS 6      // x, z, spawn_clear, dyn_slot (-1 static, -2 optional static), light_freq, light_pattern0
 
 struct DynInit {           // per map, per dynamic slot: initial DuckieObj state
   double cx, cz, corners[8], norm[4], heading_x, heading_z, angle, safety_radius;
@@ -77,6 +78,8 @@ struct SimArrays {
   uint8_t *done, *done_code, *in_lane;
   uint8_t *ob_active;      // [DTSIM_MAX_DYNAMIC][N]
   uint8_t *ob_visible;     // [DTSIM_MAX_OBJECTS][N]
+  uint8_t *ob_light;       // [DTSIM_MAX_OBJECTS][N] TrafficLightObj.pattern
+  double *tl_time;         // [N] TrafficLightObj.time (object clock: not reset with the env, objects.py:441,459)
 };
 
 struct StepParams {
@@ -118,8 +121,11 @@ struct RenderMapDev {       // per map, raster view of the grid + objects
 
 struct ObjInstDev {         // static render instance (dynamic ones are patched per env)
   float x, y, z, scale, yrot_deg;
-  int32_t mesh_id, dyn_slot, pad;
+  int32_t mesh_id, dyn_slot;
+  int32_t light_tris, light_tex0, light_tex1;   // traffic light: first `light_tris` triangles take texture 0 / 1 by pattern
+  int32_t pad[2];
 };
+static_assert(sizeof(ObjInstDev) == 48, "ObjInstDev is 48 bytes");
 
 // LDS-staged raster tile record: texel base of the (padded) texture, flags (bit0 present,
 // bit1 textured), and the affine map tile-fraction (fx, fz) -> texel coordinates

@@ -427,6 +427,12 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
       A.ob_active[ix] = 0;
     }
     for (int o = 0; o < DTSIM_MAX_OBJECTS; ++o) A.ob_visible[(size_t)o * N + e] = 1;
+    {  // TrafficLightObj.__init__ (objects.py:441-453): object clock 0, initial pattern
+      const double* objs = reinterpret_cast<const double*>(M.blobs + M.blob_off[new_map]) + mh->off_objs;
+      for (int o = 0; o < DTSIM_MAX_OBJECTS; ++o)
+        A.ob_light[(size_t)o * N + e] = (o < mh->n_obj && objs[o * OBJ_WORDS + 4] > 0.0) ? (uint8_t)objs[o * OBJ_WORDS + 5] : (uint8_t)0;
+      A.tl_time[e] = 0.0;
+    }
     A.map_id[e] = new_map;
   }
   // info fields of the new pose are filled by the first step / by k_reset's tail
@@ -666,6 +672,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
         if (dyn[d].kind == 2) duckiebot_step(A, m, dyn[d], d, e, dt);
         else duckie_step(A, dyn[d], d, e, dt);
+      }
+      if (m.h->n_lights > 0) {                         // TrafficLightObj.step (objects.py:455-463)
+        const double tl = A.tl_time[e] + dt;
+        A.tl_time[e] = tl;
+        // round(time, 3) % freq == 0  <=>  the time rounded to milliseconds is a whole multiple of freq seconds
+        const long long ms = llrint(tl * 1000.0);
+        for (int o = 0; o < m.h->n_obj; ++o) {
+          const long long f_ms = (long long)m.objs[o * OBJ_WORDS + 4] * 1000;
+          if (f_ms > 0 && ms % f_ms == 0) A.ob_light[(size_t)o * N + e] ^= 1;
+        }
       }
     }
     A.q_x[e] = q.x; A.q_y[e] = q.y; A.q_c[e] = q.c; A.q_s[e] = q.s; A.vel_u[e] = q.u; A.vel_w[e] = q.w;

@@ -254,6 +254,8 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
       st.uw[v] = td.uv[v][0] * iw; st.vw[v] = td.uv[v][1] * iw;
     }
     st.tex = td.tex; st.pad = 0;
+    if (oi.light_tris > 0 && (t - obj_first) < oi.light_tris)          // traffic light card: texture by pattern
+      st.tex = A.ob_light[(size_t)obj * N + e] ? oi.light_tex1 : oi.light_tex0;
     const float area = (st.sx[1] - st.sx[0]) * (st.sy[2] - st.sy[0]) - (st.sx[2] - st.sx[0]) * (st.sy[1] - st.sy[0]);
     ok = ok && (area != 0.f);
     st.inv_area = ok ? 1.f / area : 0.f;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 8, 96, 64
@@ -29,7 +29,7 @@ TILE_OTHER = 10
 (FIELD_POS, FIELD_ANGLE, FIELD_REWARD, FIELD_DONE, FIELD_DONE_CODE, FIELD_STEP_COUNT, FIELD_TILE,
  FIELD_LANE, FIELD_IN_LANE, FIELD_PROX, FIELD_SPEED, FIELD_TIMESTAMP, FIELD_WHEELS, FIELD_MAP_ID,
  FIELD_OBJ_CENTER, FIELD_OBJ_ACTIVE, FIELD_OBJ_YROT, FIELD_OBJ_PARAMS, FIELD_OBJ_VISIBLE,
- FIELD_EPISODE, FIELD_STATE_BLOB) = range(21)
+ FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT) = range(22)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 
@@ -70,6 +70,8 @@ class Object(C.Structure):
         ("corners", C.c_double * 8), ("norm", C.c_double * 4), ("safety_radius", C.c_double),
         ("spawn_clear", C.c_double),
         ("walk_distance", C.c_double), ("vel", C.c_double), ("wait_time", C.c_double), ("wiggle", C.c_double),
+        ("light_freq", C.c_int32), ("light_pattern", C.c_int32), ("light_tex", C.c_int32 * 2),
+        ("light_tris", C.c_int32), ("light_pad", C.c_int32),
     ]
 
 

@@ -382,5 +382,12 @@ class AssetLibrary:
             self._meshes[key] = m
         return key, self._meshes[key]
 
+    def light_cards(self):
+        """TrafficLightObj's two card textures (objects.py:438-441), or None when the tree has none."""
+        ps = [self.resolve(f"trafficlight_card{k}.jpg") for k in (0, 1)] if self.root else [None, None]
+        if None in ps:
+            return None
+        return [to_pow2(load_image_rgba(p)) for p in ps]
+
     def mesh_extents(self, kinds) -> dict:
         return {k: (self.mesh(k).min_coords, self.mesh(k).max_coords) for k in kinds}

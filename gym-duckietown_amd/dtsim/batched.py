@@ -110,6 +110,12 @@ class BatchedSimulator:
         for mk in mesh_order:
             mesh_tex_base[mk] = len(self.textures)
             self.textures.extend(self.meshes[mk].textures)
+        self.light_tex = (-1, -1)                      # traffic-light cards (only when a map has lights and the tree has cards)
+        if any(o.light_freq > 0 for mt in first for o in mt.objects):
+            cards = self.library.light_cards()
+            if cards is not None:
+                self.light_tex = (len(self.textures), len(self.textures) + 1)
+                self.textures.extend(cards)
         tex_ids = {kd: i for i, kd in enumerate(tex_kinds)} if render else None
         self.maps: List[maps.MapTables] = [
             maps.interpret_map(d, n, self.meshes, transform_uses_width, texture_ids=tex_ids, library=use_lib)
@@ -136,7 +142,7 @@ class BatchedSimulator:
         mesh_ids = {mk: i for i, mk in enumerate(mesh_order)} if render else {}
         farr = (_ffi.Map * len(self.maps))()
         for i, mt in enumerate(self.maps):
-            farr[i] = mt.to_ffi(mesh_ids)
+            farr[i] = mt.to_ffi(mesh_ids, self.light_tex if render else (-1, -1))
         _ffi.check(self._lib, self._lib.dtsim_set_maps(self._h, farr, len(self.maps)))
         if render and distortion:
             rmx, rmy = dist_mod.distortion_maps(self.camera_width, self.camera_height)
@@ -394,6 +400,7 @@ class BatchedSimulator:
         _ffi.FIELD_OBJ_CENTER: ("f8", (_ffi.MAX_DYNAMIC, 2)), _ffi.FIELD_OBJ_ACTIVE: ("u1", (_ffi.MAX_DYNAMIC,)),
         _ffi.FIELD_OBJ_YROT: ("f8", (_ffi.MAX_DYNAMIC,)), _ffi.FIELD_OBJ_PARAMS: ("f8", (_ffi.MAX_DYNAMIC, 3)),
         _ffi.FIELD_OBJ_VISIBLE: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_EPISODE: ("i4", ()),
+        _ffi.FIELD_OBJ_LIGHT: ("u1", (_ffi.MAX_OBJECTS,)),
     }
 
     def read(self, field: int) -> np.ndarray:

@@ -122,6 +122,9 @@ class ObjectTable:
     wiggle: float = math.pi / 15
     dyn_slot: int = -1
     dyn_kind: int = 0            # 0 static, 1 DuckieObj, 2 DuckiebotObj
+    light_freq: int = 0          # TrafficLightObj (objects.py:434-453): seconds between pattern switches, 0 = not a light
+    light_pattern: int = 0
+    light_tris: int = 0          # triangles of the mesh's first material chunk (mesh.textures[0])
 
 
 @dataclass
@@ -150,7 +153,7 @@ class MapTables:
     def n_dynamic(self):
         return sum(1 for o in self.objects if not o.static)
 
-    def to_ffi(self, mesh_ids: Dict[str, int]) -> _ffi.Map:
+    def to_ffi(self, mesh_ids: Dict[str, int], light_tex=(-1, -1)) -> _ffi.Map:
         m = _ffi.Map()
         m.grid_w, m.grid_h, m.tile_size = self.grid_w, self.grid_h, float(self.tile_size)
 
@@ -180,6 +183,10 @@ class MapTables:
             f.safety_radius, f.spawn_clear = float(o.safety_radius), float(o.spawn_clear)
             f.walk_distance, f.vel, f.wait_time, f.wiggle = (float(o.walk_distance), float(o.vel),
                                                             float(o.wait_time), float(o.wiggle))
+            lit = o.light_freq > 0 and light_tex[0] >= 0 and light_tex[1] >= 0 and f.mesh_id >= 0
+            f.light_freq, f.light_pattern = int(o.light_freq), int(o.light_pattern)
+            f.light_tex[0], f.light_tex[1] = (int(light_tex[0]), int(light_tex[1])) if lit else (-1, -1)
+            f.light_tris = int(o.light_tris) if lit else 0
         self._keep.append(arr)
         m.n_objects = len(self.objects)
         m.objects = C.cast(arr, C.POINTER(_ffi.Object))
@@ -283,6 +290,9 @@ def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, 
             optional=desc.get("optional", False), collidable=bool(static and kind != "trafficlight"),
             corners=corners, norm=vect.T, safety_radius=float(SAFETY_RAD_MULT * (np.linalg.norm([ex, ez]) * scale)),
             spawn_clear=float(max(mx) * 0.5 * scale + MIN_SPAWN_OBJ_DIST), min_coords=mn, max_coords=mx)
+        if static and kind == "trafficlight":      # TrafficLightObj, non-DR values (objects.py:446-451)
+            o.light_freq, o.light_pattern = 5, 0
+            o.light_tris = int(getattr(mesh, "chunk_sizes", [0])[0]) if getattr(mesh, "texture_files", None) is not None else 0
         if not static:
             if kind == "duckie":
                 o.dyn_kind = 1

@@ -31,7 +31,7 @@ class MeshData:
     per-vertex Kd colours, [T,3,2] texture coordinates, a per-triangle index into
     `texture_files` (-1 = untextured), and min_coords / max_coords (objmesh.py:230-232)."""
 
-    def __init__(self, verts, normals, colors, uvs=None, tri_tex=None, texture_files=None, name="mesh"):
+    def __init__(self, verts, normals, colors, uvs=None, tri_tex=None, texture_files=None, name="mesh", chunk_sizes=None):
         self.name = name
         self.verts = np.ascontiguousarray(verts, dtype=np.float32)
         self.normals = np.ascontiguousarray(normals, dtype=np.float32)
@@ -41,6 +41,7 @@ class MeshData:
         self.tri_tex = np.full(T, -1, np.int32) if tri_tex is None else np.ascontiguousarray(tri_tex, dtype=np.int32)
         self.texture_files: List[str] = list(texture_files or [])
         self.textures: List[np.ndarray] = []          # RGBA8, GL row order; filled by the asset library
+        self.chunk_sizes: List[int] = list(chunk_sizes) if chunk_sizes is not None else [T]   # triangles per material chunk, draw order
         self.min_coords = self.verts.min(axis=0).min(axis=0)
         self.max_coords = self.verts.max(axis=0).max(axis=0)
 
@@ -158,4 +159,9 @@ def load_obj(obj_path: str, resolve: Optional[Callable[[str], Optional[str]]] = 
     V[:, :, 1] -= lo[1]
     V[:, :, 0] -= mid[0]
     V[:, :, 2] -= mid[2]
-    return MeshData(V, N, Cc, T, tri_tex, tex_files, name=name or os.path.basename(obj_path).split(".")[0])
+    sizes, prev = [], None
+    for _corners, mname in faces:                 # chunks = runs of equal material name (objmesh.py:163-173)
+        if mname != prev:
+            sizes.append(0); prev = mname
+        sizes[-1] += 1
+    return MeshData(V, N, Cc, T, tri_tex, tex_files, name=name or os.path.basename(obj_path).split(".")[0], chunk_sizes=sizes)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 2
+#define DTSIM_ABI_VERSION 3
 
 /* error codes */
 #define DTSIM_OK 0
@@ -124,6 +124,12 @@ typedef struct dtsim_object {
    * four slots carry follow_dist, velocity, gain, trim (objects.py:199-216); its radius / k / limit /
    * wheel_dist / robot_width / robot_length are the reference defaults. */
   double walk_distance, vel, wait_time, wiggle;
+  /* TrafficLightObj (objects.py:434-477): every `light_freq` seconds of object time the first material
+   * chunk of the mesh (its first `light_tris` triangles) switches between textures light_tex[0] and
+   * light_tex[1]; light_pattern is the initial pattern.  light_freq = 0: not a traffic light. */
+  int32_t light_freq, light_pattern;
+  int32_t light_tex[2];
+  int32_t light_tris, light_pad;
 } dtsim_object;
 
 typedef struct dtsim_map {
@@ -222,7 +228,8 @@ enum {
   DTSIM_FIELD_OBJ_VISIBLE = 18,/* uint8 [N][DTSIM_MAX_OBJECTS] obj.visible (simulator.py:653-656) */
   DTSIM_FIELD_EPISODE = 19,   /* int32  [N] episodes started (auto-reset counter) */
   DTSIM_FIELD_STATE_BLOB = 20,/* opaque: full SoA state, dtsim_state_bytes() bytes (checkpoint) */
-  DTSIM_FIELD__COUNT = 21
+  DTSIM_FIELD_OBJ_LIGHT = 21, /* uint8  [N][DTSIM_MAX_OBJECTS] TrafficLightObj.pattern (0 for other objects) */
+  DTSIM_FIELD__COUNT = 22
 };
 
 /* kernels for dtsim_profile_read */

@@ -188,6 +188,18 @@ def main():
         dout[f"sx_{w}x{h}"] = np.rint(rx.astype(np.float64)).astype(np.int16)
         dout[f"sy_{w}x{h}"] = np.rint(ry.astype(np.float64)).astype(np.int16)
     np.savez_compressed(os.path.join(OUT, "ref_distortion.npz"), **dout)
+    # TrafficLightObj.step (objects.py:455-463, the reference's own code on a bare instance): pattern per step
+    import types
+    tl = {}
+    for tag, dt in (("30hz", 1 / 30), ("20hz", 1 / 20), ("frame_skip_dt", 1 / 30 / 3)):
+        o = types.SimpleNamespace(time=0, freq=5, pattern=0, texs=[0, 1], mesh=types.SimpleNamespace(textures=[0]))
+        pat = np.zeros(1300, np.uint8)
+        for t in range(1300):
+            ns.objects.TrafficLightObj.step(o, dt)
+            pat[t] = o.pattern
+        tl[tag] = pat
+    np.savez_compressed(os.path.join(OUT, "ref_trafficlight.npz"), **tl)
+
     # ObjMesh parser (objmesh.py:55-358, the reference's own code) on the procedural asset tree of
     # tests/golden/make_assets.py: triangle soup in draw order, extents, per-chunk textures
     lib = assets.AssetLibrary(os.path.join(OUT, "assets"))

@@ -241,6 +241,12 @@ def _object_instances(scene, obj_states):
         texs = getattr(mesh, "textures", None) or []
         tri_tex = np.asarray(getattr(mesh, "tri_tex", np.full(T, -1)))
         tri_img = [texs[t] if (t >= 0 and t < len(texs)) else None for t in tri_tex]
+        cards = getattr(scene, "light_cards", None)
+        if getattr(o, "light_freq", 0) > 0 and cards is not None:
+            # TrafficLightObj: mesh.textures[0] (the first material chunk) is the card of the current pattern
+            pat = int(st["light_pattern"]) if (st is not None and "light_pattern" in st) else int(o.light_pattern)
+            n0 = int(getattr(mesh, "chunk_sizes", [0])[0])
+            tri_img = [cards[pat] if t < n0 else im for t, im in enumerate(tri_img)]
         out.append((Vw, Nw, mesh.colors.astype(np.float64), uvs, tri_img))
     return out
 

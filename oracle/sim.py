@@ -290,6 +290,9 @@ class OracleObj:
     velocity: float = 0.1
     gain: float = 2.0
     trim: float = 0.0
+    # TrafficLightObj (objects.py:434-463, non-DR branch): freq 5 s, pattern 0
+    light_freq: int = 0
+    light_pattern: int = 0
     radius: float = 0.0318
     wheel_dist: float = WHEEL_DIST
     robot_width: float = ROBOT_WIDTH
@@ -350,6 +353,11 @@ class OracleObj:
 
     # objects.py:384-431
     def step(self, delta_time):
+        if self.kind == "trafficlight":               # objects.py:455-463
+            self.time += delta_time
+            if round(self.time, 3) % self.light_freq == 0:
+                self.light_pattern ^= 1
+            return
         if self.static or self.kind == "duckiebot":
             return
         self.time += delta_time
@@ -462,6 +470,8 @@ class OracleMap:
                 safety_radius=SAFETY_RAD_MULT * calculate_safety_radius(mn, mx, scale),
                 obj_corners=oc, obj_norm=generate_norm(oc), y_rot=float(np.rad2deg(angle)),
             )
+            if static and kind == "trafficlight":
+                o.light_freq, o.light_pattern = 5, 0  # objects.py:446-451
             if not static and kind == "duckiebot":
                 pass                  # DuckiebotObj(obj_desc, ..., WHEEL_DIST, ROBOT_WIDTH, ROBOT_LENGTH) simulator.py:1005-1008
             elif not static:

@@ -170,6 +170,30 @@ def tree(d):
     write_mtl(os.path.join(d, "tree.mtl"), {"trunk": {"Kd": (0.35, 0.22, 0.1)}, "crown": {"Kd": (0.1, 0.45, 0.15)}})
 
 
+def trafficlight(d):
+    o = Obj()
+    o.usemtl("pole")
+    o.box((-0.015, 0.0, -0.015), (0.015, 0.36, 0.015))
+    o.box((-0.05, 0.36, -0.05), (0.05, 0.50, 0.05))
+    o.usemtl("card")                                   # sorts first: mesh.textures[0] is the LED card
+    s_ = 0.0505
+    o.quad([(-0.04, 0.37, s_), (0.04, 0.37, s_), (0.04, 0.49, s_), (-0.04, 0.49, s_)], (0, 0, 1), [(0, 0), (1, 0), (1, 1), (0, 1)])
+    o.quad([(s_, 0.37, 0.04), (s_, 0.37, -0.04), (s_, 0.49, -0.04), (s_, 0.49, 0.04)], (1, 0, 0), [(0, 0), (1, 0), (1, 1), (0, 1)])
+    o.quad([(0.04, 0.37, -s_), (-0.04, 0.37, -s_), (-0.04, 0.49, -s_), (0.04, 0.49, -s_)], (0, 0, -1), [(0, 0), (1, 0), (1, 1), (0, 1)])
+    o.quad([(-s_, 0.37, -0.04), (-s_, 0.37, 0.04), (-s_, 0.49, 0.04), (-s_, 0.49, -0.04)], (-1, 0, 0), [(0, 0), (1, 0), (1, 1), (0, 1)])
+    o.write(os.path.join(d, "trafficlight.obj"), "trafficlight.mtl")
+    write_mtl(os.path.join(d, "trafficlight.mtl"), {"pole": {"Kd": (0.2, 0.2, 0.22)},
+                                                   "card": {"Kd": (1.0, 1.0, 1.0), "map_Kd": "trafficlight_card0.jpg"}})
+    from PIL import Image
+    for k, (top, bot) in enumerate([((230, 30, 30), (40, 60, 40)), ((60, 40, 40), (40, 220, 60))]):
+        img = np.zeros((64, 64, 3), np.uint8)
+        img[:] = (25, 25, 28)
+        v, u = np.meshgrid(np.arange(64), np.arange(64), indexing="ij")
+        img[(u - 32) ** 2 + (v - 18) ** 2 < 120] = top
+        img[(u - 32) ** 2 + (v - 46) ** 2 < 120] = bot
+        Image.fromarray(img).save(os.path.join(d, f"trafficlight_card{k}.jpg"), quality=95)
+
+
 MAP = """# test map for real-asset ingestion (MapFormat1)
 tiles:
 - [grass, asphalt, floor, grass, grass]
@@ -183,6 +207,7 @@ objects:
 - {kind: duckiebot, pos: [3.5, 1.3], rotate: 180, height: 0.12, static: true, color: blue}
 - {kind: duckie, pos: [0.8, 2.5], rotate: 45, height: 0.06}
 - {kind: cone, pos: [4.2, 2.5], rotate: 0, scale: 0.2}
+- {kind: trafficlight, pos: [2.1, 3.2], rotate: 45, height: 0.3}
 tile_size: 0.585
 """
 
@@ -191,7 +216,7 @@ def main():
     from dtsim import assets
     meshes = os.path.join(OUT, "meshes")
     os.makedirs(meshes, exist_ok=True)
-    cone(meshes); sign_generic(meshes); duckiebot(meshes); tree(meshes)
+    cone(meshes); sign_generic(meshes); duckiebot(meshes); tree(meshes); trafficlight(meshes)
     for kind in ("grass", "asphalt", "floor", "straight", "curve_left", "curve_right", "3way_left", "4way"):
         tex = assets.make_texture(kind, 128)[..., :3]
         save_png(os.path.join(OUT, "textures", "tiles-processed", "photos", kind, "texture.png"), tex)

@@ -81,11 +81,14 @@ def test_map_yaml_to_tables():
     md = lib.map_data("test_town")
     meshes = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
     mt = maps.interpret_map(md, "test_town", meshes, library=lib)
-    assert (mt.grid_w, mt.grid_h) == (5, 4) and len(mt.objects) == 6
-    assert [o.mesh_kind for o in mt.objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone"]
+    assert (mt.grid_w, mt.grid_h) == (5, 4) and len(mt.objects) == 7
+    assert [o.mesh_kind for o in mt.objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone", "trafficlight"]
+    tl = mt.objects[6]
+    assert (tl.light_freq, tl.light_pattern, tl.light_tris) == (5, 0, 8) and not tl.collidable     # objects.py:446-451, simulator.py:1027
     cone = lib.mesh("cone")
     assert np.isclose(mt.objects[0].scale, 0.1 / float(cone.max_coords[1])) and mt.objects[5].scale == 0.2
     assert mt.objects[2].optional and all(o.static for o in mt.objects)
+    assert [c.shape for c in lib.light_cards()] == [(64, 64, 4)] * 2 and assets.AssetLibrary(None).light_cards() is None
     # the same YAML through a file path
     md2 = assets.get_map(os.path.join(ASSETS, "maps", "test_town.yaml"))
     assert md2 == md

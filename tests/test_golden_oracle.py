@@ -130,3 +130,18 @@ def test_dynamics_model_anchors():
         assert (d.x, d.y, d.u) == (1.0, 2.0, 0.0)
     d.integrate(1 / 30, 1.0, 1.0)
     assert d.u > 0
+
+
+def test_trafficlight_step_matches_reference_golden():
+    """TrafficLightObj.step (objects.py:455-463): pattern switches when round(time, 3) is a multiple of freq."""
+    from oracle import sim as osim
+    g = np.load(os.path.join(G, "ref_trafficlight.npz"))
+    for tag, dt in (("30hz", 1 / 30), ("20hz", 1 / 20), ("frame_skip_dt", 1 / 30 / 3)):
+        o = osim.OracleObj(kind="trafficlight", pos=np.zeros(3), angle=0.0, scale=1.0, static=True, optional=False,
+                           min_coords=np.zeros(3), max_coords=np.ones(3), safety_radius=0.0,
+                           obj_corners=np.zeros((4, 2)), obj_norm=np.eye(2), light_freq=5, light_pattern=0)
+        pat = np.zeros(1300, np.uint8)
+        for t in range(1300):
+            o.step(dt)
+            pat[t] = o.light_pattern
+        assert np.array_equal(pat, g[tag]), tag

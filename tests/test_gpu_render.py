@@ -138,11 +138,14 @@ def _asset_scene():
     ext = {k: (m.min_coords, m.max_coords) for k, m in meshes.items()}
     om = osim.OracleMap(md, ext)
     kinds = {t["kind"] for t in om.grid if t is not None}
-    return raster.Scene(om, {k: lib.tile_texture(k) for k in kinds}, meshes), md, ext
+    scene = raster.Scene(om, {k: lib.tile_texture(k) for k in kinds}, meshes)
+    scene.light_cards = lib.light_cards()              # TrafficLightObj.texs (objects.py:438-441)
+    return scene, md, ext
 
 
-@pytest.mark.parametrize("W,H,distortion,dr", [(320, 240, False, False), (640, 480, True, False), (320, 240, False, True)])
-def test_real_assets_match_oracle(W, H, distortion, dr):
+@pytest.mark.parametrize("W,H,distortion,dr,steps", [(320, 240, False, False, 0), (640, 480, True, False, 0), (320, 240, False, True, 0),
+                                                     (320, 240, False, False, 151)])   # 151 steps: the traffic light has switched
+def test_real_assets_match_oracle(W, H, distortion, dr, steps):
     """MapFormat1 YAML + tile texture files + OBJ/MTL meshes (multi-material, textured
     chunks: GL_MODULATE of the material texture with the lit vertex colour, sign / duckiebot material
     overrides) loaded from an asset tree, rendered by the HIP raster and by the oracle."""
@@ -150,7 +153,7 @@ def test_real_assets_match_oracle(W, H, distortion, dr):
     N = 8
     sim = BatchedSimulator("test_town", N, asset_root=ASSETS, camera_width=W, camera_height=H, distortion=distortion,
                            domain_rand=dr, seed=5, max_steps=100000)
-    assert [o.mesh_kind for o in sim.maps[0].objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone"]
+    assert [o.mesh_kind for o in sim.maps[0].objects] == ["cone", "sign_stop", "tree", "duckiebot:blue", "duckie", "cone", "trafficlight"]
     # look at the objects: place the agents around them, facing them
     objs = sim.maps[0].objects
     for e in range(N):
@@ -159,6 +162,10 @@ def test_real_assets_match_oracle(W, H, distortion, dr):
         sim.init_states[e].pos[:] = [float(o.pos[0] - 0.45 * np.cos(a)), 0.0, float(o.pos[2] + 0.45 * np.sin(a))]
         sim.init_states[e].angle = float(a)
     sim.reset(states=sim.init_states)
+    if steps:
+        sim.step(np.zeros((steps, N, 2), np.float32), n_steps=steps)       # the agents stay put, the object clocks run
+    light = sim.read(_ffi.FIELD_OBJ_LIGHT)
+    assert (light[:, 6] == (1 if steps >= 150 else 0)).all() and (light[:, :6] == 0).all()
     sim.render()
     frames = sim.frames_host()
     rmap = pdist.distortion_maps(W, H) if distortion else None
@@ -166,6 +173,8 @@ def test_real_assets_match_oracle(W, H, distortion, dr):
     for e in range(N):
         cam = _camera(sim, e, W, H, dr)
         st = _obj_states(sim, e, scene)
+        for k_, s_ in enumerate(st):
+            s_["light_pattern"] = int(light[e, k_])
         ref_px = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
         no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
         n_obj_px += int((np.abs(ref_px.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
@@ -173,6 +182,30 @@ def test_real_assets_match_oracle(W, H, distortion, dr):
         assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, s)
     assert n_obj_px > 2000, n_obj_px
     sim.close()
+
+
+def test_traffic_light_pattern_follows_the_reference_clock():
+    """TrafficLightObj.step on the device vs the pattern sequence recorded from the reference's own code
+    (tests/golden/ref_trafficlight.npz), including frame_skip sub-steps; the clock survives env resets."""
+    g = np.load(os.path.join(os.path.dirname(ASSETS), "ref_trafficlight.npz"))
+    for tag, kw in (("30hz", dict()), ("20hz", dict(frame_rate=20)), ("frame_skip_dt", dict(frame_skip=3))):
+        sim = BatchedSimulator("test_town", 3, asset_root=ASSETS, render=False, domain_rand=False, seed=1, max_steps=10**6, **kw)
+        ref = g[tag]
+        per = 3 if tag == "frame_skip_dt" else 1
+        pats = []
+        T = 420
+        for t in range(T):
+            sim.step(np.zeros((1, 3, 2), np.float32))
+            pats.append(sim.read(_ffi.FIELD_OBJ_LIGHT)[0, 6])
+            if t == 200:
+                sim.reset()                            # objects persist across resets (simulator.py:349,865)
+        pats = np.array(pats)
+        if tag == "frame_skip_dt":
+            want = np.array([g["30hz"][per * (t + 1) - 1] for t in range(T)])     # 3 object steps of 1/30 s per env step
+        else:
+            want = ref[:T]
+        assert np.array_equal(pats, want), tag
+        sim.close()
 
 
 def test_render_is_deterministic_and_per_env():
