@@ -281,3 +281,55 @@ def test_error_paths():
     with pytest.raises(_ffi.DtsimError):
         sim.render()
     sim.close()
+
+
+def test_large_map_with_many_objects_matches_oracle():
+    """Maximum-size style inputs: a 30x30 grid (900 tiles, mixed kinds incl. 3way / 4way / empty cells) with 56 static
+    and 8 walking duckies -- the per-map limits of include/dtsim.h -- against the oracle's geometry."""
+    from dtsim import assets
+    G = "grass"
+    W = H = 30
+    tiles = [[G] * W for _ in range(H)]
+    for k in range(2, 28):
+        tiles[2][k] = "straight/E"; tiles[27][k] = "straight/E"; tiles[k][2] = "straight/S"; tiles[k][27] = "straight/S"
+    tiles[2][2], tiles[2][27], tiles[27][27], tiles[27][2] = "curve_left/W", "curve_left/N", "curve_left/E", "curve_left/S"
+    for k in range(3, 27):
+        tiles[14][k] = "straight/E"
+    tiles[14][2], tiles[14][27] = "3way_left/S", "3way_left/N"
+    tiles[14][14] = "4way"
+    for k in range(3, 14):
+        tiles[k][14] = "straight/S"
+    tiles[2][14] = "3way_left/W"
+    tiles[20][20] = "empty"
+    rng = np.random.default_rng(2)
+    objs = [dict(kind="duckie", pos=[float(rng.uniform(1, 29)), float(rng.uniform(1, 29))], rotate=float(rng.uniform(0, 360)),
+                 height=0.06, static=True) for _ in range(56)]
+    objs += [dict(kind="duckie", pos=[float(3 + 3 * k), 14.4], rotate=90.0, height=0.06, static=False) for k in range(8)]
+    md = dict(tiles=tiles, objects=objs, tile_size=0.585)
+    sim = BatchedSimulator("big", 2, map_data=md, render=False, domain_rand=False, seed=3, do_reset=False)
+    o = osim.OracleSim(md, EXT, do_reset=False)
+    m = o.map
+    poses = random_poses(rng, m.grid_width, m.grid_height, m.tile_size, 3000,
+                         np.array([[ob.pos[0], ob.pos[2]] for ob in m.objects]))
+    st = (_ffi.InitState * 2)()
+    for e in range(2):
+        st[e].pos[:] = [2.5 * 0.585, 0.0, 2.5 * 0.585]; st[e].angle = 0.0; st[e].wheel_dist = 0.102
+        st[e].cam_height, st[e].cam_angle_deg, st[e].cam_fov_y_deg = 0.108, 19.15, 75.0
+    sim.reset(states=st)
+    pr = sim.query(np.zeros(len(poses), np.int32), poses, safety_factor=1.0)
+    n_coll = 0
+    for q, (x, z, a) in enumerate(poses):
+        pos = np.array([x, 0, z])
+        assert (pr["tile_i"][q], pr["tile_j"][q]) == tuple(m.get_grid_coords(pos))
+        assert bool(pr["drivable"][q]) == o._drivable_pos(pos)
+        assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
+        assert bool(pr["valid"][q]) == o._valid_pose(pos, a, 1.0)
+        assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
+        try:
+            lp = o.get_lane_pos2(pos, a)
+            assert pr["in_lane"][q] == 1 and abs(pr["dist"][q] - lp[0]) <= FLOAT_TOL
+        except osim.NotInLane:
+            assert pr["in_lane"][q] == 0
+        n_coll += int(pr["collision"][q])
+    assert n_coll > 10
+    sim.close()

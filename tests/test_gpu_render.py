@@ -217,3 +217,21 @@ def test_render_is_deterministic_and_per_env():
     assert np.array_equal(a, sim.frames_host())
     assert len({a[e].tobytes() for e in range(N)}) == N        # every env has its own pose => frame
     sim.close()
+
+
+def test_odd_frame_sizes_match_oracle():
+    """Widths that are not a multiple of 4 take the byte-store path; partial 64x16 tiles on both axes."""
+    for (W, H, N) in ((90, 62, 3), (66, 17, 2)):
+        sim = BatchedSimulator("small_loop_only_duckies", N, camera_width=W, camera_height=H, distortion=False,
+                               domain_rand=False, seed=4)
+        sim.step(np.full((3, N, 2), 0.5, np.float32), n_steps=3)
+        sim.render()
+        frames = sim.frames_host()
+        assert frames.shape == (N, H, W, 3)
+        scene = _scene("small_loop_only_duckies")
+        for e in range(N):
+            cam = _camera(sim, e, W, H, False)
+            ref_px = raster.render_obs(cam, scene, "pixel", None, obj_states=_obj_states(sim, e, scene))
+            s = _stats(frames[e], ref_px)
+            assert s["frac_gt1"] <= 4e-3 and s["mean"] <= 0.05, (W, H, e, s)     # tiny frames: every silhouette pixel counts
+        sim.close()
