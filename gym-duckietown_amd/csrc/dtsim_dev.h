@@ -155,10 +155,13 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 
 // raster work decomposition: a workgroup owns a DT_TILE_W x DT_TILE_H pixel tile for 32 consecutive envs
 #ifndef DT_WAVE_W
-#define DT_WAVE_W 64                       // pixel columns of a wavefront's 256-pixel block (256x1 ... 32x8)
+#define DT_WAVE_W 64                       // pixel columns of a wavefront's block
+#endif
+#ifndef DT_PPT
+#define DT_PPT 4                           // pixels per lane: a wavefront's block is 64 * DT_PPT pixels
 #endif
 #define DT_TILE_W DT_WAVE_W
-#define DT_TILE_H (4 * (256 / DT_WAVE_W))  // 4 wavefronts stacked vertically
+#define DT_TILE_H (4 * (64 * DT_PPT / DT_WAVE_W))  // 4 wavefronts stacked vertically
 #define DT_ITEM_B 8                          // 64-entry edge batches per k_resolve work item
 #define DT_ITEMS_PER_WG (4 * 128 / DT_ITEM_B) // worst case: 4 regions x (256 px x 32 envs / 64) batches
 static inline size_t dt_raster_tiles(int W, int H) {

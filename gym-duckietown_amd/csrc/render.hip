@@ -37,7 +37,7 @@
 #include "dtsim_dev.h"
 
 #define RB 256            // threads per workgroup (4 wavefronts)
-#define PPT 4             // pixels per thread
+#define PPT DT_PPT         // pixels per thread
 #define WAVE_W DT_WAVE_W  // pixel columns per wavefront block (dtsim_dev.h)
 // pixel slot k of lane l is pixel number k*64 + l of the block, row-major: adjacent lanes = adjacent pixels
 #define SLOT_X(k, l) (((k) * 64 + (l)) % WAVE_W)
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   uint32_t* s_px = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4) + wave * WAVE_PIX;
   const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
   const bool aligned_rows = (R.W & 3) == 0;
-  const bool st_ok = aligned_rows && st_x < R.W && st_y < R.H;
+  const bool st_ok = aligned_rows && lane * 4 < WAVE_PIX && st_x < R.W && st_y < R.H;
   const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
   const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
 
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     if (aligned_rows) {
 #pragma unroll
       for (int k = 0; k < PPT; ++k) s_px[k * 64 + lane] = px[k];
-      const uint4 q = *reinterpret_cast<const uint4*>(s_px + lane * 4);   // same wavefront: DS ops are ordered
+      const uint4 q = *reinterpret_cast<const uint4*>(s_px + (lane * 4) % WAVE_PIX);   // same wavefront: DS ops are ordered
       if (st_ok) {
         uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)e * npix * 3 + st_off);   // 12-byte aligned
         d32[0] = q.x | (q.y << 24);
@@ -925,7 +925,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
     // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
     // register budget): append them to this wavefront's queue region.
-    if (!R.no_msaa && __ballot(edge[0] | edge[1] | edge[2] | edge[3])) {    // wave-uniform
+    bool any_edge = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) any_edge |= edge[k];
+    if (!R.no_msaa && __ballot(any_edge)) {    // wave-uniform
       const uint32_t etag = (uint32_t)(e - e0) << 8;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {                // per pixel slot: ballot -> rank -> masked store
