@@ -576,6 +576,19 @@ int dtsim_set_reset_sampler(dtsim_t* h, const dtsim_reset_sampler* sampler) {
   return DTSIM_OK;
 }
 
+int dtsim_reset_done(dtsim_t* h) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (!h->have_reset) return fail(DTSIM_E_STATE, "dtsim_reset_done before the first dtsim_reset");
+  if (!h->d_sampler) return fail(DTSIM_E_STATE, "dtsim_reset_done needs dtsim_set_reset_sampler");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  {
+    ProfScope ps(h, DTSIM_KERNEL_RESET);
+    dt_launch_reset(h->stream, h->A, h->M, step_params(h, 0), h->A.done, nullptr);   // mask = the done flags, on the device
+  }
+  HIPCHK(hipGetLastError());
+  return DTSIM_OK;
+}
+
 int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states) {
   if (!h) return fail(DTSIM_E_INVALID, "null argument");
   if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_reset before dtsim_set_maps");

@@ -7,5 +7,6 @@ fallback).
 from . import _ffi, assets, maps  # noqa: F401
 from ._ffi import DtsimError, DtsimLibraryError  # noqa: F401
 from .batched import BatchedSimulator  # noqa: F401
+from .vecenv import DuckietownVecEnv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -37,7 +37,7 @@ EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -164,6 +164,7 @@ def load(path: str | None = None):
         "dtsim_frames_bytes": (sz, [vp]),
         "dtsim_bind_frames": (ci, [vp, vp]),
         "dtsim_set_reset_sampler": (ci, [vp, C.POINTER(ResetSampler)]),
+        "dtsim_reset_done": (ci, [vp]),
         "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),
         "dtsim_query": (ci, [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double, C.POINTER(Probe)]),
         "dtsim_read": (ci, [vp, ci, vp, sz]),

@@ -308,6 +308,21 @@ class BatchedSimulator:
             m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
         self._reset_device(m)
 
+    def reset_done(self):
+        """Restart (device sampler) every env whose done flag is set; asynchronous, no host round trip."""
+        _ffi.check(self._lib, self._lib.dtsim_reset_done(self._h))
+
+    def field_device(self, field: int) -> DeviceArray:
+        """Zero-copy device view of one SoA field ([N, ...] as documented in include/dtsim.h)."""
+        dt, shp = self._FIELD_SHAPES[field]
+        if shp != ():
+            raise ValueError("device views are offered for the scalar per-env fields (the state is SoA: [component][N])")
+        ptr = self._lib.dtsim_field_devptr(self._h, field)
+        if not ptr:
+            raise ValueError(f"field {field} has no contiguous device view")
+        ts = {"f8": "<f8", "u1": "|u1", "i4": "<i4"}[dt]
+        return DeviceArray(ptr, (self.num_envs,), ts, self)
+
     def make_spawn_pool(self, n_pool: int):
         """Pre-sample `n_pool` spawn states (env e%N's RNG stream) for DTSIM_F_AUTO_RESET."""
         pool = (_ffi.InitState * n_pool)()

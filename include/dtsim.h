@@ -276,6 +276,10 @@ typedef struct dtsim_reset_sampler {
   int32_t start_tile[DTSIM_MAX_MAPS][2];  /* user_tile_start / the map's start_tile; -1 = a random drivable tile */
 } dtsim_reset_sampler;
 int dtsim_set_reset_sampler(dtsim_t* h, const dtsim_reset_sampler* sampler);   /* NULL uninstalls */
+/* Reset, with the installed sampler, every env whose done flag is set (the mask is read on the device: no
+ * host round trip).  What a vectorised learner loop does right after a step: read reward / done, then
+ * restart the finished episodes so that the observation it gets is the new episode's first one. */
+int dtsim_reset_done(dtsim_t* h);
 
 /* Pool of spawn states used by DTSIM_F_AUTO_RESET: env e starts episode k from
  * pool[(e + k * num_envs) % n_pool]. */
