@@ -101,3 +101,61 @@ def test_non_power_of_two_textures_are_resampled():
     assert r.shape == (128, 64, 4)
     assert assets.to_pow2(r) is not None and assets.to_pow2(r).shape == r.shape
     assert assets.to_pow2(t, 256).shape == (256, 256, 4)
+
+
+def test_obj_parser_fuzz_against_reference(tmp_path):
+    """Random OBJ/MTL files (random material order, v/t/n and v//n faces, missing / unknown materials, an
+    optional <stem>.png default texture) through both parsers: bit-identical arrays, extents and per-chunk
+    textures.  Needs the reference tree (build container only)."""
+    from oracle import refstub
+    if not refstub.available():
+        pytest.skip("reference tree not present")
+    from PIL import Image
+    rng = np.random.default_rng(123)
+    for case in range(12):
+        d = tmp_path / f"c{case}"
+        d.mkdir()
+        stem = f"mesh{case}"
+        mats = [f"m{k}_{rng.integers(0, 99)}" for k in range(int(rng.integers(0, 4)))]
+        with open(d / f"{stem}.mtl", "w") as f:
+            for m in mats:
+                f.write(f"newmtl {m}\nKd {rng.random():.4f} {rng.random():.4f} {rng.random():.4f}\n")
+                if rng.random() < 0.5:
+                    Image.fromarray(rng.integers(0, 255, (8, 8, 3), dtype=np.uint8)).save(d / f"{m}.png")
+                    f.write(f"map_Kd  {m}.png\n")
+        if case % 3 == 0:
+            os.remove(d / f"{stem}.mtl")                       # no material library at all
+        if case % 4 == 1:
+            Image.fromarray(rng.integers(0, 255, (8, 8, 3), dtype=np.uint8)).save(d / f"{stem}.png")   # default-material texture
+        nv, nt, nn = int(rng.integers(4, 12)), int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        with open(d / f"{stem}.obj", "w") as f:
+            f.write("# fuzz\n\no thing\n")
+            for _ in range(nv):
+                f.write("v  %.5f %.5f  %.5f\n" % tuple(rng.uniform(-2, 3, 3)))
+            for _ in range(nt):
+                f.write("vt %.5f %.5f\n" % tuple(rng.uniform(0, 1, 2)))
+            for _ in range(nn):
+                f.write("vn %.5f %.5f %.5f\n" % tuple(rng.uniform(-1, 1, 3)))
+            for _ in range(int(rng.integers(2, 14))):
+                if rng.random() < 0.4:
+                    f.write(f"usemtl {rng.choice(mats + ['nosuchmtl']) if mats else 'nosuchmtl'}\n")
+                with_t = rng.random() < 0.6
+                toks = []
+                for _ in range(3):
+                    v, t, n = int(rng.integers(1, nv + 1)), int(rng.integers(1, nt + 1)), int(rng.integers(1, nn + 1))
+                    toks.append(f"{v}/{t}/{n}" if with_t else f"{v}//{n}")
+                f.write("f " + " ".join(toks) + " \n")
+
+        def resolve(bn, _d=d):
+            p = os.path.join(_d, bn)
+            return p if os.path.isfile(p) else None
+
+        p = str(d / f"{stem}.obj")
+        r = refstub.ref_objmesh(p, stem, resolve, None)
+        m = objmesh.load_obj(p, resolve)
+        for k, mine in (("verts", m.verts), ("uvs", m.uvs), ("normals", m.normals), ("colors", m.colors),
+                        ("min_coords", m.min_coords), ("max_coords", m.max_coords)):
+            assert np.array_equal(r[k], mine), (case, k)
+        assert list(r["chunk_sizes"]) == m.chunk_sizes, case
+        want = ["" if t is None else os.path.basename(t) for t in r["textures"]]
+        assert _chunk_textures(m, r["chunk_sizes"]) == want, case
