@@ -148,11 +148,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # Test hook for 1-GPU boxes: DTSIM_BENCH_ONE_GPU=1 puts every rank on device 0 and uses gloo for the
+    # (control-plane only) collectives, so the multi-rank code path can be exercised without 2 GPUs.
+    one_gpu = os.environ.get("DTSIM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.no_gather = True
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     N, K, Wm = args.envs, args.steps, args.warmup
     variant = {
@@ -202,7 +211,7 @@ def main():
     t_local = time.perf_counter() - t0
     n_r, ms_r = sim.profile_read(_ffi.KERNEL_RENDER)
     n_s, ms_s = sim.profile_read(_ffi.KERNEL_STEP)
-    tt = torch.tensor([t_local], device=dev, dtype=torch.float64)
+    tt = torch.tensor([t_local], device="cpu" if one_gpu else dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.barrier()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
