@@ -24,6 +24,57 @@ __device__ inline uint32_t clip8(int32_t acc) {
   return (uint32_t)min(max(v, 0), 255);
 }
 
+// ---- vertical pass + layout / normalisation.  PER = 4 consecutive intermediate bytes per thread when the
+// rows are dword-sized (compile-time, so the accumulators stay in registers), else 1.
+template <int PER>
+__device__ inline void observe_vertical_t(const ObserveParams& P, const uint8_t* s_tmp, int e, int oy0, int oy1, int y_first, int tid) {
+  const int tmp_row_bytes = P.ow * 3, per_row = tmp_row_bytes / PER;
+  const int n_out = (oy1 - oy0) * per_row;
+  for (int i = tid; i < n_out; i += OB) {
+    const int oy = oy0 + i / per_row, j0 = (i % per_row) * PER;
+    uint32_t v[PER];
+    if (P.oh == P.H) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) v[q] = s_tmp[(size_t)(oy - y_first) * tmp_row_bytes + j0 + q];
+    } else {
+      const int y0 = P.by[2 * oy], n = P.by[2 * oy + 1];
+      const int32_t* k = P.kky + oy * P.ky;
+      const uint8_t* p = s_tmp + (size_t)(y0 - y_first) * tmp_row_bytes + j0;
+      int32_t a[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) a[q] = 1 << (PREC - 1);
+      for (int t = 0; t < n; ++t) {
+        const uint32_t kt = (uint32_t)k[t];
+        if (PER == 4) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)t * tmp_row_bytes);
+#pragma unroll
+          for (int q = 0; q < PER; ++q) a[q] += (int32_t)__umul24((w >> (8 * q)) & 255u, kt);
+        } else {
+          a[0] += (int32_t)__umul24((uint32_t)p[(size_t)t * tmp_row_bytes], kt);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) v[q] = clip8(a[q]);
+    }
+    if (PER == 4 && !P.chw && !P.f32) {                // HWC uint8: one dword store
+      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.out) + ((size_t)e * P.oh + oy) * tmp_row_bytes + j0) =
+          v[0] | (v[1 % PER] << 8) | (v[2 % PER] << 16) | (v[3 % PER] << 24);
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = j0 + q, ox = j / 3, c = j % 3;
+      const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : ((size_t)e * P.oh + oy) * tmp_row_bytes + j;
+      if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v[q] / 255.0f;     // NormalizeWrapper: (obs - 0) / (255 - 0)
+      else reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v[q];
+    }
+  }
+}
+__device__ inline void observe_vertical(const ObserveParams& P, const uint8_t* s_tmp, int e, int oy0, int oy1, int y_first, int tid) {
+  if (((P.ow * 3) & 3) == 0) observe_vertical_t<4>(P, s_tmp, e, oy0, oy1, y_first, tid);
+  else observe_vertical_t<1>(P, s_tmp, e, oy0, oy1, y_first, tid);
+}
+
 __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   extern __shared__ uint32_t s_mem[];
   const int tid = threadIdx.x;
@@ -134,42 +185,7 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
     __syncthreads();
   }
 
-  // ---- vertical pass + layout / normalisation (4 consecutive bytes per thread when the rows are dword-sized)
-  const bool vec4 = (tmp_row_bytes & 3) == 0;
-  const int per = vec4 ? 4 : 1;
-  const int n_out = (oy1 - oy0) * (tmp_row_bytes / per);
-  for (int i = tid; i < n_out; i += OB) {
-    const int oy = oy0 + i / (tmp_row_bytes / per), j0 = (i % (tmp_row_bytes / per)) * per;
-    uint32_t v[4] = {0, 0, 0, 0};
-    if (P.oh == P.H) {
-      for (int q = 0; q < per; ++q) v[q] = s_tmp[(size_t)(oy - y_first) * tmp_row_bytes + j0 + q];
-    } else {
-      const int y0 = P.by[2 * oy], n = P.by[2 * oy + 1];
-      const int32_t* k = P.kky + oy * P.ky;
-      const uint8_t* p = s_tmp + (size_t)(y0 - y_first) * tmp_row_bytes + j0;
-      int32_t a[4] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
-      if (vec4) {
-        for (int t = 0; t < n; ++t) {
-          const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)t * tmp_row_bytes);
-          const uint32_t kt = (uint32_t)k[t];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a[q] += (int32_t)__umul24((w >> (8 * q)) & 255u, kt);
-        }
-      } else {
-        for (int t = 0; t < n; ++t) a[0] += (int32_t)p[(size_t)t * tmp_row_bytes] * k[t];
-      }
-      for (int q = 0; q < per; ++q) v[q] = clip8(a[q]);
-    }
-    for (int q = 0; q < per; ++q) {
-      const int j = j0 + q, ox = j / 3, c = j % 3;
-      const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : ((size_t)e * P.oh + oy) * tmp_row_bytes + j;
-      if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v[q] / 255.0f;     // NormalizeWrapper: (obs - 0) / (255 - 0)
-      else if (!vec4 || P.chw) reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v[q];
-    }
-    if (vec4 && !P.chw && !P.f32)                      // HWC uint8: one dword store
-      *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.out) + ((size_t)e * P.oh + oy) * tmp_row_bytes + j0) =
-          v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-  }
+  observe_vertical(P, s_tmp, e, oy0, oy1, y_first, tid);
 }
 
 }  // namespace

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 PIL = pytest.importorskip("PIL.Image")
 
 
-@pytest.mark.parametrize("W,H,ow,oh", [(640, 480, 160, 120), (640, 480, 80, 80), (640, 480, 84, 84), (160, 120, 200, 150),
+@pytest.mark.parametrize("W,H,ow,oh", [(640, 480, 160, 120), (640, 480, 320, 240), (160, 120, 40, 30), (640, 480, 320, 120), (640, 480, 80, 80), (640, 480, 84, 84), (160, 120, 200, 150),
                                        (84, 84, 64, 42), (640, 480, 160, 480), (640, 480, 640, 60), (640, 480, 640, 480)])
 def test_observe_matches_pil(W, H, ow, oh):
     import torch
