@@ -598,6 +598,9 @@ __device__ inline const uint64_t* stage_maps(const MapSet& M, uint64_t* lds) {
   return lds;
 }
 
+// SAMPLER: the device-side reset sampler is compiled in (its rejection loop and Philox state cost registers, so
+// the pool / no-auto-reset launches use the lean instantiation).
+template <bool SAMPLER>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, StepParams P, const void* actions,
                                                      const dtsim_init_state* pool) {
   extern __shared__ uint64_t lds[];
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     if (P.auto_reset && A.done[e]) {
       const int ep = A.episode[e] + 1;
       A.episode[e] = ep;
-      if (P.sampler) {                               // device-side sampling (takes precedence over the pool)
+      if (SAMPLER) {                                 // device-side sampling (takes precedence over the pool)
         const int cur = A.map_id[e];
         const int nm = P.sampler->map_cycle ? (cur + 1) % M.n_maps : cur;
         const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
@@ -771,7 +774,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_query(SimArrays A, MapSet M, Ste
 void dt_launch_step(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
                     const void* actions, const dtsim_init_state* pool) {
   const int grid = (A.N + STEP_BLOCK - 1) / STEP_BLOCK;
-  hipLaunchKernelGGL(k_step, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
+  if (P.sampler) hipLaunchKernelGGL(k_step<true>, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
+  else hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
 }
 
 void dt_launch_reset(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
