@@ -140,6 +140,7 @@ size_t layout_arrays(SimArrays& A, int N, char* base) {
   A.ob_visible = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
   A.ob_light = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
   A.tl_time = carve<double>(p, n);
+  A.ob_cy = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
   return (size_t)(p - base);
 }
 
@@ -848,6 +849,7 @@ bool field_desc(dtsim* h, int field, FieldDesc& d) {
     case DTSIM_FIELD_OBJ_YROT: d = {A.ob_yrot, 8, DTSIM_MAX_DYNAMIC, N, true}; return true;
     case DTSIM_FIELD_OBJ_VISIBLE: d = {A.ob_visible, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
     case DTSIM_FIELD_OBJ_LIGHT: d = {A.ob_light, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
+    case DTSIM_FIELD_OBJ_Y: d = {A.ob_cy, 8, DTSIM_MAX_DYNAMIC, N, true}; return true;
     case DTSIM_FIELD_EPISODE: d = {A.episode, 4, 1, N, true}; return true;
     default: return false;
   }

@@ -50,7 +50,7 @@ static_assert(sizeof(TileRec) == 8, "TileRec is one word");
 struct DynInit {           // per map, per dynamic slot: initial DuckieObj state
   double cx, cz, corners[8], norm[4], heading_x, heading_z, angle, safety_radius;
   double walk_distance, vel, wait_time, wiggle;   // DuckieObj; DuckiebotObj: follow_dist, velocity, gain, trim
-  int32_t obj_index, kind;                        // kind: 1 DuckieObj, 2 DuckiebotObj
+  int32_t obj_index, kind;                        // kind: 1 DuckieObj, 2 DuckiebotObj, 3 CheckerboardObj
 };
 
 // ---- per-env SoA ------------------------------------------------------------
@@ -79,6 +79,7 @@ struct SimArrays {
   uint8_t *ob_active;      // [DTSIM_MAX_DYNAMIC][N]
   uint8_t *ob_visible;     // [DTSIM_MAX_OBJECTS][N]
   uint8_t *ob_light;       // [DTSIM_MAX_OBJECTS][N] TrafficLightObj.pattern
+  double *ob_cy;           // [DTSIM_MAX_DYNAMIC][N] centre height (CheckerboardObj; 0 for the others)
   double *tl_time;         // [N] TrafficLightObj.time (object clock: not reset with the env, objects.py:441,459)
 };
 

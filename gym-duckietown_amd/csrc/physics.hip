@@ -173,8 +173,8 @@ __device__ inline double proximity(const MapView& m, const SimArrays& A, const D
   const int nd = m.h->n_dyn;
   const int N = A.N;
   for (int d = 0; d < nd; ++d) {
-    const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
-    const double dist = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+    const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddy = 0.0 - A.ob_cy[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
+    const double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);     // |agent_pos - center| in 3-D (objects.py:373-382, 525)
     const double score = (dist - r1) - dyn[d].safety_radius;
     total += fmin(0.0, score);
   }
@@ -290,6 +290,34 @@ __device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d,
   }
   const double angle_delta = A.ob_wiggle[ix] * sin(48 * time);
   A.ob_yrot[ix] = (ang + angle_delta) * (180 / 3.141592653589793);
+}
+
+// objects.py:531-587 CheckerboardObj.step: a scripted back/forth, left/right, up/down calibration motion of the
+// centre, 20/3000 m per call, driven by a step counter that advances by 2 (kept in ob_vel); the collision box is
+// never moved (objects.py:507-511 uses the corners of the initial pose).
+__device__ inline void checker_step(const SimArrays& A, int d, int e, double dt) {
+  const size_t N = A.N, ix = (size_t)d * N + e;
+  A.ob_time[ix] += dt;
+  const int step = (int)A.ob_vel[ix];
+  const double off = 20 * 1.0 / 3000;
+  double cx = A.ob_cx[ix], cy = A.ob_cy[ix], cz = A.ob_cz[ix];
+  bool move = true;
+  if (step < 0) {}
+  else if (step < 40) cx += off;
+  else if (step < 135) cx -= off;
+  else if (step < 170) cx += off;
+  else if (step < 200) cz += off;
+  else if (step < 260) cz -= off;
+  else if (step < 290) cz += off;
+  else if (step < 310) cy += off;
+  else if (step < 330) cy -= off;
+  else if (step < 355) cx -= off;
+  else if (step < 370) cy -= off;
+  else if (step < 385) cy += off;
+  else if (step < 420) cx += off;
+  else { cx = A.ob_sx[ix]; cy = 0.0; cz = A.ob_sz[ix]; A.ob_vel[ix] = -20.0; move = false; }
+  if (move) A.ob_vel[ix] = (double)(step + 2);
+  A.ob_cx[ix] = cx; A.ob_cy[ix] = cy; A.ob_cz[ix] = cz;
 }
 
 // objects.py:230-336 DuckiebotObj.step_duckiebot + _update_pos: pure pursuit on the lane curve with
@@ -419,7 +447,7 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
     for (int d = 0; d < mh->n_dyn; ++d) {
       const size_t ix = (size_t)d * N + e;
       A.ob_cx[ix] = dyn[d].cx; A.ob_cz[ix] = dyn[d].cz;
-      A.ob_sx[ix] = dyn[d].cx; A.ob_sz[ix] = dyn[d].cz;
+      A.ob_sx[ix] = dyn[d].cx; A.ob_sz[ix] = dyn[d].cz; A.ob_cy[ix] = 0.0;
       for (int k = 0; k < 8; ++k) A.ob_corners[(size_t)(k * DTSIM_MAX_DYNAMIC + d) * N + e] = dyn[d].corners[k];
       A.ob_vel[ix] = dyn[d].vel; A.ob_wait[ix] = dyn[d].wait_time; A.ob_time[ix] = 0.0;
       A.ob_angle[ix] = dyn[d].angle; A.ob_wiggle[ix] = dyn[d].wiggle;
@@ -447,11 +475,11 @@ __device__ inline bool inconvenient_spawn(const MapView& m, const SimArrays& A, 
   for (int o = 0; o < m.h->n_obj; ++o) {
     if (!A.ob_visible[(size_t)o * N + e]) continue;
     const double* ob = m.objs + o * OBJ_WORDS;
-    double ox = ob[0], oz = ob[1];
+    double ox = ob[0], oy = 0.0, oz = ob[1];
     const int slot = (int)ob[3];
-    if (slot >= 0) { ox = A.ob_cx[(size_t)slot * N + e]; oz = A.ob_cz[(size_t)slot * N + e]; }
+    if (slot >= 0) { ox = A.ob_cx[(size_t)slot * N + e]; oy = A.ob_cy[(size_t)slot * N + e]; oz = A.ob_cz[(size_t)slot * N + e]; }
     const double ddx = ox - px, ddz = oz - pz;
-    inc = inc || (sqrt((ddx * ddx + 0.0) + ddz * ddz) < ob[2]);
+    inc = inc || (sqrt((ddx * ddx + oy * oy) + ddz * ddz) < ob[2]);
   }
   return inc;
 }
@@ -674,6 +702,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       speed = sqrt((ddx * ddx + 0.0) + ddz * ddz) / dt;
       for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
         if (dyn[d].kind == 2) duckiebot_step(A, m, dyn[d], d, e, dt);
+        else if (dyn[d].kind == 3) checker_step(A, d, e, dt);
         else duckie_step(A, dyn[d], d, e, dt);
       }
       if (m.h->n_lights > 0) {                         // TrafficLightObj.step (objects.py:455-463)

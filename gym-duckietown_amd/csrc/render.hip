@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
     if (oi.dyn_slot >= 0) {               // DuckieObj: pos = center, y_rot wiggles (objects.py:408-410)
       px = (float)A.ob_cx[(size_t)oi.dyn_slot * N + e]; pz = (float)A.ob_cz[(size_t)oi.dyn_slot * N + e];
+      py += (float)A.ob_cy[(size_t)oi.dyn_slot * N + e];
       yrot = (float)A.ob_yrot[(size_t)oi.dyn_slot * N + e];
     }
     const bool visible = A.ob_visible[(size_t)obj * N + e] != 0;

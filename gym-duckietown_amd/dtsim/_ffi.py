@@ -29,7 +29,7 @@ TILE_OTHER = 10
 (FIELD_POS, FIELD_ANGLE, FIELD_REWARD, FIELD_DONE, FIELD_DONE_CODE, FIELD_STEP_COUNT, FIELD_TILE,
  FIELD_LANE, FIELD_IN_LANE, FIELD_PROX, FIELD_SPEED, FIELD_TIMESTAMP, FIELD_WHEELS, FIELD_MAP_ID,
  FIELD_OBJ_CENTER, FIELD_OBJ_ACTIVE, FIELD_OBJ_YROT, FIELD_OBJ_PARAMS, FIELD_OBJ_VISIBLE,
- FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT) = range(22)
+ FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT, FIELD_OBJ_Y) = range(23)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 

@@ -415,7 +415,7 @@ class BatchedSimulator:
         _ffi.FIELD_OBJ_CENTER: ("f8", (_ffi.MAX_DYNAMIC, 2)), _ffi.FIELD_OBJ_ACTIVE: ("u1", (_ffi.MAX_DYNAMIC,)),
         _ffi.FIELD_OBJ_YROT: ("f8", (_ffi.MAX_DYNAMIC,)), _ffi.FIELD_OBJ_PARAMS: ("f8", (_ffi.MAX_DYNAMIC, 3)),
         _ffi.FIELD_OBJ_VISIBLE: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_EPISODE: ("i4", ()),
-        _ffi.FIELD_OBJ_LIGHT: ("u1", (_ffi.MAX_OBJECTS,)),
+        _ffi.FIELD_OBJ_LIGHT: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_OBJ_Y: ("f8", (_ffi.MAX_DYNAMIC,)),
     }
 
     def read(self, field: int) -> np.ndarray:

@@ -300,8 +300,11 @@ def interpret_map(map_data: dict, name: str = "map", meshes: Optional[Dict[str, 
             elif kind == "duckiebot":
                 o.dyn_kind = 2                    # DuckiebotObj, non-DR defaults (objects.py:208-216)
                 o.walk_distance, o.vel, o.wait_time, o.wiggle = 0.3, 0.1, 2.0, 0.0   # follow_dist, velocity, gain, trim
+            elif kind == "checkerboard":
+                o.dyn_kind = 3                    # CheckerboardObj (objects.py:479-505): scripted motion, step counter starts at -20
+                o.walk_distance, o.vel, o.wait_time, o.wiggle = ts + 0.25, -20.0, 0.0, 0.0
             else:
-                raise InvalidMapException(f"dynamic object kind {kind!r} not supported (duckie / duckiebot)")
+                raise InvalidMapException("Object kind unknown.")      # simulator.py:1016-1018
             o.dyn_slot = n_dyn
             n_dyn += 1
         objs.append(o)

@@ -110,7 +110,8 @@ typedef struct dtsim_config {
  * (generate_corners collision.py:64-79, generate_norm collision.py:99-106). */
 typedef struct dtsim_object {
   int32_t mesh_id;       /* index into dtsim_set_assets meshes, -1 = not rendered */
-  int32_t dynamic;       /* 0 static WorldObj, 1 DuckieObj pedestrian (objects.py:339), 2 DuckiebotObj follower (objects.py:180) */
+  int32_t dynamic;       /* 0 static WorldObj, 1 DuckieObj pedestrian (objects.py:339), 2 DuckiebotObj follower (objects.py:180),
+                            3 CheckerboardObj (objects.py:479-587: scripted calibration motion, `vel` carries the initial step counter) */
   int32_t collidable;    /* static && kind != trafficlight (simulator.py:1027-1030) */
   int32_t optional;
   double pos[3];
@@ -229,7 +230,8 @@ enum {
   DTSIM_FIELD_EPISODE = 19,   /* int32  [N] episodes started (auto-reset counter) */
   DTSIM_FIELD_STATE_BLOB = 20,/* opaque: full SoA state, dtsim_state_bytes() bytes (checkpoint) */
   DTSIM_FIELD_OBJ_LIGHT = 21, /* uint8  [N][DTSIM_MAX_OBJECTS] TrafficLightObj.pattern (0 for other objects) */
-  DTSIM_FIELD__COUNT = 22
+  DTSIM_FIELD_OBJ_Y = 22,     /* double [N][DTSIM_MAX_DYNAMIC] height of the object centre (CheckerboardObj moves in y) */
+  DTSIM_FIELD__COUNT = 23
 };
 
 /* kernels for dtsim_profile_read */

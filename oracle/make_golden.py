@@ -200,6 +200,14 @@ def main():
         tl[tag] = pat
     np.savez_compressed(os.path.join(OUT, "ref_trafficlight.npz"), **tl)
 
+    # CheckerboardObj.step (objects.py:531-587) on a bare instance: centre over 2.5 cycles of the script
+    o = types.SimpleNamespace(time=0, steps=-20, center=np.array([1.5, 0.0, 2.25]), reset_start=np.array([1.5, 0.0, 2.25]), pos=None)
+    cb = np.zeros((600, 3))
+    for t in range(600):
+        ns.objects.CheckerboardObj.step(o, 1 / 30)
+        cb[t] = o.center
+    np.savez_compressed(os.path.join(OUT, "ref_checkerboard.npz"), center=cb)
+
     # ObjMesh parser (objmesh.py:55-358, the reference's own code) on the procedural asset tree of
     # tests/golden/make_assets.py: triangle soup in draw order, extents, per-chunk textures
     lib = assets.AssetLibrary(os.path.join(OUT, "assets"))

@@ -290,6 +290,9 @@ class OracleObj:
     velocity: float = 0.1
     gain: float = 2.0
     trim: float = 0.0
+    # CheckerboardObj (objects.py:479-505)
+    steps: int = -20
+    reset_start: Optional[np.ndarray] = None
     # TrafficLightObj (objects.py:434-463, non-DR branch): freq 5 s, pattern 0
     light_freq: int = 0
     light_pattern: int = 0
@@ -359,6 +362,45 @@ class OracleObj:
                 self.light_pattern ^= 1
             return
         if self.static or self.kind == "duckiebot":
+            return
+        if self.kind == "checkerboard":               # objects.py:531-587
+            self.time += delta_time
+            step, off, move = self.steps, 20 * 1.0 / 3000, True
+            d = np.zeros(3)
+            if step < 0:
+                pass
+            elif step < 40:
+                d[0] = off
+            elif step < 135:
+                d[0] = -off
+            elif step < 170:
+                d[0] = off
+            elif step < 200:
+                d[2] = off
+            elif step < 260:
+                d[2] = -off
+            elif step < 290:
+                d[2] = off
+            elif step < 310:
+                d[1] = off
+            elif step < 330:
+                d[1] = -off
+            elif step < 355:
+                d[0] = -off
+            elif step < 370:
+                d[1] = -off
+            elif step < 385:
+                d[1] = off
+            elif step < 420:
+                d[0] = off
+            else:
+                self.center = np.copy(self.reset_start)
+                self.steps = -20
+                move = False
+            if move:
+                self.center = self.center + d
+                self.steps += 2
+            self.pos = self.center
             return
         self.time += delta_time
         if not self.pedestrian_active:
@@ -474,8 +516,11 @@ class OracleMap:
                 o.light_freq, o.light_pattern = 5, 0  # objects.py:446-451
             if not static and kind == "duckiebot":
                 pass                  # DuckiebotObj(obj_desc, ..., WHEEL_DIST, ROBOT_WIDTH, ROBOT_LENGTH) simulator.py:1005-1008
+            elif not static and kind == "checkerboard":     # CheckerboardObj simulator.py:1013-1014
+                o.walk_distance = ts + 0.25
+                o.start = np.copy(pos); o.reset_start = np.copy(pos); o.center = pos; o.steps = -20
             elif not static:
-                assert kind == "duckie", "oracle: DuckieObj / DuckiebotObj dynamics restated"
+                assert kind == "duckie", "oracle: DuckieObj / DuckiebotObj / CheckerboardObj dynamics restated"
                 o.walk_distance = ts  # simulator.py:1010
                 o.heading = np.array([math.cos(angle), 0, -math.sin(angle)])  # collision.py:223
                 o.start = np.copy(pos)

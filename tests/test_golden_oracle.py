@@ -145,3 +145,18 @@ def test_trafficlight_step_matches_reference_golden():
             o.step(dt)
             pat[t] = o.light_pattern
         assert np.array_equal(pat, g[tag]), tag
+
+
+def test_checkerboard_step_matches_reference_golden():
+    """CheckerboardObj.step (objects.py:531-587): the scripted calibration motion of the centre."""
+    from oracle import sim as osim
+    g = np.load(os.path.join(G, "ref_checkerboard.npz"))["center"]
+    p0 = np.array([1.5, 0.0, 2.25])
+    o = osim.OracleObj(kind="checkerboard", pos=p0.copy(), angle=0.0, scale=1.0, static=False, optional=False,
+                       min_coords=np.zeros(3), max_coords=np.ones(3), safety_radius=0.0, obj_corners=np.zeros((4, 2)),
+                       obj_norm=np.eye(2), center=p0.copy(), reset_start=p0.copy(), steps=-20)
+    got = np.zeros_like(g)
+    for t in range(len(g)):
+        o.step(1 / 30)
+        got[t] = o.center
+    assert np.array_equal(got, g)

@@ -333,3 +333,35 @@ def test_large_map_with_many_objects_matches_oracle():
         n_coll += int(pr["collision"][q])
     assert n_coll > 10
     sim.close()
+
+
+def test_checkerboard_motion_matches_oracle():
+    """CheckerboardObj (objects.py:479-587): scripted motion incl. the vertical excursion; the collision box stays
+    at the initial pose, proximity uses the moving 3-D centre."""
+    from dtsim import assets
+    md = assets.get_map("small_loop")
+    md["objects"] = [dict(kind="checkerboard", pos=[2.4, 1.35], rotate=0, height=0.2, static=False),
+                     dict(kind="duckie", pos=[1.75, 2.5], rotate=60, height=0.06, static=True)]
+    N = 3
+    sim = BatchedSimulator("cb", N, map_data=md, render=False, domain_rand=False, seed=2, max_steps=10**6)
+    o = osim.OracleSim(md, EXT, do_reset=False)
+    ob = o.map.objects[0]
+    assert sim.maps[0].objects[0].dyn_kind == 3
+    rng = np.random.default_rng(5)
+    T = 500
+    for t in range(T):
+        sim.step(np.zeros((1, N, 2), np.float32))
+        ob.step(1 / 30)
+        if t % 25 == 0 or t in (19, 20, 67, 155, 156, 219, 220):
+            cen = sim.read(_ffi.FIELD_OBJ_CENTER)[0, 0]
+            cy = sim.read(_ffi.FIELD_OBJ_Y)[0, 0]
+            assert cen[0] == ob.center[0] and cen[1] == ob.center[2] and cy == ob.center[1], (t, cen, cy, ob.center)
+            poses = random_poses(rng, 5, 5, 0.585, 60, np.array([[ob.center[0], ob.center[2]]]))
+            pr = sim.query(np.zeros(len(poses), np.int32), poses, safety_factor=1.0)
+            for q, (x, z, a) in enumerate(poses):
+                pos = np.array([x, 0, z])
+                assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
+                assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
+                assert bool(pr["inconvenient"][q]) == o._inconvenient_spawn(pos)
+    assert ob.center[1] == 0.0 or abs(ob.center[1]) < 0.2
+    sim.close()

@@ -84,13 +84,14 @@ def test_frames_match_oracle(map_name, W, H, distortion, dr):
 def _obj_states(sim, e, scene):
     """Per-object render state of env e (static: map pose; DuckieObj: device centre / y_rot)."""
     cen, yrot = sim.read(_ffi.FIELD_OBJ_CENTER)[e], sim.read(_ffi.FIELD_OBJ_YROT)[e]
+    cy = sim.read(_ffi.FIELD_OBJ_Y)[e]
     vis = sim.read(_ffi.FIELD_OBJ_VISIBLE)[e]
     out, slot = [], 0
     for k, o in enumerate(scene.m.objects):
         if o.static:
             out.append(dict(pos=o.pos, y_rot=o.y_rot, visible=bool(vis[k])))
         else:
-            out.append(dict(pos=np.array([cen[slot, 0], 0.0, cen[slot, 1]]), y_rot=float(yrot[slot]), visible=bool(vis[k])))
+            out.append(dict(pos=np.array([cen[slot, 0], cy[slot], cen[slot, 1]]), y_rot=float(yrot[slot]), visible=bool(vis[k])))
             slot += 1
     return out
 
@@ -235,3 +236,37 @@ def test_odd_frame_sizes_match_oracle():
             s = _stats(frames[e], ref_px)
             assert s["frac_gt1"] <= 4e-3 and s["mean"] <= 0.05, (W, H, e, s)     # tiny frames: every silhouette pixel counts
         sim.close()
+
+
+def test_checkerboard_renders_at_its_moving_centre():
+    """CheckerboardObj: rendered at pos = centre, including the vertical part of its script (objects.py:531-587)."""
+    md = assets.get_map("small_loop")
+    md["objects"] = [dict(kind="checkerboard", pos=[2.5, 1.3], rotate=30, height=0.25, static=False)]
+    N, W, H = 3, 320, 240
+    sim = BatchedSimulator("cb", N, map_data=md, camera_width=W, camera_height=H, distortion=False, domain_rand=False,
+                           seed=8, max_steps=10**6, do_reset=False)
+    om = osim.OracleMap(md, EXT)
+    scene = raster.Scene(om, {k: assets.get_texture(k) for k in {t["kind"] for t in om.grid if t is not None}},
+                         {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")})
+    st = (_ffi.InitState * N)()
+    o = om.objects[0]
+    for e in range(N):
+        a = 0.4 + 0.9 * e
+        st[e].pos[:] = [float(o.pos[0] - 0.5 * np.cos(a)), 0.0, float(o.pos[2] + 0.5 * np.sin(a))]
+        st[e].angle = float(a); st[e].wheel_dist = 0.102
+        st[e].cam_height, st[e].cam_angle_deg, st[e].cam_fov_y_deg = 0.108, 19.15, 75.0
+        st[e].horizon_color[:] = [0.45, 0.82, 1.0]; st[e].ground_color[:] = [0.15, 0.15, 0.15]
+        st[e].light_pos[:] = [0.0, 3.0, 0.0, 1.0]; st[e].light_ambient[:] = [0.25] * 3; st[e].light_diffuse[:] = [0.35] * 3
+    sim.init_states = st
+    sim.reset(states=st)
+    sim.step(np.zeros((170, N, 2), np.float32), n_steps=170)        # step counter 320: on its way up
+    assert 0.02 < sim.read(_ffi.FIELD_OBJ_Y)[0, 0] < 0.2
+    sim.render()
+    frames = sim.frames_host()
+    for e in range(N):
+        cam = _camera(sim, e, W, H, False)
+        stt = _obj_states(sim, e, scene)
+        ref_px = raster.render_obs(cam, scene, "pixel", None, obj_states=stt)
+        s_ = _stats(frames[e], ref_px)
+        assert s_["frac_gt1"] <= 2e-3 and s_["mean"] <= 0.03, (e, s_)
+    sim.close()
