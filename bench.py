@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cpu-steps", type=int, default=8, help="oracle env-steps for cpu_baseline")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
+    ap.add_argument("--gather-timeout", type=float, default=120.0, help="give up on the frame exchange after this many seconds")
     ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5"],
                     help="c3 (default, the headline): raster + fisheye; c2: dynamics+collision only, render off "
                          "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch; "
@@ -217,10 +218,65 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t_max = float(tt.item())
 
+    def emit(gather_, cpu_=None):
+        k_ms = ms_r / max(n_r, 1)
+        achieved = N * FRAME_BYTES / (k_ms * 1e-3)
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
+        if os.path.exists(pj):
+            try:
+                d = json.load(open(pj))
+                if d.get("envs") == N and args.config == "c3":
+                    traffic = d.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        line = {
+            "metric": "env-steps/sec (4096 envs, 640x480 RGB) at 1/2/4/8 MI355X; % HBM roofline",
+            "value": world * N * K / t_max,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1e3 * t_max / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 raster -> u8 frames; f64 physics",
+            "data": "synthetic",
+            "config": {"workload": f"{variant['label']}, {N} batched envs per GPU, 640x480 RGB raster + fisheye "
+                                   f"distortion, domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
+                                   f"auto-reset from spawn pool [BASELINE.json {variant['ref']}]",
+                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
+                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
+                         "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
+                         "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
+                         "step_kernel_ms": ms_s / max(n_s, 1)},
+            "cpu_baseline": cpu_,
+            "gather": gather_,
+            "episodes_per_env": done_frac,
+            "setup_s": t_setup,
+        }
+        print(json.dumps(line), flush=True)
+
     # ---- optional: frame all-gather over RCCL/xGMI (north star; link-bound, not in `value`)
     gather = None
     force_gather = os.environ.get("DTSIM_BENCH_FORCE_GATHER") == "1" and dist.is_initialized()
+    done_frac = float(sim.read(_ffi.FIELD_EPISODE).mean())
+    watchdog = None
     if (world > 1 or force_gather) and not args.no_gather:
+        # The exchange is reported beside `value`, never inside it: if a collective stalls (a hung link would
+        # block inside RCCL, where no exception can be caught) the already-measured line is still printed.
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                emit({"error": f"frame exchange did not finish within {args.gather_timeout:.0f} s; skipped"})
+            os._exit(0)
+
+        watchdog = threading.Timer(args.gather_timeout, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         frames = torch.as_tensor(sim.frames_device(), device=dev)
         try:
             out = torch.empty((world,) + tuple(frames.shape), dtype=torch.uint8, device=dev)
@@ -259,52 +315,14 @@ def main():
             del out
         except Exception as ex:  # e.g. OOM on small-memory parts
             gather = {"error": repr(ex)[:200]}
+        watchdog.cancel()
 
-    done_frac = float(sim.read(_ffi.FIELD_EPISODE).mean())
     cpu = None
     if rank == 0 and world == 1 and args.cpu_steps > 0 and args.config == "c3":
         cpu = cpu_baseline(args.cpu_steps)
 
     if rank == 0:
-        k_ms = ms_r / max(n_r, 1)
-        achieved = N * FRAME_BYTES / (k_ms * 1e-3)
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
-        if os.path.exists(pj):
-            try:
-                d = json.load(open(pj))
-                if d.get("envs") == N and args.config == "c3":
-                    traffic = d.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-        line = {
-            "metric": "env-steps/sec (4096 envs, 640x480 RGB) at 1/2/4/8 MI355X; % HBM roofline",
-            "value": world * N * K / t_max,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
-            "ms_per_step": 1e3 * t_max / K,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32 raster -> u8 frames; f64 physics",
-            "data": "synthetic",
-            "config": {"workload": f"{variant['label']}, {N} batched envs per GPU, 640x480 RGB raster + fisheye "
-                                   f"distortion, domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
-                                   f"auto-reset from spawn pool [BASELINE.json {variant['ref']}]",
-                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
-                       "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
-                         "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
-                         "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
-                         "step_kernel_ms": ms_s / max(n_s, 1)},
-            "cpu_baseline": cpu,
-            "gather": gather,
-            "episodes_per_env": done_frac,
-            "setup_s": t_setup,
-        }
-        print(json.dumps(line), flush=True)
+        emit(gather, cpu)
     sim.close()
     if dist.is_initialized():
         dist.destroy_process_group()

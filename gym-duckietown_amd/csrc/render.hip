@@ -829,6 +829,13 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         need_ground |= cand[k] & !is_tile[k];
         edge[k] = ((p.flags & (PF_VALID | PF_ALWAYS_EDGE)) == (PF_VALID | PF_ALWAYS_EDGE)) | (is_tile[k] & !fast[k]);
       }
+      bool any_fast = false;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) any_fast |= fast[k];
+      if (!__ballot(any_fast)) {                     // wave-uniform: nothing here takes the textured one-ray result
+#pragma unroll                                       // (ground beyond the map, horizon band): no texel loads, no filter
+        for (int k = 0; k < PPT; ++k) px[k] = (pv[k].flags & PF_VALID) ? hor_rgb : 0u;
+      } else {
       uint2 top2[PPT], bot2[PPT];
       float ax[PPT], ay[PPT];
       const uint8_t* tex_bytes = reinterpret_cast<const uint8_t*>(texels);
@@ -865,6 +872,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, rgb);
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, rgb);
         px[k] = fast[k] ? rgb : ((p.flags & PF_VALID) ? hor_rgb : 0u);
+      }
       }
       if (__ballot(need_ground)) {                   // wave-uniform: ground quad beyond the map
         const EnvCam c = cams[e];                    // colours / ground-corner light: only needed here
