@@ -76,6 +76,8 @@ struct dtsim {
   float* d_lut = nullptr;
   bool have_lut = false;
   uint32_t* d_texels = nullptr;
+  uint32_t* d_texels_seg = nullptr;   // segmented versions, same layout as d_texels (dtsim_set_segment_assets)
+  uint8_t* d_mesh_seg = nullptr;      // [n_meshes][4] flat segmentation colour per mesh
   TexDev* d_tex = nullptr;
   int n_tex = 0;
   std::vector<TexDev> h_tex;
@@ -261,22 +263,14 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
-int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const dtsim_mesh* meshes,
-                     int n_meshes) {
-  if (!h) return fail(DTSIM_E_INVALID, "null handle");
-  if (n_textures < 0 || n_textures > DTSIM_MAX_TEXTURES) return fail(DTSIM_E_LIMIT, "n_textures %d > %d", n_textures, DTSIM_MAX_TEXTURES);
-  if (n_meshes < 0 || n_meshes > DTSIM_MAX_MESHES) return fail(DTSIM_E_LIMIT, "n_meshes %d > %d", n_meshes, DTSIM_MAX_MESHES);
-  HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  // textures: padded (h+1) x (w+1) storage so that GL_REPEAT bilinear fetches never wrap
-  std::vector<uint32_t> pool;
-  h->h_tex.clear();
+// textures -> one RGBA8 pool: padded (h+1) x (w+1) storage so that GL_REPEAT bilinear fetches never wrap
+static int build_texel_pool(const dtsim_texture* textures, int n_textures, std::vector<uint32_t>& pool, std::vector<TexDev>* descs) {
   for (int t = 0; t < n_textures; ++t) {
     const dtsim_texture& tx = textures[t];
     if (tx.width <= 0 || tx.height <= 0 || (tx.width & (tx.width - 1)) || (tx.height & (tx.height - 1)) || !tx.rgba)
@@ -290,8 +284,22 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
         const uint8_t* s = tx.rgba + ((size_t)(y % tx.height) * tx.width + (x % tx.width)) * 4;
         dst[(size_t)y * pw + x] = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
       }
-    h->h_tex.push_back(d);
+    if (descs) descs->push_back(d);
   }
+  return DTSIM_OK;
+}
+
+int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const dtsim_mesh* meshes,
+                     int n_meshes) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (n_textures < 0 || n_textures > DTSIM_MAX_TEXTURES) return fail(DTSIM_E_LIMIT, "n_textures %d > %d", n_textures, DTSIM_MAX_TEXTURES);
+  if (n_meshes < 0 || n_meshes > DTSIM_MAX_MESHES) return fail(DTSIM_E_LIMIT, "n_meshes %d > %d", n_meshes, DTSIM_MAX_MESHES);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<uint32_t> pool;
+  h->h_tex.clear();
+  if (int rc = build_texel_pool(textures, n_textures, pool, &h->h_tex)) return rc;
+  if (h->d_texels_seg) { (void)hipFree(h->d_texels_seg); h->d_texels_seg = nullptr; }   // mirrors the old list
   if (h->d_texels) { (void)hipFree(h->d_texels); h->d_texels = nullptr; }
   if (h->d_tex) { (void)hipFree(h->d_tex); h->d_tex = nullptr; }
   h->n_tex = n_textures;
@@ -336,6 +344,31 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
       HIPCHK(hipMemcpy(h->d_tris, tris.data(), sizeof(TriDev) * tris.size(), hipMemcpyHostToDevice));
     }
   }
+  return DTSIM_OK;
+}
+
+int dtsim_set_segment_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const uint8_t* mesh_rgb, int n_meshes) {
+  if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (n_textures != h->n_tex || n_meshes != h->n_meshes)
+    return fail(DTSIM_E_INVALID, "segment assets must mirror dtsim_set_assets (%d textures, %d meshes), got %d / %d", h->n_tex,
+                h->n_meshes, n_textures, n_meshes);
+  if ((n_textures > 0 && !textures) || (n_meshes > 0 && !mesh_rgb)) return fail(DTSIM_E_INVALID, "null argument");
+  for (int t = 0; t < n_textures; ++t)
+    if (textures[t].width != h->h_tex[t].w || textures[t].height != h->h_tex[t].h)
+      return fail(DTSIM_E_INVALID, "segmented texture %d is %dx%d, the texture it replaces is %dx%d", t, textures[t].width,
+                  textures[t].height, h->h_tex[t].w, h->h_tex[t].h);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<uint32_t> pool;
+  if (int rc = build_texel_pool(textures, n_textures, pool, nullptr)) return rc;
+  if (h->d_texels_seg) { (void)hipFree(h->d_texels_seg); h->d_texels_seg = nullptr; }
+  if (h->d_mesh_seg) { (void)hipFree(h->d_mesh_seg); h->d_mesh_seg = nullptr; }
+  HIPCHK(hipMalloc(&h->d_texels_seg, std::max<size_t>(pool.size(), 1) * 4));
+  if (!pool.empty()) HIPCHK(hipMemcpy(h->d_texels_seg, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+  std::vector<uint8_t> rgbx((size_t)std::max(n_meshes, 1) * 4, 0);
+  for (int m = 0; m < n_meshes; ++m) { rgbx[m * 4] = mesh_rgb[m * 3]; rgbx[m * 4 + 1] = mesh_rgb[m * 3 + 1]; rgbx[m * 4 + 2] = mesh_rgb[m * 3 + 2]; }
+  HIPCHK(hipMalloc(&h->d_mesh_seg, rgbx.size()));
+  HIPCHK(hipMemcpy(h->d_mesh_seg, rgbx.data(), rgbx.size(), hipMemcpyHostToDevice));
   return DTSIM_OK;
 }
 
@@ -665,8 +698,13 @@ int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_devi
   return DTSIM_OK;
 }
 
-int dtsim_render(dtsim_t* h) {
+int dtsim_render(dtsim_t* h) { return dtsim_render_ex(h, 0u); }
+
+int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  if (flags & ~(uint32_t)DTSIM_RENDER_SEGMENT) return fail(DTSIM_E_INVALID, "unknown render flags 0x%x", flags);
+  const bool segment = (flags & DTSIM_RENDER_SEGMENT) != 0;
+  if (segment && !h->d_texels_seg) return fail(DTSIM_E_STATE, "DTSIM_RENDER_SEGMENT before dtsim_set_segment_assets");
   if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
   if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_render before dtsim_set_maps/dtsim_reset");
   if (!h->have_lut) return fail(DTSIM_E_STATE, "DTSIM_F_DISTORTION set but dtsim_set_distortion_lut was not called");
@@ -677,7 +715,8 @@ int dtsim_render(dtsim_t* h) {
   R.domain_rand = (h->cfg.flags & DTSIM_F_DOMAIN_RAND) ? 1 : 0;
   R.n_maps = h->M.n_maps;
   { const char* a = getenv("DTSIM_RASTER_NO_MSAA"); R.no_msaa = (a && a[0] == '1') ? 1 : 0; }
-  R.frames = h->frames; R.lut = h->d_lut; R.texels = h->d_texels; R.tex = h->d_tex;
+  R.frames = h->frames; R.lut = h->d_lut; R.texels = segment ? h->d_texels_seg : h->d_texels; R.tex = h->d_tex;
+  R.segment = segment ? 1 : 0; R.mesh_seg = h->d_mesh_seg;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;

@@ -185,7 +185,7 @@ struct RenderParams {
   const TriDev* tris;
   void* envcam;                 // [N] EnvCam scratch written by the setup kernel
   // mesh objects: per-env screen-space triangles written by the object setup kernel
-  int32_t max_tris, pad2;       // triangle slots per env (max over maps), 0 = no objects anywhere
+  int32_t max_tris, segment;    // triangle slots per env (max over maps), 0 = no objects anywhere; segment: DTSIM_RENDER_SEGMENT
   ScreenTri* stris;             // [N][max_tris]
   ObjEnv* objenv;               // [N]
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
@@ -194,6 +194,7 @@ struct RenderParams {
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
   int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor; zeroed per render
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
+  const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

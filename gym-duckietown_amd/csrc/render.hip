@@ -103,7 +103,7 @@ __device__ inline CamShared default_cam(float aspect) {
   return s;
 }
 
-__global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* out, EnvFast* fast,
+__global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
                             const RenderMapDev* __restrict__ maps) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
@@ -139,6 +139,9 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, float aspect, EnvCam* 
     c.gnd[k] = 255.f * A.colors[(3 + k) * N + e];
     c.base[k] = base[k];     // GL_LIGHT_MODEL_AMBIENT 0.3 (simulator.py:1741) + light ambient
     c.dif[k] = dif[k];
+  }
+  if (segment) {             // simulator.py:1730-1733 lighting off; :1753 clear and :1808 ground quad magenta
+    for (int k = 0; k < 3; ++k) { c.base[k] = 1.f; c.dif[k] = 0.f; c.hor[k] = c.gnd[k] = (k == 1) ? 0.f : 255.f; }
   }
   if (L[3] == 0.f) {  // directional: normalise once
     const float inv = rsqrtf(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
@@ -257,6 +260,14 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     st.tex = td.tex; st.pad = 0;
     if (oi.light_tris > 0 && (t - obj_first) < oi.light_tris)          // traffic light card: texture by pattern
       st.tex = A.ob_light[(size_t)obj * N + e] ? oi.light_tex1 : oi.light_tex0;
+    if (R.segment) {         // get_mesh(name, segment=True): one flat colour as every chunk's texture (objmesh.py:255-292),
+      const uint8_t* sc = R.mesh_seg + 4 * oi.mesh_id;   // MODULATEd with the per-vertex Kd -> fold it into the vertex colours
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st.cw[v][k] *= (float)sc[k] * (1.f / 255.f);
+      st.tex = -1;
+    }
     const float area = (st.sx[1] - st.sx[0]) * (st.sy[2] - st.sy[0]) - (st.sx[2] - st.sx[0]) * (st.sy[1] - st.sy[0]);
     ok = ok && (area != 0.f);
     st.inv_area = ok ? 1.f / area : 0.f;
@@ -1123,7 +1134,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) {
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
-  hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand,
+  hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
   (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
@@ -1137,7 +1148,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   const bool obj = R.max_tris > 0;
-  if (R.domain_rand) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }
+  if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
   if (!R.no_msaa) {

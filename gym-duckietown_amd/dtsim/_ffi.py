@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 8, 96, 64
@@ -32,11 +32,12 @@ TILE_OTHER = 10
  FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT, FIELD_OBJ_Y) = range(23)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
+RENDER_SEGMENT = 1
 
 EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
-    "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_frames_devptr", "dtsim_frames_bytes",
+    "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
     "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
@@ -160,6 +161,8 @@ def load(path: str | None = None):
         "dtsim_set_spawn_pool": (ci, [vp, C.POINTER(InitState), ci]),
         "dtsim_step": (ci, [vp, vp, ci, ci]),
         "dtsim_render": (ci, [vp]),
+        "dtsim_render_ex": (ci, [vp, C.c_uint32]),
+        "dtsim_set_segment_assets": (ci, [vp, C.POINTER(Texture), ci, C.POINTER(C.c_uint8), ci]),
         "dtsim_frames_devptr": (vp, [vp]),
         "dtsim_frames_bytes": (sz, [vp]),
         "dtsim_bind_frames": (ci, [vp, vp]),

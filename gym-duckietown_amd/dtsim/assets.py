@@ -379,6 +379,7 @@ class AssetLibrary:
         if key not in self._meshes:
             m = load_obj(p, self.resolve, name=key, change_materials=change)
             m.textures = [to_pow2(load_image_rgba(t)) for t in m.texture_files]
+            m.seg_name = base                      # get_mesh(mesh_name, segment=True) hashes the mesh name
             self._meshes[key] = m
         return key, self._meshes[key]
 
@@ -391,3 +392,104 @@ class AssetLibrary:
 
     def mesh_extents(self, kinds) -> dict:
         return {k: (self.mesh(k).min_coords, self.mesh(k).max_coords) for k in kinds}
+
+
+# ---------------------------------------------------------------- segmentation assets --
+# `render(segment=True)` swaps every texture for a segmented version (graphics.py:52-126) and every
+# mesh for a flat-coloured one (objmesh.py:255-292).  The tile branch of load_texture() goes through
+# OpenCV (8-bit BGR->HSV, inRange, erode, HSV->BGR); cv2 is absent offline, so its 8-bit colour
+# conversions are restated below from OpenCV's documented algorithm -- parity unpinned.
+
+def gen_segmentation_color(name: str):
+    """objmesh.py:260-266: decimal character codes concatenated, cut into 3-digit groups, each % 255."""
+    hashed = "".join(str(ord(ch)) for ch in name)
+    col = [int(hashed[i:i + 3]) % 255 for i in range(0, len(hashed), 3)][:3]
+    if len(col) != 3:
+        raise ValueError(f"mesh name {name!r} is too short for gen_segmentation_color")
+    return col
+
+
+def should_segment_out(tex_path: str) -> bool:
+    """graphics.py:59-67."""
+    for yes in ("sign", "trafficlight", "asphalt"):
+        if yes in tex_path:
+            return True
+    for no in ("left", "right", "way", "curve", "straight"):
+        if no in tex_path:
+            return False
+    return True
+
+
+def _round_half_even_div(num: int, den: float) -> int:
+    return int(np.rint(num / den))
+
+
+_HSV_SHIFT = 12
+_SDIV = np.array([0] + [_round_half_even_div(255 << _HSV_SHIFT, 1.0 * i) for i in range(1, 256)], np.int64)
+_HDIV180 = np.array([0] + [_round_half_even_div(180 << _HSV_SHIFT, 6.0 * i) for i in range(1, 256)], np.int64)
+
+
+def bgr2hsv_u8(bgr: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(bgr, COLOR_BGR2HSV) for uint8 (OpenCV RGB2HSV_b, hrange 180): integer arithmetic with the
+    12-bit reciprocal tables."""
+    b, g, r = (bgr[..., k].astype(np.int64) for k in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    vr = np.where(v == r, -1, 0)
+    vg = np.where(v == g, -1, 0)
+    half = 1 << (_HSV_SHIFT - 1)
+    s = (diff * _SDIV[v] + half) >> _HSV_SHIFT
+    h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))))
+    h = (h * _HDIV180[diff] + half) >> _HSV_SHIFT
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s & 255, v], axis=-1).astype(np.uint8)
+
+
+def hsv2bgr_u8(hsv: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(hsv, COLOR_HSV2BGR) for uint8 (OpenCV HSV2RGB_b -> HSV2RGB_native in float32, hrange 180,
+    saturate_cast<uchar>(x * 255) = round half to even)."""
+    f = np.float32
+    h = hsv[..., 0].astype(f) * f(6.0 / 180.0)
+    s = hsv[..., 1].astype(f) * f(1.0 / 255.0)
+    v = hsv[..., 2].astype(f) * f(1.0 / 255.0)
+    h = np.fmod(h, f(6.0))
+    sector = np.floor(h).astype(np.int64)
+    h = h - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    h = np.where(bad, f(0), h)
+    one = f(1.0)
+    tab = np.stack([v, v * (one - s), v * (one - s * h), v * (one - s * (one - h))], axis=-1)
+    sector_data = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    idx = sector_data[sector]                                    # [..., 3] -> b, g, r
+    bgr = np.take_along_axis(tab, idx, axis=-1)
+    bgr = np.where((s == 0)[..., None], v[..., None], bgr)
+    return np.clip(np.rint(bgr * f(255.0)), 0, 255).astype(np.uint8)
+
+
+def segment_texture(tex: np.ndarray, tex_path: str, into_color=(0, 0, 0)) -> np.ndarray:
+    """load_texture(tex_path, segment=True, segment_into_color) (graphics.py:91-126) applied to an RGBA8 texture in
+    GL row order: either a flat fill, or (lane-marking tiles) everything that is not saturated / bright paint
+    blacked out."""
+    out = np.empty_like(tex)
+    out[..., 3] = 255
+    if should_segment_out(tex_path):
+        out[..., :3] = np.asarray(into_color, np.int64).astype(np.uint8)
+        return out
+    bgr = tex[::-1, :, 2::-1]                                    # image row order, B G R
+    hsv = bgr2hsv_u8(bgr)
+    inr = (hsv[..., 0] <= 179) & (hsv[..., 1] <= 100) & (hsv[..., 2] <= 160)      # inRange([0,0,0],[179,100,160])
+    keep = ~inr                                                  # bitwise_not; erode by the centre-only kernel = identity
+    pad = np.pad(keep, 1, constant_values=True)                  # erode's border never lowers the minimum
+    H, W = keep.shape
+    ring = np.ones_like(keep)
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            if (dy, dx) != (1, 1):
+                ring &= pad[dy:dy + H, dx:dx + W]                # erode by the 8-neighbour ring kernel
+    mask = keep & ring
+    hsv = np.where(mask[..., None], hsv, 0).astype(np.uint8)
+    res = hsv2bgr_u8(hsv)
+    out[..., :3] = res[::-1, :, ::-1]
+    return out

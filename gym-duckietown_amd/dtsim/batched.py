@@ -95,6 +95,7 @@ class BatchedSimulator:
         first = [maps.interpret_map(d, n, self.meshes, transform_uses_width, library=use_lib)
                  for d, n in zip(datas, self.map_names)]
         mesh_order = list(self.meshes)                 # "duckie", "*", then every object mesh the library loaded
+        self._mesh_order, self._have_segment_assets = mesh_order, False
         tex_kinds: List[str] = []
         for mt in first:
             for kd in mt.texture_kinds:
@@ -354,8 +355,49 @@ class BatchedSimulator:
             raise ValueError(f"actions has {a.size} elements, expected {n_steps}*{self.num_envs}*2")
         _ffi.check(self._lib, self._lib.dtsim_step(self._h, a.ctypes.data_as(C.c_void_p), int(n_steps), 0))
 
-    def render(self):
-        _ffi.check(self._lib, self._lib.dtsim_render(self._h))
+    def render(self, segment: bool = False):
+        """render_obs() of every env into the frame batch; `segment=True` is the reference's segmentation render
+        (simulator.py:1730-1737,1753,1808,1879)."""
+        if not segment:
+            _ffi.check(self._lib, self._lib.dtsim_render(self._h))
+            return
+        if not self._have_segment_assets:
+            self._install_segment_assets()
+        _ffi.check(self._lib, self._lib.dtsim_render_ex(self._h, _ffi.RENDER_SEGMENT))
+
+    def segment_assets(self):
+        """(segmented textures mirroring self.textures, per-mesh flat colours [n_meshes,3]) -- host prep of the
+        segmentation render: tile textures through load_texture(segment=True) (graphics.py:70-126, into black),
+        mesh textures and meshes through gen_segmentation_color(mesh_name) (objmesh.py:255-292)."""
+        import os
+        lib = self.library
+        seg_tex = []
+        for i, kd in enumerate(self.texture_kinds):
+            p = lib.tile_texture_file(kd) if lib.root else None
+            hint = p if p else os.path.join("tiles-processed", lib.style, kd, "texture.png")
+            seg_tex.append(assets.segment_texture(self.textures[i], hint))
+        rgb = np.zeros((len(self._mesh_order), 3), np.uint8)
+        k = len(self.texture_kinds)
+        for mi, mk in enumerate(self._mesh_order):
+            m = self.meshes[mk]
+            col = assets.gen_segmentation_color(getattr(m, "seg_name", None) or (mk if len(mk) >= 3 else "object"))
+            rgb[mi] = col
+            for t in m.textures:                   # only ever sampled through the flat colour (st.tex = -1 on the device)
+                seg_tex.append(assets.segment_texture(t, "mesh", col))
+                k += 1
+        while len(seg_tex) < len(self.textures):   # traffic-light cards: a segmented mesh has no switching card
+            seg_tex.append(assets.segment_texture(self.textures[len(seg_tex)], "trafficlight"))
+        return seg_tex, rgb
+
+    def _install_segment_assets(self):
+        seg_tex, rgb = self.segment_assets()
+        tarr = (_ffi.Texture * max(len(seg_tex), 1))()
+        for i, t in enumerate(seg_tex):
+            tarr[i].width, tarr[i].height = t.shape[1], t.shape[0]
+            tarr[i].rgba = t.ctypes.data_as(C.POINTER(C.c_uint8))
+        _ffi.check(self._lib, self._lib.dtsim_set_segment_assets(
+            self._h, tarr, len(seg_tex), rgb.ctypes.data_as(C.POINTER(C.c_uint8)), len(self._mesh_order)))
+        self._have_segment_assets = True
 
     def frames_device(self) -> DeviceArray:
         ptr = self._lib.dtsim_frames_devptr(self._h)

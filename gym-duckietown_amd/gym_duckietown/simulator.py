@@ -9,8 +9,8 @@ Same constructor keywords, `reset() / step() / render() / seed() / close()`, att
 It is an N=1 view of dtsim.BatchedSimulator: every number comes from the GPU kernels
 (`dtsim_step`, `dtsim_render`, `dtsim_query`); nothing is recomputed on the host.
 
-Not provided (out of scope): the pyglet human window, `top_down` / `free_cam` /
-`segment` renders, `draw_bbox` / `draw_curve`, LEDs, `randomize_maps_on_reset`, `camera_rand`'s
+Not provided (out of scope): the pyglet human window, `top_down` / `free_cam`
+renders, `draw_bbox` / `draw_curve`, LEDs, `randomize_maps_on_reset`, `camera_rand`'s
 carnivalmirror calibration sampling.
 """
 from __future__ import annotations
@@ -199,8 +199,6 @@ class Simulator(_EnvBase):
         pass
 
     def reset(self, segment: bool = False):
-        if segment:
-            raise NotImplementedError("segmentation render is out of scope")
         self._sim.reset()
         st = self._sim.init_states[0]
         es = self._sim.env_state[0]
@@ -209,7 +207,7 @@ class Simulator(_EnvBase):
         self.ground_color = np.array(list(st.ground_color))
         self.wheel_dist = st.wheel_dist
         self.cam_height, self.cam_angle, self.cam_fov_y = st.cam_height, [st.cam_angle_deg, 0, 0], st.cam_fov_y_deg
-        return self.render_obs()
+        return self.render_obs(segment=segment)
 
     def step(self, action: np.ndarray):
         action = np.clip(action, -1, 1) if self._ACTION_MODE == "wheels" else np.asarray(action)
@@ -223,17 +221,18 @@ class Simulator(_EnvBase):
         return obs, d.reward, d.done, misc
 
     def render_obs(self, segment: bool = False) -> np.ndarray:
-        self._sim.render()
+        """simulator.py:1953-1972; `segment=True` is the segmentation render (:1730-1737, 1753, 1808, 1879)."""
+        self._sim.render(segment=bool(segment))
         return self._sim.frames_host()[0]
 
     def render(self, mode: str = "human", close: bool = False, segment: bool = False):
         assert mode in ["human", "top_down", "free_cam", "rgb_array"]
         if close:
             return
-        if mode != "rgb_array" or segment:
+        if mode != "rgb_array":
             raise NotImplementedError("only mode='rgb_array' is implemented (the camera observation at the "
                                       "configured resolution); human/top_down/free_cam windows are out of scope")
-        return self.render_obs()
+        return self.render_obs(segment=segment)
 
     # --------------------------------------------------------- device-side queries --
     def _probe(self, pos, angle, safety_factor=1.0):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 3
+#define DTSIM_ABI_VERSION 4
 
 /* error codes */
 #define DTSIM_OK 0
@@ -296,6 +296,19 @@ int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_devi
 /* Simulator.render_obs (simulator.py:1953-1972) = _render_img (:1707-1951) + distort:
  * writes [num_envs][cam_height][cam_width][3] uint8, row 0 = image top.  Asynchronous. */
 int dtsim_render(dtsim_t* h);
+
+/* Segmentation render, `_render_img(..., segment=True)` (simulator.py:1730-1737, 1753, 1808, 1879; reached from
+ * reset(segment) :760, render_obs(segment) :1953 and render(mode, segment) :1974): lighting off, colour buffer
+ * cleared to and ground quad drawn in magenta, every texture replaced by its segmented version
+ * (graphics.py:52-57 Texture.bind -> load_texture(segment=True) :70-126), every mesh drawn through
+ * get_mesh(name, segment=True) = flat `gen_segmentation_color(mesh_name)` modulated by the per-vertex Kd
+ * (objmesh.py:255-292, 360-362).  The segmented textures are prepared on the host (dtsim/assets.py) and must
+ * mirror the dtsim_set_assets list entry for entry (same count, same sizes); mesh_rgb is [n_meshes][3]. */
+int dtsim_set_segment_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures,
+                             const uint8_t* mesh_rgb, int n_meshes);
+enum { DTSIM_RENDER_SEGMENT = 1u };
+/* dtsim_render with flags (DTSIM_RENDER_*); dtsim_render(h) == dtsim_render_ex(h, 0). */
+int dtsim_render_ex(dtsim_t* h, uint32_t flags);
 void* dtsim_frames_devptr(dtsim_t* h);
 size_t dtsim_frames_bytes(const dtsim_t* h);
 /* Render into caller-owned device memory instead (e.g. a torch tensor that is the

@@ -370,3 +370,29 @@ def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None):
     if rmap is not None:
         img = distort(img, rmap[0], rmap[1])
     return img
+
+
+def segment_view(cam, scene, seg_textures, mesh_colors):
+    """(camera, scene) of `_render_img(..., segment=True)`: GL_LIGHTING / GL_LIGHT0 / GL_COLOR_MATERIAL disabled
+    (simulator.py:1730-1733: the fragment is texture x vertex colour), colour buffer cleared to and ground quad drawn
+    in (255, 0, 255) clamped = magenta (:1753, :1808), tile textures bound through Texture.bind(segment=True)
+    (graphics.py:52-57; `seg_textures`: kind -> segmented image, prepared like load_texture(segment=True)), objects
+    drawn through get_mesh(name, segment=True): every chunk textured with the flat gen_segmentation_color(name)
+    (objmesh.py:255-292; `mesh_colors`: mesh key -> RGB 0..254), no traffic-light card switching."""
+    import copy
+    c = copy.copy(cam)
+    c.base, c.dif = np.ones(3), np.zeros(3)
+    c.horizon = np.array([255.0, 0.0, 255.0])
+    c.ground = np.array([255.0, 0.0, 255.0])
+    meshes = {}
+    for key, m in scene.meshes.items():
+        mm = copy.copy(m)
+        flat = np.zeros((2, 2, 4), np.uint8)
+        flat[..., :3] = np.asarray(mesh_colors[key], np.uint8)
+        flat[..., 3] = 255
+        mm.textures = [flat]
+        mm.tri_tex = np.zeros(m.verts.shape[0], np.int32)
+        meshes[key] = mm
+    sc = Scene(scene.m, dict(seg_textures), meshes)
+    sc.light_cards = None
+    return c, sc

@@ -159,3 +159,43 @@ def test_obj_parser_fuzz_against_reference(tmp_path):
         assert list(r["chunk_sizes"]) == m.chunk_sizes, case
         want = ["" if t is None else os.path.basename(t) for t in r["textures"]]
         assert _chunk_textures(m, r["chunk_sizes"]) == want, case
+
+
+def test_segmentation_assets_follow_the_reference_rules():
+    """graphics.py:59-126 / objmesh.py:260-266: which textures are blanked, which keep their paint, the name hash."""
+    from dtsim import assets as A
+    # gen_segmentation_color: decimal char codes, 3-digit groups, % 255 (checked by hand for "duckie":
+    # "100" "117" "991" -> 100, 117, 991 % 255 = 226)
+    assert A.gen_segmentation_color("duckie") == [100, 117, 226]
+    assert A.gen_segmentation_color("duckiebot") == [100, 117, 226]          # same first three groups (reference quirk)
+    with pytest.raises(ValueError):
+        A.gen_segmentation_color("*")
+    assert A.should_segment_out("tiles-processed/photos/asphalt/texture.jpg")
+    assert A.should_segment_out("tiles-processed/photos/grass/texture.jpg")
+    assert A.should_segment_out("sign_left_T_intersect.png")                    # "sign" wins over "left"
+    assert not A.should_segment_out("tiles-processed/photos/curve_left/texture.jpg")
+    assert not A.should_segment_out("tiles-processed/photos/4way/texture.jpg")
+    # 8-bit BGR<->HSV known values (OpenCV documentation: H in [0,180), S, V in [0,255])
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128], [0, 255, 255]]], np.uint8)
+    hsv = A.bgr2hsv_u8(px)
+    assert hsv.tolist() == [[[120, 255, 255], [60, 255, 255], [0, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128], [30, 255, 255]]]
+    assert np.array_equal(A.hsv2bgr_u8(hsv), px)
+    rng = np.random.default_rng(0)
+    rnd = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    back = A.hsv2bgr_u8(A.bgr2hsv_u8(rnd))
+    assert np.abs(back.astype(int) - rnd.astype(int)).max() <= 6                # 8-bit HSV is lossy, but only slightly
+    # a lane-marking tile: dark asphalt goes black, yellow / white paint survives except its 1-px rim
+    tex = np.zeros((32, 32, 4), np.uint8)
+    tex[..., :3] = (60, 60, 64)
+    tex[..., 3] = 255
+    tex[:, 10:16, :3] = (240, 200, 40)                                          # yellow line, 6 px wide
+    tex[:, 24:28, :3] = (235, 235, 230)                                         # white line, 4 px wide
+    seg = A.segment_texture(tex, "tiles-processed/photos/straight/texture.png")
+    assert (seg[:, :10, :3] == 0).all() and (seg[:, 16:24, :3] == 0).all() and (seg[:, 28:, :3] == 0).all()
+    assert (seg[:, 10, :3] == 0).all() and (seg[:, 15, :3] == 0).all()         # rim eroded by the 8-neighbour kernel
+    assert np.abs(seg[:, 11:15, :3].astype(int) - (240, 200, 40)).max() <= 4
+    assert np.abs(seg[:, 25:27, :3].astype(int) - (235, 235, 230)).max() <= 4
+    flat = A.segment_texture(tex, "tiles-processed/photos/grass/texture.png")
+    assert (flat[..., :3] == 0).all() and (flat[..., 3] == 255).all()
+    col = A.segment_texture(tex, "duckie.png", [100, 117, 226])
+    assert (col[..., :3] == (100, 117, 226)).all()

@@ -92,3 +92,24 @@ def test_batched_multimap_slot_alternation():
     tiles = sim.read(_ffi.FIELD_TILE)
     assert (tiles[::2, 0] < 8).all() and (tiles[1::2, 0] < 5).all()
     sim.close()
+
+
+def test_segmentation_render_like_test_segmentation_py():
+    """test_segmentation.py:164-186: `reset()`, `render(segment=True)`, `step`, alternating `render(segment=...)`;
+    the segmented view keeps the geometry of the camera view: magenta where the normal frame shows sky / ground,
+    black asphalt, paint and flat-coloured objects elsewhere."""
+    from gym_duckietown.envs import DuckietownEnv
+    env = DuckietownEnv(map_name="loop_only_duckies", domain_rand=False, max_steps=10**6, seed=2, camera_width=160, camera_height=120)
+    obs = env.reset()
+    seg = env.render("rgb_array", segment=True)
+    assert seg.shape == obs.shape and seg.dtype == np.uint8
+    sky = (np.abs(obs.astype(int) - np.round(np.array(env.horizon_color) * 255)).max(-1) <= 1)
+    mag = (seg == np.array([255, 0, 255], np.uint8)).all(-1)
+    assert (mag[sky]).mean() > 0.95 and mag.mean() < 0.9
+    assert ((seg == 0).all(-1)).mean() > 0.1                      # blanked asphalt / grass
+    for i in range(4):
+        obs, _, _, _ = env.step(np.array([0.3, 0.0]))
+        img = env.render("rgb_array", segment=(i % 2 == 0))
+        assert (i % 2 == 0) == bool((img == np.array([255, 0, 255], np.uint8)).all(-1).any())
+    assert np.array_equal(env.reset(segment=True), env.render_obs(segment=True))
+    env.close()

@@ -270,3 +270,39 @@ def test_checkerboard_renders_at_its_moving_centre():
         s_ = _stats(frames[e], ref_px)
         assert s_["frac_gt1"] <= 2e-3 and s_["mean"] <= 0.03, (e, s_)
     sim.close()
+
+
+@pytest.mark.parametrize("map_name,W,H,distortion,dr", [
+    ("loop_only_duckies", 320, 240, False, False),
+    ("loop_dyn_duckiebots", 320, 240, True, True),
+])
+def test_segment_render_matches_oracle(map_name, W, H, distortion, dr):
+    """`render_obs(segment=True)` (simulator.py:1730-1737,1753,1808,1879): unlit, magenta sky / ground, segmented
+    tile textures, flat-coloured meshes; and the normal render afterwards is unchanged."""
+    N = 3
+    sim = BatchedSimulator(map_name, N, camera_width=W, camera_height=H, distortion=distortion, domain_rand=dr, seed=5)
+    sim.step(np.random.default_rng(4).uniform(0.2, 0.8, (6, N, 2)).astype(np.float32), n_steps=6)
+    sim.render()
+    normal = sim.frames_host().copy()
+    sim.render(segment=True)
+    frames = sim.frames_host().copy()
+    sim.render()
+    assert np.array_equal(sim.frames_host(), normal)
+    scene = _scene(map_name)
+    seg_tex, rgb = sim.segment_assets()
+    seg_by_kind = {kd: seg_tex[i] for i, kd in enumerate(sim.texture_kinds)}
+    cols = {mk: rgb[i] for i, mk in enumerate(sim._mesh_order)}
+    rmap = pdist.distortion_maps(W, H) if distortion else None
+    n_obj_px = 0
+    for e in range(N):
+        cam, sc = raster.segment_view(_camera(sim, e, W, H, dr), scene, seg_by_kind, cols)
+        st = _obj_states(sim, e, scene)
+        ref_px = raster.render_obs(cam, sc, "pixel", rmap, obj_states=st)
+        s_ = _stats(frames[e], ref_px)
+        assert s_["frac_gt1"] <= 2e-3 and s_["frac_gt2"] <= 1e-3 and s_["mean"] <= 0.03, (e, s_)
+        valid = np.ones((H, W), bool) if rmap is None else (ref_px.sum(-1) > 0) | (frames[e].sum(-1) > 0)
+        magenta = (frames[e] == np.array([255, 0, 255], np.uint8)).all(-1)
+        assert magenta.mean() > 0.2                      # the sky, at least
+        obj = cols["duckie"].astype(int)
+        n_obj_px += int((np.abs(frames[e].astype(int) - obj).max(-1) <= 60).sum())
+    sim.close()
