@@ -91,6 +91,7 @@ class BatchedSimulator:
         names = [map_name] if isinstance(map_name, str) else list(map_name)
         datas = [map_data] if (map_data is not None) else [self.library.map_data(n) for n in names]
         self.map_names = [assets.map_basename(n) for n in names]
+        self.map_datas, self._ctor_map_names = datas, names
         self.meshes: Dict[str, assets.MeshData] = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
         first = [maps.interpret_map(d, n, self.meshes, transform_uses_width, library=use_lib)
                  for d, n in zip(datas, self.map_names)]

@@ -9,9 +9,11 @@ Same constructor keywords, `reset() / step() / render() / seed() / close()`, att
 It is an N=1 view of dtsim.BatchedSimulator: every number comes from the GPU kernels
 (`dtsim_step`, `dtsim_render`, `dtsim_query`); nothing is recomputed on the host.
 
-Not provided (out of scope): the pyglet human window, `top_down` / `free_cam`
-renders, `draw_bbox` / `draw_curve`, LEDs, `randomize_maps_on_reset`, `camera_rand`'s
-carnivalmirror calibration sampling.
+`render(mode)` returns the 800x600 window image of every mode (agent camera, `free_cam`, `top_down`) from a second
+handle that copies the state; `segment=True` is the segmentation render.
+
+Not provided (out of scope): the pyglet window itself (nothing is displayed), the `draw_bbox` /
+`draw_curve` line overlays, LEDs, `randomize_maps_on_reset`, `camera_rand`'s carnivalmirror calibration sampling.
 """
 from __future__ import annotations
 
@@ -196,7 +198,9 @@ class Simulator(_EnvBase):
         return [seed]
 
     def close(self):
-        pass
+        for v in getattr(self, "_viewers", {}).values():
+            v.close()
+        self._viewers = {}
 
     def reset(self, segment: bool = False):
         self._sim.reset()
@@ -226,13 +230,85 @@ class Simulator(_EnvBase):
         return self._sim.frames_host()[0]
 
     def render(self, mode: str = "human", close: bool = False, segment: bool = False):
+        """simulator.py:1974-2053: the WINDOW_WIDTH x WINDOW_HEIGHT view of the current state -- the agent camera
+        ("human", "rgb_array", "free_cam"; the last without the fisheye) or the map from above with the agent's mesh
+        drawn at its pose ("top_down", :1786-1798, 1920-1927).  The image is returned for every mode; there is no
+        pyglet window here ("human" displays nothing and draws no text label)."""
         assert mode in ["human", "top_down", "free_cam", "rgb_array"]
         if close:
             return
-        if mode != "rgb_array":
-            raise NotImplementedError("only mode='rgb_array' is implemented (the camera observation at the "
-                                      "configured resolution); human/top_down/free_cam windows are out of scope")
-        return self.render_obs(segment=segment)
+        v = self._viewer(self.distortion and mode != "free_cam")
+        self._sync_viewer(v, top_down=(mode == "top_down"))
+        v.render(segment=bool(segment))
+        return v.frames_host()[0]
+
+    # ------------------------------------------------------------------ viewer --
+    def _viewer(self, distortion: bool):
+        """A second one-env handle at the window size that renders copies of this env's state: same map and assets,
+        per-env camera enabled (so a top-down pose can be given to it), plus one extra non-static duckiebot that
+        stands for `self.mesh` in the top-down view (hidden otherwise)."""
+        import copy
+        v = self._viewers.get(bool(distortion)) if hasattr(self, "_viewers") else None
+        if v is not None:
+            return v
+        if not hasattr(self, "_viewers"):
+            self._viewers = {}
+        md = copy.deepcopy(self._sim.map_datas[0])
+        objs = md.get("objects") or []
+        objs = [o for o in (list(objs.values()) if isinstance(objs, dict) else list(objs)) if o["kind"] != "floor_tag"]
+        n_dyn = sum(1 for o in objs if not o.get("static", True))
+        self._agent_marker = None
+        if n_dyn < _ffi.MAX_DYNAMIC and len(objs) < _ffi.MAX_OBJECTS:
+            self._agent_marker = (len(objs), n_dyn)                   # (object index, dynamic slot)
+            marker = {"kind": "duckiebot", "pos": [0.5, 0.5], "rotate": 0, "static": False, "color": "red"}
+            if self._sim.library.root:
+                marker["scale"] = 1.0                                 # self.mesh.render() is unscaled (:1923-1926)
+            else:
+                marker["height"] = 0.12                               # the stand-in meshes are unit-height blobs
+            objs.append(marker)
+        md["objects"] = objs
+        v = BatchedSimulator(self._sim._ctor_map_names[0], 1, map_data=md, camera_width=WINDOW_WIDTH, camera_height=WINDOW_HEIGHT,
+                             distortion=bool(distortion), domain_rand=True, seed=0, max_steps=self.max_steps,
+                             frame_rate=self.frame_rate, device=self._sim._device, style=self.style,
+                             asset_root=self._sim.library.root, do_reset=False)
+        self._viewers[bool(distortion)] = v
+        return v
+
+    def _sync_viewer(self, v, top_down: bool):
+        import ctypes as C
+        st = (_ffi.InitState * 1)()
+        C.memmove(st, C.byref(self._sim.init_states[0]), C.sizeof(_ffi.InitState))
+        s0 = st[0]
+        pos, ang = self.cur_pos, self.cur_angle
+        if not self.domain_rand:
+            s0.camera_noise[:] = [0.0, 0.0, 0.0]                      # drawn, but only applied under domain_rand (:1768-1769)
+        if top_down:                                                  # gluLookAt((a, H, b), (a, 0, b - 0.01), +y)  (:1786-1798)
+            a = self.grid_width * self.road_tile_size / 2
+            b = self.grid_height * self.road_tile_size / 2
+            h_from_floor = (max(a, b) + 0.1) / math.tan(math.radians(s0.cam_fov_y_deg) / 2)
+            # the camera model puts the eye CAMERA_FORWARD_DIST ahead of `pos` along dir = (cos, 0, -sin)
+            s0.pos[:] = [a, 0.0, b + CAMERA_FORWARD_DIST]
+            s0.angle = math.pi / 2
+            s0.cam_height = h_from_floor
+            s0.cam_angle_deg = math.degrees(math.atan2(h_from_floor, 0.01))
+            s0.camera_noise[:] = [0.0, 0.0, 0.0]
+        else:
+            s0.pos[:] = [float(pos[0]), 0.0, float(pos[2])]
+            s0.angle = float(ang)
+        v.init_states = st
+        v.reset(states=st)
+        for f in (_ffi.FIELD_OBJ_CENTER, _ffi.FIELD_OBJ_YROT, _ffi.FIELD_OBJ_Y, _ffi.FIELD_OBJ_ACTIVE, _ffi.FIELD_OBJ_VISIBLE,
+                  _ffi.FIELD_OBJ_LIGHT):
+            arr = self._sim.read(f).copy()
+            if self._agent_marker is not None:
+                k, slot = self._agent_marker
+                if f == _ffi.FIELD_OBJ_CENTER:
+                    arr[0, slot] = [pos[0], pos[2]]
+                elif f == _ffi.FIELD_OBJ_YROT:
+                    arr[0, slot] = math.degrees(ang)                  # glRotatef(cur_angle * 180 / pi, 0, 1, 0)  (:1924)
+                elif f == _ffi.FIELD_OBJ_VISIBLE:
+                    arr[0, k] = 1 if top_down else 0
+            v.write(f, arr)
 
     # --------------------------------------------------------- device-side queries --
     def _probe(self, pos, angle, safety_factor=1.0):

@@ -7,6 +7,7 @@ import pytest
 from dtsim import BatchedSimulator, _ffi
 from oracle import sim as osim
 from util import make_oracle
+from dtsim import distortion as pdist
 
 pytestmark = pytest.mark.gpu
 
@@ -101,7 +102,9 @@ def test_segmentation_render_like_test_segmentation_py():
     from gym_duckietown.envs import DuckietownEnv
     env = DuckietownEnv(map_name="loop_only_duckies", domain_rand=False, max_steps=10**6, seed=2, camera_width=160, camera_height=120)
     obs = env.reset()
-    seg = env.render("rgb_array", segment=True)
+    win = env.render("rgb_array", segment=True)                  # the 800x600 window image
+    assert win.shape == (600, 800, 3) and (win == np.array([255, 0, 255], np.uint8)).all(-1).any()
+    seg = env.render_obs(segment=True)
     assert seg.shape == obs.shape and seg.dtype == np.uint8
     sky = (np.abs(obs.astype(int) - np.round(np.array(env.horizon_color) * 255)).max(-1) <= 1)
     mag = (seg == np.array([255, 0, 255], np.uint8)).all(-1)
@@ -109,7 +112,73 @@ def test_segmentation_render_like_test_segmentation_py():
     assert ((seg == 0).all(-1)).mean() > 0.1                      # blanked asphalt / grass
     for i in range(4):
         obs, _, _, _ = env.step(np.array([0.3, 0.0]))
-        img = env.render("rgb_array", segment=(i % 2 == 0))
+        img = env.render_obs(segment=(i % 2 == 0))
         assert (i % 2 == 0) == bool((img == np.array([255, 0, 255], np.uint8)).all(-1).any())
     assert np.array_equal(env.reset(segment=True), env.render_obs(segment=True))
+    env.close()
+
+
+def test_render_modes_window_views_match_oracle():
+    """render(mode) (simulator.py:1974-2003): 800x600 views of the current state.  "rgb_array" / "free_cam" are the
+    agent camera (with / without the fisheye); "top_down" is gluLookAt((a, H, b), (a, 0, b - 0.01), +y) with the
+    agent's mesh at its pose (:1786-1798, 1920-1927).  Checked against the oracle raster on the same inputs."""
+    from gym_duckietown.envs import DuckietownEnv
+    from gym_duckietown.simulator import WINDOW_WIDTH as WW, WINDOW_HEIGHT as WH
+    from dtsim import assets
+    from oracle import raster
+    import math
+    envd = DuckietownEnv(map_name="small_loop_only_duckies", domain_rand=False, seed=9, distortion=True)
+    envd.reset()
+    imgd, freed = envd.render("rgb_array"), envd.render("free_cam")
+    assert imgd.shape == freed.shape == (WH, WW, 3)
+    assert (np.abs(imgd.astype(int) - freed.astype(int)).max(-1) > 8).mean() > 0.02       # the fisheye moves pixels; free_cam has none
+    envd.close()
+    env = DuckietownEnv(map_name="small_loop_only_duckies", domain_rand=False, seed=9, camera_width=160, camera_height=120)
+    env.reset()
+    for _ in range(5):
+        env.step(np.array([0.4, 0.2]))
+    obs = env.render_obs()
+    img = env.render("rgb_array")
+    assert img.shape == (WH, WW, 3) and img.dtype == np.uint8
+    assert abs(float(obs.mean()) - float(img.mean())) < 5                      # run_tests.py:17-22
+    free = env.render("free_cam")
+    top = env.render("top_down")
+    assert np.array_equal(free, img) and top.shape == (WH, WW, 3)
+
+    om = osim.OracleMap(assets.get_map("small_loop_only_duckies"), __import__("util").EXT)
+    kinds = {t["kind"] for t in om.grid if t is not None}
+    meshes = {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")}
+    scene = raster.Scene(om, {k: assets.get_texture(k) for k in kinds}, meshes)
+    st = env._sim.init_states[0]
+    states = [dict(pos=o.pos, y_rot=o.y_rot, visible=True) for o in om.objects]
+    cam = raster.Camera(env.cur_pos, env.cur_angle, width=WW, height=WH, horizon_color=list(st.horizon_color),
+                        ground_color=list(st.ground_color))
+    ref = raster.render_obs(cam, scene, "pixel", None, obj_states=states)
+    d = np.abs(free.astype(int) - ref.astype(int)).max(-1)
+    assert (d > 1).mean() <= 2e-3 and np.abs(free.astype(int) - ref.astype(int)).mean() <= 0.03, ((d > 1).mean(),)
+
+    # top-down: oracle camera straight from the reference's gluLookAt arguments
+    a, b = env.grid_width * env.road_tile_size / 2, env.grid_height * env.road_tile_size / 2
+    Hf = (max(a, b) + 0.1) / math.tan(math.radians(75.0) / 2)
+    tcam = raster.Camera([a, 0.0, b + 0.066], math.pi / 2, cam_height=Hf, cam_angle_deg=math.degrees(math.atan2(Hf, 0.01)),
+                         width=WW, height=WH, horizon_color=list(st.horizon_color), ground_color=list(st.ground_color))
+    assert np.allclose(tcam.C, [a, Hf, b], atol=1e-12)
+    fwd = np.array([0.0, -Hf, -0.01]) / math.hypot(Hf, 0.01)                   # gluLookAt forward
+    assert np.allclose(tcam.to_eye(tcam.C + fwd), [0, 0, -1], atol=1e-9)       # eye space looks down -z
+    assert np.allclose(tcam.to_eye(tcam.C + np.array([1.0, 0, 0])), [1, 0, 0], atol=1e-9)
+    # the agent marker: an extra duckiebot (stand-in mesh, 0.12 m tall) at cur_pos, rotated by cur_angle
+    import copy
+    md = copy.deepcopy(assets.get_map("small_loop_only_duckies"))
+    md["objects"] = list(md["objects"]) + [{"kind": "duckiebot", "pos": [0.5, 0.5], "rotate": 0, "static": False, "height": 0.12}]
+    om2 = osim.OracleMap(md, __import__("util").EXT)
+    scene2 = raster.Scene(om2, scene.textures, meshes)
+    states2 = states + [dict(pos=env.cur_pos, y_rot=math.degrees(env.cur_angle), visible=True)]
+    rmap = None
+    tref = raster.render_obs(tcam, scene2, "pixel", rmap, obj_states=states2)
+    d = np.abs(top.astype(int) - tref.astype(int)).max(-1)
+    assert (d > 1).mean() <= 3e-3 and np.abs(top.astype(int) - tref.astype(int)).mean() <= 0.05, ((d > 1).mean(),)
+    no_agent = raster.render_obs(tcam, scene2, "pixel", rmap, obj_states=states + [dict(states2[-1], visible=False)])
+    assert (np.abs(tref.astype(int) - no_agent.astype(int)).max(-1) > 0).sum() > 30     # the marker is in the picture
+    seg = env.render("top_down", segment=True)
+    assert (seg == np.array([255, 0, 255], np.uint8)).all(-1).mean() > 0.05
     env.close()
