@@ -251,7 +251,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
-                         "step_kernel_ms": ms_s / max(n_s, 1)},
+                         "step_kernel_ms": ms_s / max(n_s, 1),
+                         # the pass is VALU-issue bound, not HBM bound: PMC SQ_INSTS_VALU of k_raster
+                         # = 64.8 lane-operations per pixel (profiles/r01e_raster_sq_ta_pmc_summary.txt) against
+                         # 1024 SIMDs x 2.1 GHz / 4 cycles x 64 lanes
+                         "valu": {"ops_per_pixel": 64.8, "peak_lane_ops_per_s": 1024 * 2.1e9 / 4 * 64,
+                                  "achieved_lane_ops_per_s": 64.8 * N * W * H / (k_ms * 1e-3) if args.config == "c3" else None}},
             "cpu_baseline": cpu_,
             "gather": gather_,
             "episodes_per_env": done_frac,
