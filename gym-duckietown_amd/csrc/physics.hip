@@ -255,10 +255,65 @@ __device__ inline double compute_reward(const Lane& L, double prox, double speed
   return ((1.0 * speed) * L.dot_dir + (-10 * fabs(L.dist))) + (40 * prox);
 }
 
-// objects.py:384-431 DuckieObj.step (non-DR finish_walk branch; DR parameters are
-// supplied per env through DTSIM_FIELD_OBJ_PARAMS because the reference draws them from
-// the unseeded global np.random, objects.py:349-350).
-__device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d, int e, double dt) {
+// ---- device-side reset sampler (dtsim_reset_sampler, SURVEY 8f N2) ----------------------------------
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so an env's draws for episode k depend only on
+// (seed, env, k) -- reproducible regardless of which step the reset happens in or how envs are sharded.
+struct Philox {
+  uint32_t key[2], ctr[4], out[4];
+  int left;
+};
+__device__ inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ inline void philox_refill(Philox& g) {
+  uint32_t c[4] = {g.ctr[0], g.ctr[1], g.ctr[2], g.ctr[3]}, k[2] = {g.key[0], g.key[1]};
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  for (int i = 0; i < 4; ++i) g.out[i] = c[i];
+  g.left = 4;
+  if (++g.ctr[0] == 0) ++g.ctr[1];
+}
+__device__ inline Philox philox_init(uint64_t seed, uint32_t env, uint32_t episode) {
+  Philox g;
+  g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32) ^ (env * 0x9E3779B1u + 0x7F4A7C15u);
+  g.ctr[0] = 0; g.ctr[1] = 0; g.ctr[2] = episode; g.ctr[3] = env;
+  g.left = 0;
+  return g;
+}
+__device__ inline uint32_t rng_u32(Philox& g) {
+  if (g.left == 0) philox_refill(g);
+  return g.out[--g.left];
+}
+__device__ inline double rng_double(Philox& g) {     // [0,1) with 53 random bits (numpy's construction)
+  const uint32_t a = rng_u32(g) >> 5, b = rng_u32(g) >> 6;
+  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+__device__ inline double rng_uniform(Philox& g, double lo, double hi) { return lo + (hi - lo) * rng_double(g); }
+__device__ inline int rng_below(Philox& g, int n) { return (int)(((uint64_t)rng_u32(g) * (uint64_t)n) >> 32); }
+__device__ inline double rng_normal(Philox& g, double loc, double scale) {   // Box-Muller
+  const double u1 = 1.0 - rng_double(g), u2 = rng_double(g);
+  return loc + scale * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+// Stream of one dynamic object's domain-randomisation draws: same key as the env's reset stream, counter space
+// disjoint from it (word 1 carries a tag + the dynamic slot, word 0 the event: creation or the step of a finish_walk).
+__device__ inline Philox philox_object(uint64_t seed, uint32_t env, uint32_t episode, uint32_t slot, uint32_t event) {
+  Philox g = philox_init(seed, env, episode);
+  g.ctr[0] = event; g.ctr[1] = 0x4F424A00u + slot;
+  return g;
+}
+#define DT_OBJ_EVENT_CREATE 0xFFFFFFFFu
+
+// objects.py:384-431 DuckieObj.step.  The reference draws a DuckieObj's domain-randomised parameters from the
+// unseeded global np.random (objects.py:349-350, 424-427), so there is no stream to reproduce: on the host path they
+// are supplied per env (DTSIM_FIELD_OBJ_PARAMS) and finish_walk takes the non-DR branch; with the device reset
+// sampler installed and domain_rand on (`rs`), finish_walk redraws them from the env's Philox stream with the
+// reference's distributions: vel = -sign(vel) |N(0.02, 0.005)|, wait = randint(3, 20).
+__device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d, int e, double dt,
+                                   const dtsim_reset_sampler* rs, int step_count) {
   const size_t N = A.N, ix = (size_t)d * N + e;
   double time = A.ob_time[ix] + dt;
   A.ob_time[ix] = time;
@@ -285,8 +340,15 @@ __device__ inline void duckie_step(const SimArrays& A, const DynInit& di, int d,
     ang += 3.141592653589793;
     A.ob_angle[ix] = ang;
     A.ob_active[ix] = 0;
-    A.ob_vel[ix] = vel * -1;
-    A.ob_wait[ix] = 8;
+    if (rs != nullptr && rs->domain_rand) {
+      Philox g = philox_object(rs->seed, (uint32_t)e, (uint32_t)A.episode[e], (uint32_t)d, (uint32_t)step_count);
+      const double mag = fabs(rng_normal(g, 0.02, 0.005));
+      A.ob_vel[ix] = vel > 0 ? -mag : (vel < 0 ? mag : -0.0 * mag);   // -1 * np.sign(vel) * |N|
+      A.ob_wait[ix] = (double)(3 + rng_below(g, 17));
+    } else {
+      A.ob_vel[ix] = vel * -1;
+      A.ob_wait[ix] = 8;
+    }
   }
   const double angle_delta = A.ob_wiggle[ix] * sin(48 * time);
   A.ob_yrot[ix] = (ang + angle_delta) * (180 / 3.141592653589793);
@@ -409,7 +471,7 @@ __device__ inline void dyn_integrate(Dyn& q, double dt, double L_, double R_, do
 
 // Simulator.reset()'s hand-over of one env (simulator.py:740-755) from a host-drawn state.
 __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, const dtsim_init_state& st,
-                                  int delay_steps) {
+                                  int delay_steps, const dtsim_reset_sampler* rs = nullptr) {
   const size_t N = A.N;
   const int new_map = st.map_id;
   const MapHdr* mh = reinterpret_cast<const MapHdr*>(M.blobs + M.blob_off[new_map]);
@@ -451,6 +513,14 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
       for (int k = 0; k < 8; ++k) A.ob_corners[(size_t)(k * DTSIM_MAX_DYNAMIC + d) * N + e] = dyn[d].corners[k];
       A.ob_vel[ix] = dyn[d].vel; A.ob_wait[ix] = dyn[d].wait_time; A.ob_time[ix] = 0.0;
       A.ob_angle[ix] = dyn[d].angle; A.ob_wiggle[ix] = dyn[d].wiggle;
+      if (rs != nullptr && dyn[d].kind == 1) {       // DuckieObj.__init__ draws (objects.py:348-363), device sampler only
+        Philox g = philox_object(rs->seed, (uint32_t)e, (uint32_t)A.episode[e], (uint32_t)d, DT_OBJ_EVENT_CREATE);
+        if (rs->domain_rand) {
+          A.ob_wait[ix] = (double)(3 + rng_below(g, 17));                 // np.random.randint(3, 20)
+          A.ob_vel[ix] = fabs(rng_normal(g, 0.02, 0.005));                // np.abs(np.random.normal(0.02, 0.005))
+        }
+        A.ob_wiggle[ix] = 3.141592653589793 / (double)(14 + rng_below(g, 3));   // np.pi / choice([14, 15, 16]): always drawn
+      }
       A.ob_yrot[ix] = dyn[d].angle * (180 / 3.141592653589793);
       A.ob_active[ix] = 0;
     }
@@ -484,49 +554,7 @@ __device__ inline bool inconvenient_spawn(const MapView& m, const SimArrays& A, 
   return inc;
 }
 
-// ---- device-side reset sampler (dtsim_reset_sampler, SURVEY 8f N2) ----------------------------------
-// Philox4x32-10 (Salmon et al. 2011): counter-based, so an env's draws for episode k depend only on
-// (seed, env, k) -- reproducible regardless of which step the reset happens in or how envs are sharded.
-struct Philox {
-  uint32_t key[2], ctr[4], out[4];
-  int left;
-};
-__device__ inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
-  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
-}
-__device__ inline void philox_refill(Philox& g) {
-  uint32_t c[4] = {g.ctr[0], g.ctr[1], g.ctr[2], g.ctr[3]}, k[2] = {g.key[0], g.key[1]};
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k);
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-  }
-  for (int i = 0; i < 4; ++i) g.out[i] = c[i];
-  g.left = 4;
-  if (++g.ctr[0] == 0) ++g.ctr[1];
-}
-__device__ inline Philox philox_init(uint64_t seed, uint32_t env, uint32_t episode) {
-  Philox g;
-  g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32) ^ (env * 0x9E3779B1u + 0x7F4A7C15u);
-  g.ctr[0] = 0; g.ctr[1] = 0; g.ctr[2] = episode; g.ctr[3] = env;
-  g.left = 0;
-  return g;
-}
-__device__ inline uint32_t rng_u32(Philox& g) {
-  if (g.left == 0) philox_refill(g);
-  return g.out[--g.left];
-}
-__device__ inline double rng_double(Philox& g) {     // [0,1) with 53 random bits (numpy's construction)
-  const uint32_t a = rng_u32(g) >> 5, b = rng_u32(g) >> 6;
-  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-}
-__device__ inline double rng_uniform(Philox& g, double lo, double hi) { return lo + (hi - lo) * rng_double(g); }
-__device__ inline int rng_below(Philox& g, int n) { return (int)(((uint64_t)rng_u32(g) * (uint64_t)n) >> 32); }
-__device__ inline double rng_normal(Philox& g, double loc, double scale) {   // Box-Muller
-  const double u1 = 1.0 - rng_double(g), u2 = rng_double(g);
-  return loc + scale * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-}
+// ---- device-side reset sampler (dtsim_reset_sampler): Philox helpers are defined above (objects use them too)
 // _perturb simulator.py:1065-1085: val * U(1 - scale, 1 + scale) per component
 __device__ inline void perturb3(Philox& g, bool on, const double v[3], double scale, double out[3]) {
   for (int k = 0; k < 3; ++k) out[k] = on ? v[k] * rng_uniform(g, 1.0 - scale, 1.0 + scale) : v[k];
@@ -647,7 +675,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
         const int cur = A.map_id[e];
         const int nm = P.sampler->map_cycle ? (cur + 1) % M.n_maps : cur;
         const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
-        apply_init(A, M, e, st, P.delay_steps);
+        apply_init(A, M, e, st, P.delay_steps, P.sampler);
       } else {
         const long long slot = ((long long)e + (long long)ep * N) % P.n_pool;
         apply_init(A, M, e, pool[slot], P.delay_steps);
@@ -703,7 +731,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
         if (dyn[d].kind == 2) duckiebot_step(A, m, dyn[d], d, e, dt);
         else if (dyn[d].kind == 3) checker_step(A, d, e, dt);
-        else duckie_step(A, dyn[d], d, e, dt);
+        else duckie_step(A, dyn[d], d, e, dt, SAMPLER ? P.sampler : nullptr, sc);
       }
       if (m.h->n_lights > 0) {                         // TrafficLightObj.step (objects.py:455-463)
         const double tl = A.tl_time[e] + dt;
@@ -755,9 +783,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, Ste
     const int cur = A.map_id[e] < 0 ? (P.sampler->map_cycle ? e % M.n_maps : 0) : A.map_id[e];
     const int nm = (A.map_id[e] >= 0 && P.sampler->map_cycle) ? (cur + 1) % M.n_maps : cur;
     // objects of a fresh env must exist before the spawn test looks at them
-    if (A.map_id[e] != nm) { dtsim_init_state z{}; z.map_id = nm; z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps); }
+    if (A.map_id[e] != nm) { dtsim_init_state z{}; z.map_id = nm; z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps, P.sampler); }
     const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
-    apply_init(A, M, e, st, P.delay_steps);
+    apply_init(A, M, e, st, P.delay_steps, P.sampler);
   } else
   apply_init(A, M, e, states[e], P.delay_steps);
   const int mid = A.map_id[e];

@@ -85,3 +85,47 @@ def test_sampler_errors():
     rc = sim._lib.dtsim_reset(sim._h, None, None)
     assert rc != 0 and b"sampler" in sim._lib.dtsim_last_error()
     sim.close()
+
+
+def test_device_sampler_randomises_walking_duckies():
+    """DuckieObj under domain_rand with the device sampler: the reference's distributions (objects.py:348-363 at
+    creation, :424-427 at finish_walk -- drawn there from the unseeded global np.random, so only the distributions
+    can be matched): wait = randint(3, 20), vel = |N(0.02, 0.005)| with the sign flipping per walk,
+    wiggle = pi / choice([14, 15, 16])."""
+    N = 1024
+    kw = dict(render=False, domain_rand=True, device_reset=True, max_steps=10**6)
+    sim = BatchedSimulator("loop_pedestrians", N, seed=11, **kw)
+    nd = sim.maps[0].n_dynamic
+    assert nd >= 4
+    p0 = sim.read(_ffi.FIELD_OBJ_PARAMS)[:, :nd]                       # [N, nd, (vel, wait, wiggle)]
+    vel, wait, wig = p0[..., 0], p0[..., 1], p0[..., 2]
+    assert (wait == np.round(wait)).all() and wait.min() == 3 and wait.max() == 19
+    cnt = np.bincount(wait.astype(int).ravel(), minlength=20)[3:20]
+    assert cnt.min() > 0.6 * cnt.mean()                                # uniform over the 17 values
+    assert (vel > 0).all() and abs(vel.mean() - 0.02) < 5e-4 and abs(vel.std() - 0.005) < 5e-4
+    k = np.round(np.pi / wig).astype(int)
+    assert np.allclose(np.pi / k, wig, rtol=0, atol=1e-15) and set(np.unique(k)) == {14, 15, 16}
+    # same seed -> same draws; another seed -> different; envs differ from each other
+    same = BatchedSimulator("loop_pedestrians", N, seed=11, **kw)
+    other = BatchedSimulator("loop_pedestrians", N, seed=12, **kw)
+    assert np.array_equal(same.read(_ffi.FIELD_OBJ_PARAMS), sim.read(_ffi.FIELD_OBJ_PARAMS))
+    assert not np.array_equal(other.read(_ffi.FIELD_OBJ_PARAMS)[:, :nd], p0)
+    assert len(np.unique(vel[:, 0])) > N // 2
+    same.close(); other.close()
+    # walk: a duckie waits `wait` seconds, walks tile_size at |vel| per step, then finish_walk redraws
+    T = 30 * 20 + 60
+    sim.step(np.zeros((T, N, 2), np.float32), n_steps=T)
+    p1 = sim.read(_ffi.FIELD_OBJ_PARAMS)[:, :nd]
+    flipped = p1[..., 0] < 0
+    assert 0.6 < flipped.mean() <= 1.0                                 # most have finished their first walk by now
+    mag = np.abs(p1[..., 0][flipped])
+    assert abs(mag.mean() - 0.02) < 6e-4 and abs(mag.std() - 0.005) < 6e-4
+    assert not np.allclose(mag, np.abs(vel[flipped]))                  # a fresh draw, not just the sign flip
+    w1 = p1[..., 1][flipped]
+    assert w1.max() <= 19 and w1.min() > -1.0 / 30 - 1e-9              # counting down from an integer in [3, 19]
+    sim.close()
+    # without the device sampler the host path keeps the explicit (non-random) parameters
+    host = BatchedSimulator("loop_pedestrians", 8, render=False, domain_rand=True, seed=11)
+    ph = host.read(_ffi.FIELD_OBJ_PARAMS)[:, :nd]
+    assert (ph[..., 1] == 8).all() and (ph[..., 0] == 0.02).all()
+    host.close()
