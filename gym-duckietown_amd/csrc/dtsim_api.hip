@@ -584,7 +584,8 @@ int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy)
 static int check_states(const dtsim* h, const dtsim_init_state* st, int n, const uint8_t* mask) {
   for (int e = 0; e < n; ++e) {
     if (mask && !mask[e]) continue;
-    if (st[e].map_id < 0 || st[e].map_id >= h->M.n_maps) return fail(DTSIM_E_INVALID, "state %d: map_id %d out of range", e, st[e].map_id);
+    const int mid = st[e].map_id & ~DTSIM_MAP_RELOAD;
+    if (st[e].map_id < 0 || mid >= h->M.n_maps) return fail(DTSIM_E_INVALID, "state %d: map_id %d out of range", e, st[e].map_id);
   }
   return DTSIM_OK;
 }

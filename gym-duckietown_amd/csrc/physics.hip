@@ -473,7 +473,8 @@ __device__ inline void dyn_integrate(Dyn& q, double dt, double L_, double R_, do
 __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, const dtsim_init_state& st,
                                   int delay_steps, const dtsim_reset_sampler* rs = nullptr) {
   const size_t N = A.N;
-  const int new_map = st.map_id;
+  const int new_map = st.map_id & ~DTSIM_MAP_RELOAD;
+  const bool reload = (st.map_id & DTSIM_MAP_RELOAD) != 0;
   const MapHdr* mh = reinterpret_cast<const MapHdr*>(M.blobs + M.blob_off[new_map]);
   A.pos_x[e] = st.pos[0]; A.pos_z[e] = st.pos[2]; A.angle[e] = st.angle;
   // cartesian_from_weird simulator.py:1629-1638
@@ -504,7 +505,7 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
   for (int k = 0; k < 4; ++k) A.colors[(12 + k) * N + e] = (float)st.light_pos[k];
   // World objects are created at map load and persist across resets in the reference
   // (simulator.py:349,865); (re)create them only when the env's map changes.
-  if (A.map_id[e] != new_map) {
+  if (A.map_id[e] != new_map || reload) {
     const DynInit* dyn = M.dyn + (size_t)new_map * DTSIM_MAX_DYNAMIC;
     for (int d = 0; d < mh->n_dyn; ++d) {
       const size_t ix = (size_t)d * N + e;
@@ -656,6 +657,19 @@ __device__ inline const uint64_t* stage_maps(const MapSet& M, uint64_t* lds) {
 
 // SAMPLER: the device-side reset sampler is compiled in (its rejection loop and Philox state cost registers, so
 // the pool / no-auto-reset launches use the lean instantiation).
+// Which map a device-sampled reset moves the env to: MultiMapEnv's round robin (multimap_env.py:44-49), or
+// randomize_maps_on_reset's uniform draw -- `self.np_random.choice(self.map_names)`, the first draw of reset()
+// (simulator.py:541-544) -- from its own counter word of the env's Philox key.
+__device__ inline int sampler_next_map(const dtsim_reset_sampler& rs, int n_maps, int cur, int e, int episode) {
+  if (rs.map_cycle == 1) return (cur + 1) % n_maps;
+  if (rs.map_cycle == 2) {
+    Philox g = philox_init(rs.seed, (uint32_t)e, (uint32_t)episode);
+    g.ctr[1] = 0x4D415000u;
+    return rng_below(g, n_maps);
+  }
+  return cur;
+}
+
 template <bool SAMPLER>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, StepParams P, const void* actions,
                                                      const dtsim_init_state* pool) {
@@ -673,7 +687,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       A.episode[e] = ep;
       if (SAMPLER) {                                 // device-side sampling (takes precedence over the pool)
         const int cur = A.map_id[e];
-        const int nm = P.sampler->map_cycle ? (cur + 1) % M.n_maps : cur;
+        const int nm = sampler_next_map(*P.sampler, M.n_maps, cur, e, ep);
+        const bool reload = P.sampler->map_cycle == 2;
+        // the objects of the new (or reloaded) map must exist before the spawn test looks at them
+        if (cur != nm || reload) { dtsim_init_state z{}; z.map_id = nm | (reload ? DTSIM_MAP_RELOAD : 0); z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps, P.sampler); }
         const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
         apply_init(A, M, e, st, P.delay_steps, P.sampler);
       } else {
@@ -781,9 +798,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, Ste
     const int ep = A.episode[e] + 1;
     A.episode[e] = ep;
     const int cur = A.map_id[e] < 0 ? (P.sampler->map_cycle ? e % M.n_maps : 0) : A.map_id[e];
-    const int nm = (A.map_id[e] >= 0 && P.sampler->map_cycle) ? (cur + 1) % M.n_maps : cur;
+    const bool reload = P.sampler->map_cycle == 2;
+    const int nm = reload ? sampler_next_map(*P.sampler, M.n_maps, cur, e, ep)
+                          : ((A.map_id[e] >= 0 && P.sampler->map_cycle) ? (cur + 1) % M.n_maps : cur);
     // objects of a fresh env must exist before the spawn test looks at them
-    if (A.map_id[e] != nm) { dtsim_init_state z{}; z.map_id = nm; z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps, P.sampler); }
+    if (A.map_id[e] != nm || reload) { dtsim_init_state z{}; z.map_id = nm | (reload ? DTSIM_MAP_RELOAD : 0); z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps, P.sampler); }
     const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
     apply_init(A, M, e, st, P.delay_steps, P.sampler);
   } else

@@ -33,6 +33,7 @@ TILE_OTHER = 10
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 RENDER_SEGMENT = 1
+MAP_RELOAD = 0x40000000
 
 EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",

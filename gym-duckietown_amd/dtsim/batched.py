@@ -39,7 +39,8 @@ class BatchedSimulator:
                  # batched / device options
                  render: bool = True, auto_reset: bool = False, delay_steps: int = 5, device: int = 0,
                  stream: Optional[int] = None, profile: bool = False, actions_f64: bool = False,
-                 map_cycle: bool = False, transform_uses_width: bool = False, map_data: Optional[dict] = None,
+                 map_cycle: bool = False, map_random: bool = False, transform_uses_width: bool = False,
+                 map_data: Optional[dict] = None,
                  asset_root: Optional[str] = None, style: str = "photos", device_reset: bool = False,
                  do_reset: bool = True):
         self._lib = _ffi.load()
@@ -62,6 +63,7 @@ class BatchedSimulator:
         self.auto_reset = bool(auto_reset)
         self.actions_f64 = bool(actions_f64)
         self.map_cycle = bool(map_cycle)
+        self.map_random = bool(map_random)     # randomize_maps_on_reset: a uniformly drawn map, reloaded, at every reset
         self.seed_value = seed
 
         flags = 0
@@ -172,7 +174,7 @@ class BatchedSimulator:
         sv = self.seed_value if seed is None else seed
         rs.seed = int(sv if sv is not None else np.random.SeedSequence().entropy) & 0xFFFFFFFFFFFFFFFF
         rs.domain_rand, rs.dynamics_rand = int(self.domain_rand), int(self.dynamics_rand)
-        rs.map_cycle = int(self.map_cycle and len(self.maps) > 1)
+        rs.map_cycle = 2 if self.map_random else int(self.map_cycle and len(self.maps) > 1)
         rs.max_attempts = R.MAX_SPAWN_ATTEMPTS
         rs.accept_start_angle_deg = float(self.accept_start_angle_deg)
         rs.color_sky[:] = [float(v) for v in self.color_sky]
@@ -189,6 +191,8 @@ class BatchedSimulator:
         self._sampler = rs
 
     def _map_for_reset(self, e: int) -> int:
+        if self.map_random:                    # simulator.py:541-544: np_random.choice(map_names), the first draw of reset()
+            return int(self.env_state[e].np_random.integers(0, len(self.maps)))
         if len(self.maps) == 1:
             return 0
         if not self.map_cycle:
@@ -210,7 +214,7 @@ class BatchedSimulator:
                 self.env_state[e], mt, domain_rand=self.domain_rand, camera_rand=self.camera_rand,
                 dynamics_rand=self.dynamics_rand, color_sky=self.color_sky, color_ground=self.color_ground,
                 num_tris_distractors=self.num_tris_distractors, n_visible_draw=(), user_tile_start=self.user_tile_start)
-            st.map_id = mi
+            st.map_id = mi | (_ffi.MAP_RELOAD if self.map_random else 0)
             self.init_states[e] = st
             self.env_state[e].spawn_attempts = 0
             if mt.start_pose is not None:                       # simulator.py:679-688
@@ -225,7 +229,8 @@ class BatchedSimulator:
             return
         # The device evaluates candidates against each env's *current* world; a map switch
         # or a first reset must create that world first: provisional reset at a dummy pose.
-        need_world = [e for e in pend if (not self._have_reset) or self.env_map[e] != self.init_states[e].map_id]
+        need_world = [e for e in pend if (not self._have_reset) or self.map_random
+                      or self.env_map[e] != (self.init_states[e].map_id & ~_ffi.MAP_RELOAD)]
         if need_world:
             mask = np.zeros(self.num_envs, np.uint8)
             for e in need_world:
@@ -233,6 +238,8 @@ class BatchedSimulator:
                 self.init_states[e].pos[:] = [0.0, 0.0, 0.0]
                 self.init_states[e].angle = 0.0
             self._reset_device(mask)
+            for e in need_world:                               # the objects are fresh now: the final reset must keep them
+                self.init_states[e].map_id &= ~_ffi.MAP_RELOAD
         self._write_visibility({e: pend[e][2] for e in pend})
         active = dict(pend)
         while active:
@@ -284,7 +291,7 @@ class BatchedSimulator:
         _ffi.check(self._lib, self._lib.dtsim_reset(self._h, mp, self.init_states))
         sel = range(self.num_envs) if mask is None else np.flatnonzero(mask)
         for e in sel:
-            self.env_map[e] = self.init_states[e].map_id
+            self.env_map[e] = self.init_states[e].map_id & ~_ffi.MAP_RELOAD
         self._have_reset = True
 
     def reset(self, mask: Optional[np.ndarray] = None, states=None):

@@ -13,7 +13,7 @@ It is an N=1 view of dtsim.BatchedSimulator: every number comes from the GPU ker
 handle that copies the state; `segment=True` is the segmentation render.
 
 Not provided (out of scope): the pyglet window itself (nothing is displayed), the `draw_bbox` /
-`draw_curve` line overlays, LEDs, `randomize_maps_on_reset`, `camera_rand`'s carnivalmirror calibration sampling.
+`draw_curve` line overlays, LEDs, `camera_rand`'s carnivalmirror calibration sampling.
 """
 from __future__ import annotations
 
@@ -104,8 +104,8 @@ class Simulator(_EnvBase):
                  camera_rand: bool = False, randomize_maps_on_reset: bool = False, num_tris_distractors: int = 12,
                  color_ground: Sequence[float] = (0.15, 0.15, 0.15), color_sky: Sequence[float] = BLUE_SKY,
                  style: str = "photos", enable_leds: bool = False, device: int = 0, **env_kwargs):
-        if draw_curve or draw_bbox or randomize_maps_on_reset or enable_leds or camera_rand:
-            raise NotImplementedError("draw_curve / draw_bbox / randomize_maps_on_reset / enable_leds / camera_rand "
+        if draw_curve or draw_bbox or enable_leds or camera_rand:
+            raise NotImplementedError("draw_curve / draw_bbox / enable_leds / camera_rand "
                                       "are outside the hot path this backend implements")
         self.enable_leds = enable_leds
         self.seed_value = seed
@@ -128,10 +128,15 @@ class Simulator(_EnvBase):
         self.dynamics_rand = dynamics_rand
         self.user_tile_start = user_tile_start
         self.style = style
-        self.randomize_maps_on_reset = False
+        self.randomize_maps_on_reset = bool(randomize_maps_on_reset)
+        maps_arg = map_name
+        if self.randomize_maps_on_reset:                 # simulator.py:373-378: every map but calibration* / regress*
+            self.map_names = self._all_map_names(env_kwargs.get("asset_root"))
+            maps_arg = list(self.map_names)
+            env_kwargs = dict(env_kwargs, map_random=True)
         try:
             self._sim = BatchedSimulator(
-                map_name, 1, max_steps=max_steps, domain_rand=domain_rand, frame_rate=frame_rate, frame_skip=frame_skip,
+                maps_arg, 1, max_steps=max_steps, domain_rand=domain_rand, frame_rate=frame_rate, frame_skip=frame_skip,
                 camera_width=camera_width, camera_height=camera_height, robot_speed=robot_speed,
                 accept_start_angle_deg=accept_start_angle_deg, user_tile_start=user_tile_start, seed=seed,
                 distortion=self.distortion, dynamics_rand=dynamics_rand, num_tris_distractors=num_tris_distractors,
@@ -139,30 +144,53 @@ class Simulator(_EnvBase):
                 device=device, style=style, do_reset=False, **env_kwargs)
         except KeyError as e:
             raise InvalidMapException("Cannot load map data", map_name=map_name) from e
-        mt = self._sim.maps[0]
+        self._bind_map(0)
+        self.cam_offset = np.array([0, 0, 0])
+        self.reset()
+        self.last_action = np.array([0, 0])
+        self.wheelVels = np.array([0, 0])
+
+    @staticmethod
+    def _all_map_names(asset_root=None):
+        """The map list randomize_maps_on_reset draws from (simulator.py:373-378), sorted, and capped at the
+        library's DTSIM_MAX_MAPS resident maps."""
+        import os
+        from dtsim import assets
+        lib = assets.AssetLibrary(asset_root)
+        if lib.root:
+            names = sorted({os.path.splitext(os.path.basename(p))[0] for p in lib._files
+                            if p.endswith(".yaml") and os.path.basename(os.path.dirname(p)) == "maps"})
+        else:
+            names = sorted(assets.MAPS)
+        names = [n for n in names if not n.startswith(("calibration", "regress"))]
+        if len(names) > _ffi.MAX_MAPS:
+            logger.warning(f"randomize_maps_on_reset: {len(names)} maps found, keeping the first {_ffi.MAX_MAPS} (DTSIM_MAX_MAPS)")
+            names = names[:_ffi.MAX_MAPS]
+        return names
+
+    def _bind_map(self, idx: int):
+        """Point the map-dependent attributes (simulator.py:_load_map / _interpret_map) at map `idx` of the handle."""
+        mt = self._sim.maps[idx]
+        self._map_idx = idx
         self._mt = mt
         self.map_name = mt.name
         self.road_tile_size = mt.tile_size
         self.grid_width, self.grid_height = mt.grid_w, mt.grid_h
         self.grid = []
-        for idx, kind in enumerate(mt.tile_kind_names):
+        for ti, kind in enumerate(mt.tile_kind_names):
             if kind is None:
                 self.grid.append(None)
                 continue
-            t = {"coords": (idx % mt.grid_w, idx // mt.grid_w), "kind": kind, "angle": int(mt.tile_angle[idx]),
-                 "drivable": bool(mt.tile_curve_off[idx] >= 0)}
+            t = {"coords": (ti % mt.grid_w, ti // mt.grid_w), "kind": kind, "angle": int(mt.tile_angle[ti]),
+                 "drivable": bool(mt.tile_curve_off[ti] >= 0)}
             if t["drivable"]:
-                o, c = int(mt.tile_curve_off[idx]), int(mt.tile_curve_cnt[idx])
+                o, c = int(mt.tile_curve_off[ti]), int(mt.tile_curve_cnt[ti])
                 t["curves"] = mt.curves3[o:o + c]
             self.grid.append(t)
         self.drivable_tiles = [self.grid[j * mt.grid_w + i] for (i, j) in mt.drivable_tiles]
         self.objects = mt.objects
         self.start_tile = self._get_tile(*mt.start_tile) if mt.start_tile is not None else None
         self.start_pose = mt.start_pose
-        self.cam_offset = np.array([0, 0, 0])
-        self.reset()
-        self.last_action = np.array([0, 0])
-        self.wheelVels = np.array([0, 0])
 
     # ---------------------------------------------------------------- state views --
     def _f(self, field):
@@ -204,6 +232,11 @@ class Simulator(_EnvBase):
 
     def reset(self, segment: bool = False):
         self._sim.reset()
+        if int(self._sim.env_map[0]) != self._map_idx:   # randomize_maps_on_reset: _load_map(map_name) (simulator.py:541-544)
+            self._bind_map(int(self._sim.env_map[0]))
+            for v in getattr(self, "_viewers", {}).values():
+                v.close()
+            self._viewers = {}
         st = self._sim.init_states[0]
         es = self._sim.env_state[0]
         self.randomization_settings = es.settings
@@ -253,7 +286,7 @@ class Simulator(_EnvBase):
             return v
         if not hasattr(self, "_viewers"):
             self._viewers = {}
-        md = copy.deepcopy(self._sim.map_datas[0])
+        md = copy.deepcopy(self._sim.map_datas[self._map_idx])
         objs = md.get("objects") or []
         objs = [o for o in (list(objs.values()) if isinstance(objs, dict) else list(objs)) if o["kind"] != "floor_tag"]
         n_dyn = sum(1 for o in objs if not o.get("static", True))
@@ -267,7 +300,7 @@ class Simulator(_EnvBase):
                 marker["height"] = 0.12                               # the stand-in meshes are unit-height blobs
             objs.append(marker)
         md["objects"] = objs
-        v = BatchedSimulator(self._sim._ctor_map_names[0], 1, map_data=md, camera_width=WINDOW_WIDTH, camera_height=WINDOW_HEIGHT,
+        v = BatchedSimulator(self._sim._ctor_map_names[self._map_idx], 1, map_data=md, camera_width=WINDOW_WIDTH, camera_height=WINDOW_HEIGHT,
                              distortion=bool(distortion), domain_rand=True, seed=0, max_steps=self.max_steps,
                              frame_rate=self.frame_rate, device=self._sim._device, style=self.style,
                              asset_root=self._sim.library.root, do_reset=False)

@@ -171,10 +171,14 @@ typedef struct dtsim_mesh {
 /* Everything Simulator.reset() decides for one env (simulator.py:528-763).  Drawn on
  * the host in the reference's RNG order (dtsim/reset.py) -- or by the oracle in parity
  * tests -- and uploaded. */
+#define DTSIM_MAP_RELOAD 0x40000000
+
 typedef struct dtsim_init_state {
   double pos[3];            /* cur_pos  simulator.py:740 */
   double angle;             /* cur_angle simulator.py:741 */
-  int32_t map_id;
+  int32_t map_id;           /* index into dtsim_set_maps; | DTSIM_MAP_RELOAD: re-create the map's objects even if the env
+                               is already on this map (randomize_maps_on_reset reloads the map at every reset,
+                               simulator.py:541-544) */
   int32_t dynamics_trim_on; /* dynamics_rand: get_DB18_uncalibrated(trim) simulator.py:746-748 */
   double dynamics_trim;
   double wheel_dist;        /* simulator.py:597 */
@@ -271,7 +275,8 @@ typedef struct dtsim_reset_sampler {
   uint64_t seed;
   int32_t domain_rand;              /* draw camera / light / colour / wheel_dist perturbations */
   int32_t dynamics_rand;            /* apply the drawn trim (simulator.py:744-750) */
-  int32_t map_cycle;                /* MultiMapEnv: switch to the next map at every reset (multimap_env.py:44-49) */
+  int32_t map_cycle;                /* 1: MultiMapEnv, the next map at every reset (multimap_env.py:44-49);
+                                       2: randomize_maps_on_reset, a uniformly drawn map, reloaded (simulator.py:541-544) */
   int32_t max_attempts;             /* MAX_SPAWN_ATTEMPTS, 5000 */
   double accept_start_angle_deg;    /* simulator.py:724-728 */
   double color_sky[3], color_ground[3];

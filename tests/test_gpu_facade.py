@@ -182,3 +182,47 @@ def test_render_modes_window_views_match_oracle():
     seg = env.render("top_down", segment=True)
     assert (seg == np.array([255, 0, 255], np.uint8)).all(-1).mean() > 0.05
     env.close()
+
+
+def test_randomize_maps_on_reset():
+    """simulator.py:373-378, 541-544: every reset first draws a map (np_random.choice == integers(0, n)) and reloads it."""
+    from gym_duckietown.envs import DuckietownEnv
+    from gym_duckietown.simulator import get_agent_corners
+    from dtsim import assets
+    env = DuckietownEnv(randomize_maps_on_reset=True, seed=3, domain_rand=False, camera_width=160, camera_height=120)
+    names = env.map_names
+    assert names == sorted(assets.MAPS) and len(names) >= 3
+    assert env.map_name == names[int(np.random.default_rng(3).integers(0, len(names)))]      # the constructor's reset
+    seen = set()
+    for _ in range(24):
+        obs = env.reset()
+        seen.add(env.map_name)
+        md = assets.get_map(env.map_name)
+        assert (env.grid_height, env.grid_width) == (len(md["tiles"]), len(md["tiles"][0]))
+        assert obs.shape == (120, 160, 3) and 0 < obs.mean() < 255
+        assert env._valid_pose(env.cur_pos, env.cur_angle, 1.3)
+        assert not env._collision(get_agent_corners(env.cur_pos, env.cur_angle))
+        env.step(np.array([0.3, 0.3]))
+    assert len(seen) >= 3
+    env.close()
+
+
+def test_batched_random_maps_device_sampler():
+    from dtsim import assets
+    names = sorted(assets.MAPS)
+    N = 1024
+    sim = BatchedSimulator(names, N, render=False, domain_rand=False, seed=5, device_reset=True, map_random=True)
+    m0 = sim.read(_ffi.FIELD_MAP_ID).copy()
+    cnt = np.bincount(m0, minlength=len(names))
+    assert cnt.min() > 0.6 * N / len(names)                      # uniform over the maps
+    sim.reset()
+    m1 = sim.read(_ffi.FIELD_MAP_ID)
+    assert (m1 != m0).mean() > 0.5                               # a fresh draw per reset
+    pos, ang = sim.read(_ffi.FIELD_POS), sim.read(_ffi.FIELD_ANGLE)
+    pr = sim.query(np.arange(N, dtype=np.int32), np.stack([pos[:, 0], pos[:, 2], ang], 1), safety_factor=1.3)
+    assert pr["valid"].all() and pr["in_lane"].all() and not pr["inconvenient"].any()
+    # the reload re-creates the walking duckies: none is mid-walk right after a reset, even where the map did not change
+    sim.step(np.zeros((300, N, 2), np.float32), n_steps=300)
+    sim.reset()
+    assert not sim.read(_ffi.FIELD_OBJ_ACTIVE).any()
+    sim.close()
