@@ -262,6 +262,11 @@ def main():
             "episodes_per_env": done_frac,
             "setup_s": t_setup,
         }
+        try:                                   # RCCL's version banner sits in the C stdio buffer until exit: push it out
+            import ctypes                      # first, so that the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
 
     # ---- optional: frame all-gather over RCCL/xGMI (north star; link-bound, not in `value`)
@@ -299,6 +304,39 @@ def main():
             gather = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "steps": ks,
                       "collective": "all_gather_into_tensor(uint8 frames)", "bytes_per_rank_per_step": int(frames.numel())}
             del out
+            # what a learner on rank 0 needs: gather-to-root instead of all-gather, double-buffered so
+            # that the exchange of step t overlaps the simulation of step t+1 (the sim runs on its own HIP stream;
+            # only the buffer about to be overwritten is waited for)
+            try:
+                bufs = [torch.empty_like(frames) for _ in range(2)]
+                roots = [[torch.empty_like(frames) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+                works = [None, None]
+                kp = min(K, 6)
+                sync_all()
+                tg = time.perf_counter()
+                for t in range(kp):
+                    b = t % 2
+                    if works[b] is not None:
+                        works[b].wait()
+                        torch.cuda.current_stream().synchronize()
+                    sim.bind_frames(bufs[b].data_ptr())
+                    one_step(Wm + t)
+                    sim.sync()
+                    works[b] = dist.gather(bufs[b], roots[b], dst=0, async_op=True)
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg
+                sim.bind_frames(None)
+                tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+                dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
+                gather["to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
+                                                "collective": "gather(uint8 frames, dst=0), double-buffered against the next step"}
+                del bufs, roots
+            except Exception as ex:
+                sim.bind_frames(None)
+                gather["to_root_overlapped"] = {"error": repr(ex)[:200]}
             # the same exchange on what learners consume: 160x120 observations made on the device
             # (dtsim_observe, PIL-exact bilinear): 16x fewer bytes over xGMI
             obs = torch.as_tensor(sim.observe(120, 160), device=dev)
