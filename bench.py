@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--cpu-steps", type=int, default=8, help="oracle env-steps for cpu_baseline")
+    ap.add_argument("--cpu-steps", type=int, default=32, help="oracle env-steps for cpu_baseline (about 15 s on one host core)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="give up on the frame exchange after this many seconds")
     ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5"],
