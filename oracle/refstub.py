@@ -191,7 +191,7 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
     return ns
 
 
-def ref_objmesh(obj_path: str, mesh_name: str, resolve, change_materials=None):
+def ref_objmesh(obj_path: str, mesh_name: str, resolve, change_materials=None, segment=False):
     """Run the reference's own ObjMesh parser (objmesh.py:55-358) on `obj_path`.  pyglet's vertex
     lists are captured instead of created, `get_resource_path` is `resolve` (basename -> path or
     None => KeyError, like duckietown_world), textures are recorded by path.  Returns
@@ -212,9 +212,11 @@ def ref_objmesh(obj_path: str, mesh_name: str, resolve, change_materials=None):
 
     om.pyglet.graphics.vertex_list = vertex_list
     om.get_resource_path = get_resource_path
-    om.load_texture = lambda path, **kw: path
+    # segment=True (objmesh.py:255-292): record what every chunk asks load_texture for -- (path, segment flag,
+    # gen_segmentation_color(mesh_name)) -- instead of the path alone
+    om.load_texture = (lambda path, **kw: (path, kw.get("segment"), kw.get("segment_into_color"))) if segment else (lambda path, **kw: path)
     om.logger = MagicMock()
-    mesh = om.ObjMesh(obj_path, mesh_name, False, change_materials)
+    mesh = om.ObjMesh(obj_path, mesh_name, bool(segment), change_materials)
     cat = lambda key, w: np.concatenate([c[key].reshape(-1, 3, w) for c in chunks], axis=0)
     return dict(verts=cat("v3f", 3), uvs=cat("t2f", 2), normals=cat("n3f", 3), colors=cat("c3f", 3),
                 chunk_sizes=np.array([c["v3f"].size // 9 for c in chunks]), textures=list(mesh.textures),

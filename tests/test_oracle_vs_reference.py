@@ -62,3 +62,28 @@ def test_reference_fill_holes_equals_oracle_and_product():
     px, py = pd.distortion_maps(160, 120)
     assert np.array_equal(rx, ox) and np.array_equal(ry, oy)
     assert np.array_equal(rx, px) and np.array_equal(ry, py)
+
+
+def test_segmentation_rules_equal_the_reference(tmp_path):
+    """graphics.py:59-67 should_segment_out and objmesh.py:260-266 gen_segmentation_color (a closure inside
+    ObjMesh.__init__, observed through the colour it hands to load_texture) against dtsim/assets.py."""
+    ns = refstub.load()
+    paths = ["tiles-processed/photos/straight/texture.jpg", "tiles-processed/photos/curve_left/texture.jpg",
+             "tiles-processed/photos/curve_right/texture.jpg", "tiles-processed/photos/3way_left/texture.jpg",
+             "tiles-processed/photos/4way/texture.jpg", "tiles-processed/photos/asphalt/texture.jpg",
+             "tiles-processed/photos/grass/texture.jpg", "tiles-processed/photos/floor/texture.jpg",
+             "tiles-processed/synthetic/calibration/texture.png", "sign_left_T_intersect.png", "sign_4_way_intersect.png",
+             "trafficlight_card0.jpg", "duckie.png", "black_tile.png", "/data/highway/left.png", "bus.png", "/home/asphalt/straight.png"]
+    for p in paths:
+        assert assets.should_segment_out(p) == ns.graphics.should_segment_out(p), p
+    obj = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n"
+    for name in ["duckie", "duckiebot", "sign_generic", "trafficlight", "tree", "house", "bus", "cone", "truck", "barrier",
+                 "building", "object"]:
+        f = tmp_path / f"{name}.obj"
+        f.write_text(obj)
+        (tmp_path / "black_tile.png").write_bytes(b"")
+        res = {"black_tile.png": str(tmp_path / "black_tile.png")}
+        r = refstub.ref_objmesh(str(f), name, lambda bn, _r=res: _r.get(bn), segment=True)
+        (path, seg, col), = r["textures"]                          # untextured chunk -> the black_tile hack with the name's colour
+        assert seg is True and path.endswith("black_tile.png")
+        assert list(col) == assets.gen_segmentation_color(name), name
