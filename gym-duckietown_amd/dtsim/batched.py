@@ -42,6 +42,7 @@ class BatchedSimulator:
                  map_cycle: bool = False, map_random: bool = False, transform_uses_width: bool = False,
                  map_data: Optional[dict] = None,
                  asset_root: Optional[str] = None, style: str = "photos", device_reset: bool = False,
+                 undistort: bool = False,
                  do_reset: bool = True):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
@@ -148,8 +149,12 @@ class BatchedSimulator:
         for i, mt in enumerate(self.maps):
             farr[i] = mt.to_ffi(mesh_ids, self.light_tex if render else (-1, -1))
         _ffi.check(self._lib, self._lib.dtsim_set_maps(self._h, farr, len(self.maps)))
+        self.undistort = bool(undistort and distortion)
         if render and distortion:
-            rmx, rmy = dist_mod.distortion_maps(self.camera_width, self.camera_height)
+            # undistort=True: UndistortWrapper(env) -- the simulator's fisheye is skipped (env.undistort, simulator.py:1969)
+            # and the wrapper's rectify map is the per-pixel source map instead (wrappers.py:209-227)
+            rmx, rmy = (dist_mod.undistort_wrapper_maps if self.undistort else dist_mod.distortion_maps)(
+                self.camera_width, self.camera_height)
             self.rmapx, self.rmapy = rmx, rmy
             _ffi.check(self._lib, self._lib.dtsim_set_distortion_lut(
                 self._h, rmx.ctypes.data_as(C.POINTER(C.c_float)), rmy.ctypes.data_as(C.POINTER(C.c_float))))

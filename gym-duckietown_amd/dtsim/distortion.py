@@ -160,3 +160,15 @@ def distortion_maps(width: int, height: int):
     rx, ry = invert_map(mapx, mapy)
     rx, ry = fill_holes(rx, ry)
     return np.ascontiguousarray(rx, np.float32), np.ascontiguousarray(ry, np.float32)
+
+
+# UndistortWrapper (src/gym_duckietown/wrappers.py:145-227): the wrapper turns the simulator's own fisheye off
+# (`env.undistort = True`) and remaps the rectilinear render with initUndistortRectifyMap(K, D, I, P) / INTER_NEAREST.
+UNDISTORT_P = np.array([[220.2460277141687, 0, 301.8668918355899], [0, 238.6758484095299, 227.0880056118307], [0, 0, 1.0]])
+
+
+def undistort_wrapper_maps(width: int, height: int):
+    """(mapx, mapy) float32 [height,width] of UndistortWrapper._undistort (wrappers.py:209-227).  Installed as the
+    raster's per-pixel source map (`BatchedSimulator(distortion=True, undistort=True)`) they give the wrapped
+    observation in the one render pass -- the same folding as the fisheye remap."""
+    return rectify_maps(CAMERA_MATRIX, DIST_COEFS, UNDISTORT_P, (width, height))

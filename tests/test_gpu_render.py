@@ -306,3 +306,28 @@ def test_segment_render_matches_oracle(map_name, W, H, distortion, dr):
         obj = cols["duckie"].astype(int)
         n_obj_px += int((np.abs(frames[e].astype(int) - obj).max(-1) <= 60).sum())
     sim.close()
+
+
+def test_undistort_wrapper_folded_into_the_raster():
+    """UndistortWrapper (wrappers.py:145-227) = render without the fisheye, then cv2.remap(INTER_NEAREST) through
+    initUndistortRectifyMap(K, D, I, P).  With `undistort=True` the wrapper's map is the raster's source map: the
+    device frame must equal the host wrapper applied to the device's rectilinear frame, byte for byte."""
+    from gym_duckietown.wrappers import UndistortWrapper
+    N, W, H = 3, 640, 480
+    kw = dict(camera_width=W, camera_height=H, domain_rand=False, seed=21)
+    plain = BatchedSimulator("loop_only_duckies", N, distortion=False, **kw)
+    und = BatchedSimulator("loop_only_duckies", N, distortion=True, undistort=True, **kw)
+    acts = np.random.default_rng(2).uniform(0.2, 0.8, (5, N, 2)).astype(np.float32)
+    for s_ in (plain, und):
+        s_.step(acts, n_steps=5)
+        s_.render()
+    assert np.array_equal(plain.read(_ffi.FIELD_POS), und.read(_ffi.FIELD_POS))
+    rect, got = plain.frames_host(), und.frames_host()
+    w = UndistortWrapper.__new__(UndistortWrapper)
+    w.mapx = w.mapy = None
+    mx, my = pdist.undistort_wrapper_maps(W, H)
+    assert np.array_equal(np.stack(w._maps(H, W)), np.stack([mx, my]))          # the two host statements agree
+    for e in range(N):
+        assert np.array_equal(w.observation(rect[e]), got[e]), e
+    assert (got.reshape(N, -1, 3).sum(-1) == 0).mean() > 0.01                      # BORDER_CONSTANT corners
+    plain.close(); und.close()
