@@ -15,7 +15,7 @@ is measured separately (`gather`, xGMI-link bound) and never part 
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (dominant kernel = the raster; achieved = algorithmic bytes / HIP-event kernel time) and
-`cpu_baseline` (the oracle, 1 host core, bounded sample; N=1 only).
+`cpu_baseline` (the oracle on 1 host core, plus `all_cores`: one env per process; bounded samples; N=1 only).
 """
 from __future__ import annotations
 
@@ -36,19 +36,22 @@ W, H = 640, 480
 FRAME_BYTES = W * H * 3    # algorithmic bytes per env-step: the frame, written once
 
 
-def cpu_baseline(n_steps: int):
-    """The oracle (kind "port") on ONE host core: full Simulator.step incl. software raster
-    and fisheye remap, same map / resolution / action distribution, bounded sample."""
+def _oracle_env_steps(job):
+    """n oracle env-steps of one env (full Simulator.step incl. software raster and fisheye remap); returns the
+    seconds the stepping took.  Top-level so that multiprocessing's spawn context can import it."""
+    n_steps, seed = job
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, "1")               # one core per env, as the reference scales (one env per process)
     from dtsim import assets
     from dtsim import distortion as pdist
     from oracle import raster, sim as osim
     ext = assets.mesh_extents(("duckie",))
-    o = osim.OracleSim(assets.get_map("small_loop"), ext, domain_rand=False, seed=1000)
+    o = osim.OracleSim(assets.get_map("small_loop"), ext, domain_rand=False, seed=seed)
     kinds = {t["kind"] for t in o.map.grid if t is not None}
     scene = raster.Scene(o.map, {k: assets.get_texture(k) for k in kinds},
                          {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")})
     rmap = pdist.distortion_maps(W, H)
-    rng = np.random.default_rng(1234)
+    rng = np.random.default_rng(1234 + seed)
     t0 = time.perf_counter()
     for _ in range(n_steps):
         a = rng.uniform(-1, 1, 2)
@@ -58,10 +61,31 @@ def cpu_baseline(n_steps: int):
         raster.render_obs(cam, scene, "gouraud", rmap)
         if done:
             o.reset()
-    dt = time.perf_counter() - t0
-    return {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_steps} env-steps of small_loop 640x480 + fisheye on the numpy oracle (oracle/sim.py + oracle/raster.py); "
-                      "the reference's Pyglet/OpenGL path is not runnable on this host (no pyglet/duckietown_world/GL)"}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(n_steps: int, all_cores_steps: int = 8):
+    """The oracle (kind "port") on the host: ONE core for `n_steps` env-steps (the headline `value`), and --
+    SURVEY 8(d) -- on all cores, one env per process, the only scaling the reference supports
+    (`all_cores`).  Same map / resolution / action distribution as the GPU workload, bounded samples."""
+    dt = _oracle_env_steps((n_steps, 1000))
+    out = {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{n_steps} env-steps of small_loop 640x480 + fisheye on the numpy oracle (oracle/sim.py + oracle/raster.py); "
+                     "the reference's Pyglet/OpenGL path is not runnable on this host (no pyglet/duckietown_world/GL)"}
+    procs = min(os.cpu_count() or 1, 64)
+    if all_cores_steps > 0 and procs > 1:
+        try:
+            import multiprocessing as mp
+            t0 = time.perf_counter()
+            with mp.get_context("spawn").Pool(procs) as pool:           # spawn: the parent holds a HIP context
+                spent = pool.map(_oracle_env_steps, [(all_cores_steps, 2000 + i) for i in range(procs)])
+            wall = time.perf_counter() - t0
+            out["all_cores"] = {"value": procs * all_cores_steps / max(spent), "unit": "env-steps/s", "cores": procs,
+                                "sample": f"{procs} processes x {all_cores_steps} env-steps, one env per process; "
+                                          f"stepping time of the slowest process (pool start-up excluded; wall {wall:.1f} s)"}
+        except Exception as ex:
+            out["all_cores"] = {"error": repr(ex)[:200]}
+    return out
 
 
 def main_c2(args):
