@@ -155,3 +155,14 @@ def test_dropin_facade_surface_imports_without_gpu():
     assert issubclass(DuckietownEnv, Simulator) and callable(MultiMapEnv.reset)
     assert np.array_equal(get_agent_corners(np.array([1.0, 0, 1.0]), 0.3), osim.get_agent_corners(np.array([1.0, 0, 1.0]), 0.3))
     assert np.array_equal(_actual_center(np.array([1.0, 0, 1.0]), 0.3), osim.actual_center(np.array([1.0, 0, 1.0]), 0.3))
+
+
+def test_bench_cpu_baseline_worker_runs():
+    """bench.py's cpu_baseline leg (the only place besides tests / smoke that may use the oracle) steps the oracle on
+    the host; one env-step here keeps the import path and the worker signature honest."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dt = bench._oracle_env_steps((1, 1000))
+    assert 0 < dt < 120
