@@ -16,6 +16,35 @@ pytestmark = pytest.mark.gpu
 FLOAT_TOL = 1e-9
 
 
+def _assert_queries(sim, o, poses, sf):
+    """dtsim_query vs the oracle for every pose: flags / tile / curve index bit-exact, floats within FLOAT_TOL."""
+    m = o.map
+    pr = sim.query(np.zeros(len(poses), np.int32), poses, safety_factor=sf)
+    nflag = nlane = 0
+    for q, (x, z, a) in enumerate(poses):
+        pos = np.array([x, 0, z])
+        i, j = m.get_grid_coords(pos)
+        assert (pr["tile_i"][q], pr["tile_j"][q]) == (i, j)
+        assert bool(pr["drivable"][q]) == o._drivable_pos(pos)
+        assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
+        assert bool(pr["valid"][q]) == o._valid_pose(pos, a, sf)
+        assert bool(pr["inconvenient"][q]) == o._inconvenient_spawn(pos)
+        nflag += int(pr["collision"][q])
+        assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
+        try:
+            lp = o.get_lane_pos2(pos, a)
+            assert pr["in_lane"][q] == 1
+            assert pr["curve_idx"][q] == o._last_curve[0] and pr["t"][q] == o._last_curve[1]
+            assert np.allclose([pr["dist"][q], pr["dot_dir"][q], pr["angle_rad"][q]], [lp[0], lp[1], lp[3]],
+                               rtol=0, atol=FLOAT_TOL)
+            assert abs(pr["angle_deg"][q] - lp[2]) <= 1e-7
+            nlane += 1
+        except osim.NotInLane:
+            assert pr["in_lane"][q] == 0
+        assert abs(pr["reward"][q] - o.compute_reward(pos, a, o.robot_speed)) <= 1e-8
+    return nflag, nlane
+
+
 @pytest.mark.parametrize("map_name", ["small_loop", "small_loop_only_duckies", "loop_only_duckies", "loop_pedestrians"])
 def test_query_matches_oracle(map_name):
     sim = BatchedSimulator(map_name, 2, render=False, domain_rand=False, seed=3)
@@ -25,30 +54,27 @@ def test_query_matches_oracle(map_name):
     cents = np.array([[ob.pos[0], ob.pos[2]] for ob in m.objects]) if m.objects else None
     poses = random_poses(rng, m.grid_width, m.grid_height, m.tile_size, 4000, cents)
     for sf in (1.0, 1.3):
-        pr = sim.query(np.zeros(len(poses), np.int32), poses, safety_factor=sf)
-        nflag = 0
-        for q, (x, z, a) in enumerate(poses):
-            pos = np.array([x, 0, z])
-            i, j = m.get_grid_coords(pos)
-            assert (pr["tile_i"][q], pr["tile_j"][q]) == (i, j)
-            assert bool(pr["drivable"][q]) == o._drivable_pos(pos)
-            assert bool(pr["collision"][q]) == o._collision(osim.get_agent_corners(pos, a))
-            assert bool(pr["valid"][q]) == o._valid_pose(pos, a, sf)
-            assert bool(pr["inconvenient"][q]) == o._inconvenient_spawn(pos)
-            nflag += int(pr["collision"][q])
-            assert abs(pr["prox"][q] - o.proximity_penalty2(pos, a)) <= FLOAT_TOL
-            try:
-                lp = o.get_lane_pos2(pos, a)
-                assert pr["in_lane"][q] == 1
-                assert pr["curve_idx"][q] == o._last_curve[0] and pr["t"][q] == o._last_curve[1]
-                assert np.allclose([pr["dist"][q], pr["dot_dir"][q], pr["angle_rad"][q]], [lp[0], lp[1], lp[3]],
-                                   rtol=0, atol=FLOAT_TOL)
-                assert abs(pr["angle_deg"][q] - lp[2]) <= 1e-7
-            except osim.NotInLane:
-                assert pr["in_lane"][q] == 0
-            assert abs(pr["reward"][q] - o.compute_reward(pos, a, o.robot_speed)) <= 1e-8
+        nflag, _ = _assert_queries(sim, o, poses, sf)
         if m.objects:
             assert nflag > 10  # the sample does exercise collisions
+    sim.close()
+
+
+def test_query_on_every_tile_kind_and_orientation():
+    """straight / curve_left / curve_right / 3way_left / 3way_right in all four orientations and 4way (2, 6 and 12
+    curves per tile, simulator.py:1151-1335); the oracle is pinned against the reference on this very map
+    (tests/test_oracle_vs_reference.py)."""
+    import copy
+    from util import junction_map, EXT
+    md = junction_map()
+    sim = BatchedSimulator("junctions", 2, map_data=copy.deepcopy(md), render=False, domain_rand=False, seed=3)
+    o = osim.OracleSim(copy.deepcopy(md), EXT, do_reset=False)
+    m = o.map
+    rng = np.random.default_rng(13)
+    cents = np.array([[ob.pos[0], ob.pos[2]] for ob in m.objects])
+    poses = random_poses(rng, m.grid_width, m.grid_height, m.tile_size, 6000, cents)
+    nflag, nlane = _assert_queries(sim, o, poses, 1.0)
+    assert nflag > 10 and nlane > 2000
     sim.close()
 
 

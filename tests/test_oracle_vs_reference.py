@@ -7,7 +7,7 @@ import pytest
 
 from dtsim import assets
 from oracle import refstub, sim as osim
-from util import EXT
+from util import EXT, junction_map
 
 pytestmark = pytest.mark.skipif(not refstub.available(), reason="reference tree not present")
 
@@ -87,3 +87,47 @@ def test_segmentation_rules_equal_the_reference(tmp_path):
         (path, seg, col), = r["textures"]                          # untextured chunk -> the black_tile hack with the name's colour
         assert seg is True and path.endswith("black_tile.png")
         assert list(col) == assets.gen_segmentation_color(name), name
+
+
+def test_every_tile_kind_and_orientation_against_the_reference():
+    """Curves, drivable flags, lane pose, valid pose, collision and proximity on a map holding every drivable tile kind
+    in every orientation -- the loop fixtures only have straights and curves."""
+    md = junction_map()
+    r, ns = _ref("junctions", md=md)
+    o = osim.OracleSim(copy.deepcopy(md), EXT, do_reset=False)
+    # curve tables: same control points, tile by tile
+    for j in range(r.grid_height):
+        for i in range(r.grid_width):
+            t = r._get_tile(i, j)
+            ot = o.map.get_tile(i, j)
+            if t is None:
+                assert ot is None
+                continue
+            assert t["drivable"] == ot["drivable"] and t["kind"] == ot["kind"] and t["angle"] == ot["angle"]
+            if t["drivable"]:
+                assert np.array_equal(np.asarray(t["curves"]), np.asarray(ot["curves"])), (i, j, t["kind"], t["angle"])
+    rng = np.random.default_rng(5)
+    n_lane = 0
+    for _ in range(3000):
+        pos = np.array([rng.uniform(-0.3, r.grid_width * 0.585 + 0.3), 0, rng.uniform(-0.3, r.grid_height * 0.585 + 0.3)])
+        a = rng.uniform(-7, 7)
+        assert r._drivable_pos(pos) == o._drivable_pos(pos)
+        assert r._valid_pose(pos, a) == o._valid_pose(pos, a)
+        assert r._collision(ns.simulator.get_agent_corners(pos, a)) == o._collision(osim.get_agent_corners(pos, a))
+        assert r.proximity_penalty2(pos, a) == o.proximity_penalty2(pos, a)
+        try:
+            lp = tuple(float(v) for v in r.get_lane_pos2(pos, a))
+        except ns.simulator.NotInLane:
+            lp = None
+        try:
+            lp2 = o.get_lane_pos2(pos, a)
+        except osim.NotInLane:
+            lp2 = None
+        assert lp == lp2
+        n_lane += lp is not None
+        cp, ct = r.closest_curve_point(pos, a)
+        ocp, oct = o.closest_curve_point(pos, a)
+        assert (cp is None) == (ocp is None)
+        if cp is not None:
+            assert np.array_equal(cp, ocp) and np.array_equal(ct, oct)
+    assert n_lane > 1000
