@@ -9,6 +9,7 @@ travel to the GPU box where /root/reference does not exist:
   ref_probes_<map>.npz   random poses -> get_grid_coords, _drivable_pos, _collision,
                          _valid_pose (sf 1.0 / 1.3), proximity_penalty2, get_lane_pos2,
                          compute_reward, _compute_done_reward  (unmodified reference code)
+  ref_probes_junctions.npz  the same on oracle/fixtures.py:junction_map (every tile kind in every orientation)
   ref_maps.npz           _interpret_map tables: curves, collidable corners/norms/centres/radii
   ref_resets.json        Simulator.reset() results per (map, domain_rand, seed): pose + DR values
   ref_duckie_walk.npz    DuckieObj.step trajectory (centre, active flag, y_rot) over 700 steps
@@ -70,8 +71,8 @@ def ref_sim(map_name, domain_rand=False, seed=None, md=None):
     return sim, ns
 
 
-def probes(map_name, n=1500, seed=7):
-    r, ns = ref_sim(map_name)
+def probes(map_name, n=1500, seed=7, md=None):
+    r, ns = ref_sim(map_name, md=md)
     rng = np.random.default_rng(seed)
     W, H, TS = r.grid_width, r.grid_height, r.road_tile_size
     poses = np.stack([rng.uniform(-0.2, W * TS + 0.2, n), rng.uniform(-0.2, H * TS + 0.2, n), rng.uniform(-4, 7, n)], 1)
@@ -118,6 +119,8 @@ def main():
             maps_out[f"{m}_centers"] = r.collidable_centers
             maps_out[f"{m}_radii"] = r.collidable_safety_radii
     np.savez_compressed(os.path.join(OUT, "ref_maps.npz"), **maps_out)
+    from oracle.fixtures import junction_map           # every tile kind x orientation (3-way / 4-way curve tables)
+    np.savez_compressed(os.path.join(OUT, "ref_probes_junctions.npz"), **probes("junctions", n=3000, seed=9, md=junction_map()))
 
     resets = []
     for m in MAPS:

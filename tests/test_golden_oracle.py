@@ -16,10 +16,14 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 MAPS = ["small_loop", "small_loop_only_duckies", "loop_only_duckies"]
 
 
-@pytest.mark.parametrize("m", MAPS)
+@pytest.mark.parametrize("m", MAPS + ["junctions"])
 def test_probes_bit_exact(m):
     g = np.load(os.path.join(G, f"ref_probes_{m}.npz"))
-    o = make_oracle(m, do_reset=False)
+    if m == "junctions":                           # every tile kind x orientation (oracle/fixtures.py)
+        from util import junction_map
+        o = osim.OracleSim(junction_map(), EXT, do_reset=False)
+    else:
+        o = make_oracle(m, do_reset=False)
     for q, (x, z, a) in enumerate(g["poses"]):
         pos = np.array([x, 0, z])
         assert tuple(g["tile"][q]) == o.map.get_grid_coords(pos)

@@ -46,15 +46,4 @@ def random_poses(rng, mt_w, mt_h, ts, n, centers=None):
     return pos
 
 
-def junction_map():
-    """Every drivable tile kind in every orientation (simulator.py:1151-1335 _get_curve: straight, curve_left/right,
-    3way_left/right, 4way), plus grass / asphalt / floor and an empty cell, and a few objects."""
-    o = ["S", "E", "N", "W"]
-    rows = []
-    for kind in ("straight", "curve_left", "curve_right", "3way_left", "3way_right"):
-        rows.append([f"{kind}/{d}" for d in o] + ["grass", "asphalt"])
-    rows.append(["4way", "4way", "floor", "empty", "grass", "4way"])
-    return {"tiles": rows, "tile_size": 0.585,
-            "objects": [{"kind": "duckie", "pos": [1.3, 0.4], "rotate": 30, "height": 0.08},
-                        {"kind": "cone", "pos": [4.6, 3.5], "rotate": -75, "height": 0.1, "static": True},
-                        {"kind": "duckie", "pos": [2.5, 4.5], "rotate": 120, "height": 0.08, "optional": True}]}
+from oracle.fixtures import junction_map  # noqa: E402,F401  (every tile kind x orientation)
