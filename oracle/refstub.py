@@ -114,6 +114,19 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
 
     sys.modules["gym"].Env = _Env
 
+    class _Wrapper:  # gym.Wrapper family: just enough for the reference's wrappers.py to be instantiated
+        def __init__(self, env=None):
+            self.env = env
+            self.observation_space = getattr(env, "observation_space", None)
+            self.action_space = getattr(env, "action_space", None)
+
+        @property
+        def unwrapped(self):
+            return getattr(self.env, "unwrapped", self.env)
+
+    for _n in ("Wrapper", "ActionWrapper", "ObservationWrapper", "RewardWrapper"):
+        setattr(sys.modules["gym"], _n, type(_n, (_Wrapper,), {}))
+
     class _ZException(Exception):
         def __init__(self, msg="", **kw):
             super().__init__(msg)
@@ -161,6 +174,7 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
         ns.distortion = importlib.import_module("gym_duckietown.distortion")
         ns.objmesh = importlib.import_module("gym_duckietown.objmesh")
         ns.randomizer = importlib.import_module("gym_duckietown.randomization.randomizer")
+        ns.wrappers = importlib.import_module("gym_duckietown.wrappers")
     finally:
         sys.path.remove(REFERENCE_SRC)
         # The reference package must not shadow the product's drop-in package

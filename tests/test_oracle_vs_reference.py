@@ -131,3 +131,46 @@ def test_every_tile_kind_and_orientation_against_the_reference():
         if cp is not None:
             assert np.array_equal(cp, ocp) and np.array_equal(ct, oct)
     assert n_lane > 1000
+
+
+def test_wrappers_equal_the_reference():
+    """src/gym_duckietown/wrappers.py run through the stub loader: the action wrappers' arithmetic, the observation
+    transpose, and the calibration constants UndistortWrapper / Distortion carry (cv2 itself is absent: the remaps stay
+    restatements)."""
+    import gym_duckietown.wrappers as mine
+    from dtsim import distortion as pdist
+    ns = refstub.load()
+    ref = ns.wrappers
+
+    class Env:
+        wheel_dist = 0.1093
+        distortion = True
+        undistort = False
+        observation_space = None
+        action_space = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+    rng = np.random.default_rng(4)
+    for a in range(3):
+        assert list(ref.DiscreteWrapper(Env()).action(a)) == list(mine.DiscreteWrapper(Env()).action(a))
+    for kw in ({}, dict(gain=1.3, trim=0.07, radius=0.03, k=25.0, limit=0.8)):
+        r, m = ref.SteeringToWheelVelWrapper(Env(), **kw), mine.SteeringToWheelVelWrapper(Env(), **kw)
+        for _ in range(200):
+            act = rng.uniform(-1.5, 1.5, 2)
+            assert np.array_equal(np.asarray(r.action(act), dtype=np.float64), np.asarray(m.action(act), dtype=np.float64))
+    obs = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    po = ref.PyTorchObsWrapper.__new__(ref.PyTorchObsWrapper)
+    assert np.array_equal(po.observation(obs), mine.PyTorchObsWrapper.observation(None, obs))
+    e = Env()
+    u = ref.UndistortWrapper(e)
+    assert e.undistort is True
+    assert np.array_equal(u.camera_matrix, mine.UndistortWrapper.K) and np.array_equal(u.camera_matrix, pdist.CAMERA_MATRIX)
+    assert np.array_equal(np.ravel(u.distortion_coefs), mine.UndistortWrapper.D) and np.array_equal(np.ravel(u.distortion_coefs), pdist.DIST_COEFS)
+    assert np.array_equal(u.projection_matrix, mine.UndistortWrapper.P) and np.array_equal(u.projection_matrix[:, :3], pdist.UNDISTORT_P)
+    ns.distortion.cv2.getOptimalNewCameraMatrix = lambda **kw: (None, None)      # cv2 is a stub here
+    d = ns.distortion.Distortion()
+    assert np.array_equal(d.camera_matrix, pdist.CAMERA_MATRIX) and np.array_equal(np.ravel(d.distortion_coefs), pdist.DIST_COEFS)
+    assert (d.W, d.H) == (640, 480)
