@@ -175,6 +175,7 @@ def load(mesh_extents=None, transform_uses_width: bool = False):
         ns.objmesh = importlib.import_module("gym_duckietown.objmesh")
         ns.randomizer = importlib.import_module("gym_duckietown.randomization.randomizer")
         ns.wrappers = importlib.import_module("gym_duckietown.wrappers")
+        ns.duckietown_env = importlib.import_module("gym_duckietown.envs.duckietown_env")
     finally:
         sys.path.remove(REFERENCE_SRC)
         # The reference package must not shadow the product's drop-in package

@@ -174,3 +174,36 @@ def test_wrappers_equal_the_reference():
     d = ns.distortion.Distortion()
     assert np.array_equal(d.camera_matrix, pdist.CAMERA_MATRIX) and np.array_equal(np.ravel(d.distortion_coefs), pdist.DIST_COEFS)
     assert (d.W, d.H) == (640, 480)
+
+
+def test_duckietown_env_kinematics_equal_the_reference():
+    """envs/duckietown_env.py:36-61: (vel, steering) -> [left, right] duty handed to Simulator.step, and the
+    `DuckietownEnv` info block; against the oracle's wheels_from_vel_steer (which the HIP k_step is checked against)."""
+    ns = refstub.load()
+    DE = ns.duckietown_env.DuckietownEnv
+    seen = {}
+
+    def fake_step(self, vels):
+        seen["vels"] = np.array(vels, dtype=np.float64)
+        return None, 0.0, False, {}
+
+    orig = ns.simulator.Simulator.step
+    ns.simulator.Simulator.step = fake_step
+    try:
+        rng = np.random.default_rng(8)
+        for kw in (dict(gain=1.0, trim=0.0, radius=0.0318, k=27.0, limit=1.0), dict(gain=1.4, trim=-0.05, radius=0.03, k=24.0, limit=0.7)):
+            env = DE.__new__(DE)
+            for k, v in kw.items():
+                setattr(env, k, v)
+            env.wheel_dist = 0.102 * 1.04
+            env.unwrapped = env                    # gym.Env.unwrapped (the stubbed gym.Env has none)
+            o = osim.OracleSim(assets.get_map("small_loop"), EXT, do_reset=False, **kw)
+            o.wheel_dist = env.wheel_dist
+            for _ in range(300):
+                act = rng.uniform(-1.6, 1.6, 2)
+                _, _, _, info = env.step(act)
+                mine = o.wheels_from_vel_steer(act)
+                assert np.array_equal(seen["vels"], np.asarray(mine, dtype=np.float64))
+                assert set(info["DuckietownEnv"]) == {"k", "gain", "train", "radius", "omega_r", "omega_l"}
+    finally:
+        ns.simulator.Simulator.step = orig
