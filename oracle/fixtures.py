@@ -14,4 +14,5 @@ def junction_map():
     return {"tiles": rows, "tile_size": 0.585,
             "objects": [{"kind": "duckie", "pos": [1.3, 0.4], "rotate": 30, "height": 0.08},
                         {"kind": "cone", "pos": [4.6, 3.5], "rotate": -75, "height": 0.1, "static": True},
-                        {"kind": "duckie", "pos": [2.5, 4.5], "rotate": 120, "height": 0.08, "optional": True}]}
+                        {"kind": "duckie", "pos": [2.5, 4.5], "rotate": 120, "height": 0.08, "optional": True},
+                        {"kind": "barrier", "pos": [3.4, 2.6], "rotate": 45, "scale": 0.17}]}     # `scale` form (simulator.py:978-985)

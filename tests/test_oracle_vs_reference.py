@@ -207,3 +207,28 @@ def test_duckietown_env_kinematics_equal_the_reference():
                 assert set(info["DuckietownEnv"]) == {"k", "gain", "train", "radius", "omega_r", "omega_l"}
     finally:
         ns.simulator.Simulator.step = orig
+
+
+@pytest.mark.parametrize("dr", [False, True])
+def test_reset_start_tile_branches(dr):
+    """reset()'s tile / pose selection branches (simulator.py:659-688): `user_tile_start`, the map's `start_tile`,
+    the map's `start_pose`; optional objects' visibility draw (:648-656) on the junction map."""
+    base = assets.get_map("loop_only_duckies")
+    cases = []
+    cases.append((copy.deepcopy(base), dict(user_tile_start=(1, 0))))
+    md = copy.deepcopy(base); md["start_tile"] = [2, 0]
+    cases.append((md, {}))
+    md = copy.deepcopy(base); md["start_tile"] = [1, 0]; md["start_pose"] = [[0.3, 0, 0.25], 1.2]
+    cases.append((md, {}))
+    jm = junction_map()                                    # has an `optional` object
+    jm["tiles"] = [[("grass" if c == "empty" else c) for c in row] for row in jm["tiles"]]   # the reference's reset() cannot
+    cases.append((jm, {}))                                  # iterate a grid with empty cells (simulator.py:634-637)
+    for md, kw in cases:
+        for seed in (3,):
+            r, _ = _ref("case", dr, seed, md=copy.deepcopy(md))
+            r.user_tile_start = kw.get("user_tile_start")
+            o = osim.OracleSim(copy.deepcopy(md), EXT, domain_rand=dr, seed=seed, do_reset=False, **kw)
+            for _ in range(3):
+                r.reset(); o.reset()
+                assert np.array_equal(r.cur_pos, o.cur_pos) and r.cur_angle == o.cur_angle
+                assert [bool(ob.visible) for ob in r.objects] == [bool(ob.visible) for ob in o.map.objects]
