@@ -134,6 +134,41 @@ def test_reset_rng_order_matches_oracle(map_name, dr):
     sim.close()
 
 
+@pytest.mark.parametrize("case", ["user_tile_start", "start_tile", "start_pose", "optional"])
+def test_reset_tile_and_pose_branches_match_oracle(case):
+    """reset()'s tile / pose selection (simulator.py:659-688) and the optional objects' visibility draws (:648-656)
+    on the host RNG-order path; the oracle is pinned on these branches against the reference
+    (tests/test_oracle_vs_reference.py::test_reset_start_tile_branches)."""
+    import copy
+    from dtsim import assets
+    from util import junction_map, EXT
+    md, kw = copy.deepcopy(assets.get_map("loop_only_duckies")), {}
+    if case == "user_tile_start":
+        kw = dict(user_tile_start=(1, 0))
+    elif case == "start_tile":
+        md["start_tile"] = [2, 0]
+    elif case == "start_pose":
+        md["start_tile"] = [1, 0]
+        md["start_pose"] = [[0.3, 0, 0.25], 1.2]
+    else:
+        md = junction_map()
+        md["tiles"] = [[("grass" if c == "empty" else c) for c in row] for row in md["tiles"]]   # as in the reference pin
+    N = 4
+    sim = BatchedSimulator("case", N, map_data=copy.deepcopy(md), render=False, domain_rand=True, seed=50, **kw)
+    oracles = [osim.OracleSim(copy.deepcopy(md), EXT, domain_rand=True, seed=50 + e, **kw) for e in range(N)]
+    for rep in range(2):
+        pos, ang = sim.read(_ffi.FIELD_POS), sim.read(_ffi.FIELD_ANGLE)
+        vis = sim.read(_ffi.FIELD_OBJ_VISIBLE)
+        for e, o in enumerate(oracles):
+            assert np.array_equal(pos[e], o.cur_pos), (case, rep, e, pos[e], o.cur_pos)
+            assert ang[e] == o.cur_angle
+            assert [bool(v) for v in vis[e][:len(o.map.objects)]] == [bool(ob.visible) for ob in o.map.objects]
+        sim.reset()
+        for o in oracles:
+            o.reset()
+    sim.close()
+
+
 def _run_traj(map_name, mode, N, T, seed, frame_skip=1, max_steps=1500, dr=False, actions_f64=False):
     sim = BatchedSimulator(map_name, N, render=False, domain_rand=dr, seed=seed, action_mode=mode,
                            frame_skip=frame_skip, max_steps=max_steps, actions_f64=actions_f64)
