@@ -232,3 +232,49 @@ def test_reset_start_tile_branches(dr):
                 r.reset(); o.reset()
                 assert np.array_equal(r.cur_pos, o.cur_pos) and r.cur_angle == o.cur_angle
                 assert [bool(ob.visible) for ob in r.objects] == [bool(ob.visible) for ob in o.map.objects]
+
+
+@pytest.mark.parametrize("m,steps", [("loop_pedestrians", (250, 300)), ("loop_dyn_duckiebots", (60, 240))])
+def test_collision_and_proximity_against_moving_objects(m, steps):
+    """_collision (static batch + every object's check_collision with its *stored* obj_norm, simulator.py:1473-1492,
+    objects.py:152-160, 272-281, 373-382), proximity_penalty2 and _inconvenient_spawn while DuckieObj pedestrians are
+    mid-walk / DuckiebotObj followers have driven away from their spawn."""
+    md = assets.get_map(m)
+    r, ns = _ref(m, md=copy.deepcopy(md))
+    if m == "loop_pedestrians":
+        for ob in r.objects:
+            ob.wiggle = np.pi / 15                       # the reference draws it from the global RNG (objects.py:362)
+    o = osim.OracleSim(copy.deepcopy(md), EXT, do_reset=False)
+    rng = np.random.default_rng(17)
+    t = 0
+    for t_end in steps:
+        while t < t_end:
+            for ob in r.objects:
+                if ob.kind == "duckiebot" and not ob.static:
+                    ob.step_duckiebot(1 / 30, r.closest_curve_point, r.objects)
+                elif not ob.static:
+                    ob.step(1 / 30)
+            for ob in o.map.objects:
+                if ob.kind == "duckiebot" and not ob.static:
+                    ob.step_duckiebot(1 / 30, o.closest_curve_point)
+                elif not ob.static:
+                    ob.step(1 / 30)
+            t += 1
+        moved = 0
+        for ro, oo in zip(r.objects, o.map.objects):
+            assert np.array_equal(np.asarray(ro.pos, float), np.asarray(oo.pos, float))
+            moved += int(not ro.static)
+        assert moved > 0
+        n_col = 0
+        for _ in range(600):
+            ob = r.objects[rng.integers(len(r.objects))]
+            c = np.asarray(ob.pos, float)
+            pos = np.array([c[0] + rng.uniform(-0.35, 0.35), 0, c[2] + rng.uniform(-0.35, 0.35)])
+            a = rng.uniform(-7, 7)
+            col = r._collision(ns.simulator.get_agent_corners(pos, a))
+            assert col == o._collision(osim.get_agent_corners(pos, a))
+            assert r._valid_pose(pos, a) == o._valid_pose(pos, a)
+            assert r.proximity_penalty2(pos, a) == o.proximity_penalty2(pos, a)
+            assert r._inconvenient_spawn(pos) == o._inconvenient_spawn(pos)
+            n_col += int(col)
+        assert n_col > 30
