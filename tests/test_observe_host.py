@@ -42,3 +42,16 @@ def test_observation_layouts():
     c = resample.observation(fr, 60, 80, chw=True, normalize=True)
     assert c.shape == (3, 3, 60, 80) and c.dtype == np.float32
     assert np.array_equal(c, o.transpose(0, 3, 1, 2).astype(np.float32) / np.float32(255))
+
+
+def test_resize_matches_pil_on_random_sizes():
+    """Fuzz: random source / target sizes (up- and down-scaling, extreme aspect changes, 1-pixel axes) against Pillow."""
+    from PIL import Image
+    rng = np.random.default_rng(123)
+    for _ in range(60):
+        H, W = int(rng.integers(1, 97)), int(rng.integers(1, 131))
+        oh, ow = int(rng.integers(1, 80)), int(rng.integers(1, 90))
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        got = resample.resize_bilinear(img, oh, ow)
+        assert np.array_equal(got, want), ((H, W), (oh, ow))
