@@ -24,6 +24,12 @@ def _has_gpu():
 
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
+        # a wedged kernel must not hold the GPU box until the harness kills it: bound every GPU test
+        # (the whole `-m gpu` suite takes ~75 s; pytest-timeout's thread method ends the process)
+        if config.pluginmanager.hasplugin("timeout"):
+            for it in items:
+                if "gpu" in it.keywords and it.get_closest_marker("timeout") is None:
+                    it.add_marker(pytest.mark.timeout(300, method="thread"))
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for it in items:
