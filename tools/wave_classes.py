@@ -36,7 +36,8 @@ def pixel_classes(cam, scene, sx, sy, valid):
     tg, gx, gz = raster._plane_hit(cam, xe, fwd, yla, cam.C[1] - raster.GROUND_Y)
     gok = down & (tg >= raster.NEAR) & (tg <= raster.FAR) & (np.abs(gx) <= raster.GROUND_HALF) & (np.abs(gz) <= raster.GROUND_HALF)
     cls = np.where(tok, 3, np.where(gok, 2, 1))
-    return np.where(valid, cls, 0)
+    key = np.where(tok, 16 + jj * 64 + ii, cls)            # primitive id: the tile, or sky / ground
+    return np.where(valid, cls, 0), np.where(valid, key, 0)
 
 
 def main():
@@ -52,6 +53,12 @@ def main():
     names = ["border/sky only", "ground only (+sky)", "tile only (+sky)", "tile + ground"]
     tot = np.zeros(4)
     px = np.zeros(4)
+    edge_px = 0.0
+    edge_blk_any = tile_blks = 0
+
+    def blk_is_tile(cls):
+        b = cls.reshape(H // BH, BH, W // BW, BW).transpose(0, 2, 1, 3).reshape(-1, BH * BW)
+        return (b == 3).any(1)
     for k in range(n):
         o.reset()
         for _ in range(int(rng.integers(0, 40))):
@@ -60,7 +67,14 @@ def main():
             if done:
                 o.reset()
         cam = raster.Camera(o.cur_pos, o.cur_angle, width=W, height=H)
-        cls = pixel_classes(cam, scene, sx, sy, valid)
+        cls, key0 = pixel_classes(cam, scene, sx, sy, valid)
+        # a pixel needs the exact 4-sample path when its MSAA samples do not all see the same primitive
+        edge = np.zeros((H, W), bool)
+        for (ox, oy) in raster.SAMPLE_OFFSETS:
+            _, ks = pixel_classes(cam, scene, sx + ox, sy + oy, valid)
+            edge |= ks != key0
+        eblk = edge.reshape(H // BH, BH, W // BW, BW).transpose(0, 2, 1, 3).reshape(-1, BH * BW)
+        edge_px += edge.mean(); edge_blk_any += (eblk.any(1) & (blk_is_tile(cls))).sum(); tile_blks += blk_is_tile(cls).sum()
         blk = cls.reshape(H // BH, BH, W // BW, BW).transpose(0, 2, 1, 3).reshape(-1, BH * BW)
         has_t, has_g = (blk == 3).any(1), (blk == 2).any(1)
         kind = np.where(has_t & has_g, 3, np.where(has_t, 2, np.where(has_g, 1, 0)))
@@ -71,6 +85,8 @@ def main():
     for nm, f in zip(names, tot):
         print(f"  {nm:22s} {100 * f:5.1f} % of the blocks")
     print("  pixels: border %.1f %%, sky %.1f %%, ground %.1f %%, tile %.1f %%" % tuple(100 * px))
+    print(f"  pixels whose 4 MSAA samples see different primitives: {100 * edge_px / n:.2f} %; "
+          f"{100 * edge_blk_any / max(tile_blks, 1):.1f} % of the blocks with tile pixels contain at least one")
 
 
 if __name__ == "__main__":
