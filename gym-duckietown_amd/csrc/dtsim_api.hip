@@ -91,6 +91,12 @@ struct dtsim {
   ScreenTri* d_stris = nullptr;
   ObjEnv* d_objenv = nullptr;
   ObjBox* d_objbox = nullptr;
+  std::vector<uint32_t> h_pool;       // host copy of the RGBA8 pool (quad blocks are built from it at dtsim_set_maps)
+  void* d_pixtab = nullptr;           // per-pixel tables of the shared camera (k_pix_setup)
+  uint8_t* d_qtex = nullptr;          // quad-layout blocks for k_raster_q
+  uint32_t* d_qtiles = nullptr;
+  int n_qtiles = 0, qlog2 = 0;
+  float q_per_m = 0.f;
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
   uint32_t* d_items = nullptr;
@@ -235,10 +241,11 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(frames %zu B): %s", h->frames_bytes, hipGetErrorString(e)); }
     h->frames = h->frames_own;
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
-    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64));   // EnvCam[N] then EnvFast[N]
+    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64));   // EnvCam[N], EnvFast[N], EnvQ[N]
+    if (e == hipSuccess) e = hipMalloc(&h->d_pixtab, (size_t)cfg->cam_height * cfg->cam_width * 64 + 1024);   // PixTab + SampTab + 1 KB store dump
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
-      const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + 31) / 32);
-      if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * 256 * 32 * sizeof(uint16_t));
+      const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
+      if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
       if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * DT_ITEMS_PER_WG * sizeof(uint32_t));
     }
@@ -263,7 +270,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -299,6 +306,7 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
   std::vector<uint32_t> pool;
   h->h_tex.clear();
   if (int rc = build_texel_pool(textures, n_textures, pool, &h->h_tex)) return rc;
+  h->h_pool = pool;
   if (h->d_texels_seg) { (void)hipFree(h->d_texels_seg); h->d_texels_seg = nullptr; }   // mirrors the old list
   if (h->d_texels) { (void)hipFree(h->d_texels); h->d_texels = nullptr; }
   if (h->d_tex) { (void)hipFree(h->d_tex); h->d_tex = nullptr; }
@@ -370,6 +378,36 @@ int dtsim_set_segment_assets(dtsim_t* h, const dtsim_texture* textures, int n_te
   HIPCHK(hipMalloc(&h->d_mesh_seg, rgbx.size()));
   HIPCHK(hipMemcpy(h->d_mesh_seg, rgbx.data(), rgbx.size(), hipMemcpyHostToDevice));
   return DTSIM_OK;
+}
+
+// One quad block (S x S records of 16 B) of a tile texture pre-rotated by the tile angle (render.hip k_raster_q).
+// Cell (x0, z0) covers the padded-quad coordinates [x0, x0+1) x [z0, z0+1) of the tile, i.e. the GL_LINEAR taps
+// P[z0-1][x0-1], P[z0-1][x0], P[z0][x0-1], P[z0][x0] (GL_REPEAT wrap) of the tile-frame image P with
+// P[zz][xx] = T[y][x], (x, y) the texel the tile-local point ((xx+.5)/S, (zz+.5)/S) maps to under glRotatef(angle*90+180)
+// and uv = (pu, 1-pv) (simulator.py:394-401,1872-1873): u = {1-fx, fz, fx, 1-fz}[angle], v = {fz, fx, 1-fz, 1-fx}[angle].
+// `pool` holds T padded to (S+1) x (S+1).  Meta dword: cells to the nearest tile boundary (DT_QMETA, dtsim_dev.h).
+static void build_quad_block(std::vector<uint32_t>& out, const uint32_t* pool, int S, int ang) {
+  const size_t base = out.size();
+  out.resize(base + (size_t)S * S * 4);
+  auto texel = [&](int xx, int zz) -> uint32_t {
+    xx &= S - 1; zz &= S - 1;
+    int x, y;
+    switch (ang & 3) {
+      case 0: x = S - 1 - xx; y = zz; break;
+      case 1: x = zz; y = xx; break;
+      case 2: x = xx; y = S - 1 - zz; break;
+      default: x = S - 1 - zz; y = S - 1 - xx; break;
+    }
+    return pool[(size_t)y * (S + 1) + x];
+  };
+  for (int z0 = 0; z0 < S; ++z0)
+    for (int x0 = 0; x0 < S; ++x0) {
+      const uint32_t t00 = texel(x0 - 1, z0 - 1), t10 = texel(x0, z0 - 1), t01 = texel(x0 - 1, z0), t11 = texel(x0, z0);
+      uint32_t* q = &out[base + ((size_t)z0 * S + x0) * 4];
+      for (int c = 0; c < 3; ++c)
+        q[c] = ((t00 >> (8 * c)) & 255u) | (((t10 >> (8 * c)) & 255u) << 8) | (((t01 >> (8 * c)) & 255u) << 16) | (((t11 >> (8 * c)) & 255u) << 24);
+      q[3] = (uint32_t)std::min(std::min(std::min(x0, S - x0), std::min(z0, S - z0)), 0xFFFF);
+    }
 }
 
 int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
@@ -507,15 +545,63 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     }
     h->map_n_dyn[mi] = n_dyn; h->map_n_obj[mi] = mp.n_objects;
   }
+  // ---- quad-layout fast path tables: possible when every tile texture is one square power-of-two size
+  std::vector<uint32_t> qblocks, qtiles;
+  int qlog2 = -1;
+  float q_per_m = 0.f;
+  if ((h->cfg.flags & DTSIM_F_RENDER) && tex_w == tex_h && tex_w >= 2) {
+    const int S = tex_w;
+    qlog2 = 0; while ((1 << qlog2) < S) ++qlog2;
+    std::vector<int> block_of((size_t)std::max(h->n_tex, 1) * 4, -1);
+    // the two one-record blocks: off-grid (meta high half 1) and untextured (meta 0); then the S x S blocks
+    const uint32_t special[8] = {0u, 0u, 0u, 1u << 16, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};   // untextured: white vertex colour
+    qblocks.assign(special, special + 8);
+    const size_t block_bytes = (size_t)S * S * 16;
+    const uint32_t cell_sel = (qlog2 == 8) ? 0x0c0c0400u : (uint32_t)(S * S - 1);   // v_perm selector (S = 256) / cell mask
+    const uint32_t zero_sel = (qlog2 == 8) ? 0x0c0c0c0cu : 0u;
+    int n_blocks = 0;
+    for (int mi = 0; mi < n_maps; ++mi) {
+      const dtsim_map& mp = maps[mi];
+      RenderMapDev& rm = rmaps[mi];
+      rm.qt_off = (int32_t)(qtiles.size() / 2); rm.qt_pitch = mp.grid_w + 2 * DT_QRING;
+      q_per_m = std::max(q_per_m, (float)((double)S / mp.tile_size));
+      for (int j = -DT_QRING; j < mp.grid_h + DT_QRING; ++j)
+        for (int i = -DT_QRING; i < mp.grid_w + DT_QRING; ++i) {
+          uint32_t off = 0u, sel = zero_sel;        // record 0: off-grid
+          if (i >= 0 && j >= 0 && i < mp.grid_w && j < mp.grid_h) {
+            const int t = j * mp.grid_w + i;
+            if (mp.tile_kind[t] != DTSIM_TILE_EMPTY) {
+              const int tx = mp.tile_tex[t];
+              if (tx < 0 || tx >= (int)h->h_tex.size()) off = 16u;   // record 1: present but untextured
+              else {
+                int& b = block_of[(size_t)tx * 4 + (mp.tile_angle[t] & 3)];
+                if (b < 0) { b = n_blocks++; build_quad_block(qblocks, h->h_pool.data() + h->h_tex[tx].off, S, mp.tile_angle[t] & 3); }
+                off = (uint32_t)(32 + (size_t)(getenv("DTSIM_DEBUG_ONE_BLOCK") ? 0 : b) * block_bytes); sel = cell_sel;   // debug: L2-resident pool
+              }
+            }
+          }
+          qtiles.push_back(off); qtiles.push_back(sel);
+        }
+    }
+    if (32 + (size_t)n_blocks * block_bytes >= ((size_t)1 << 32)) qlog2 = -1;   // 32-bit block offsets
+  }
   M.total_words = (int32_t)blobs.size();
   if ((size_t)M.total_words * 8 > 60000)
     return fail(DTSIM_E_LIMIT, "map tables %zu B exceed the 60 KB LDS staging budget", (size_t)M.total_words * 8);
   if (trecs.size() > DTSIM_LDS_TILES)
     return fail(DTSIM_E_LIMIT, "%zu tiles over all maps exceed the %d LDS raster records", trecs.size(), DTSIM_LDS_TILES);
-  void* olds[] = {h->d_blobs, h->d_dyn, h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_tilerecs};
+  void* olds[] = {h->d_blobs, h->d_dyn, h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_tilerecs, h->d_qtex, h->d_qtiles};
   for (void* p : olds) if (p) (void)hipFree(p);
   h->d_blobs = nullptr; h->d_dyn = nullptr; h->d_rmaps = nullptr; h->d_rtiles = nullptr; h->d_robjs = nullptr;
-  h->d_tilerecs = nullptr;
+  h->d_tilerecs = nullptr; h->d_qtex = nullptr; h->d_qtiles = nullptr;
+  h->n_qtiles = 0; h->qlog2 = 0; h->q_per_m = 0.f;
+  if (qlog2 > 0 && !qtiles.empty()) {
+    HIPCHK(hipMalloc(&h->d_qtex, qblocks.size() * 4));
+    HIPCHK(hipMemcpy(h->d_qtex, qblocks.data(), qblocks.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_qtiles, qtiles.size() * 4));
+    HIPCHK(hipMemcpy(h->d_qtiles, qtiles.data(), qtiles.size() * 4, hipMemcpyHostToDevice));
+    h->n_qtiles = (int)qtiles.size() / 2; h->qlog2 = qlog2; h->q_per_m = q_per_m;
+  }
   HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
   if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
@@ -722,13 +808,18 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
-  const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + 31) / 32);
+  const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
   R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items;
   if (getenv("DTSIM_DEBUG_QUEUE")) {
     R.dbg = h->d_qcount + n_wg_ * 4;
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
   }
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
+  R.qtex = h->d_qtex; R.qtiles = h->d_qtiles; R.n_qtiles = h->n_qtiles; R.qlog2 = h->qlog2; R.q_per_m = h->q_per_m;
+  R.pixtab = h->d_pixtab;
+  R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
+  R.qmax_tiles = 0;
+  for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
     dt_launch_render(h->stream, h->A, R);
@@ -737,7 +828,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   if (getenv("DTSIM_DEBUG_QUEUE")) {   // profiling aid: how many pixels took the exact MSAA path
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t npix = (size_t)R.W * R.H;
-    const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + 31) / 32);
+    const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
     std::vector<int32_t> qc(n_wg * 4);
     HIPCHK(hipMemcpy(qc.data(), h->d_qcount, qc.size() * 4, hipMemcpyDeviceToHost));
     long long tot = 0, mx = 0, iters = 0, nonempty = 0;

@@ -118,6 +118,7 @@ struct RenderMapDev {       // per map, raster view of the grid + objects
   float tile_size, inv_tile_size;
   int32_t tile_off;         // offset into tile table (uint32 per tile: tex | angle<<8 | present<<15)
   int32_t obj_off;          // offset into object-instance table
+  int32_t qt_off, qt_pitch; // quad-texture tile table of the map: first entry, row pitch (grid_w + 2*DT_QRING)
 };
 
 struct ObjInstDev {         // static render instance (dynamic ones are patched per env)
@@ -163,8 +164,19 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 #endif
 #define DT_TILE_W DT_WAVE_W
 #define DT_TILE_H (4 * (64 * DT_PPT / DT_WAVE_W))  // 4 wavefronts stacked vertically
+#ifndef DT_ENVS_PER_BLOCK
+#define DT_ENVS_PER_BLOCK 32                 // envs a raster workgroup loops over
+#endif
 #define DT_ITEM_B 8                          // 64-entry edge batches per k_resolve work item
-#define DT_ITEMS_PER_WG (4 * 128 / DT_ITEM_B) // worst case: 4 regions x (256 px x 32 envs / 64) batches
+#define DT_ITEMS_PER_WG (4 * (DT_PPT * DT_ENVS_PER_BLOCK) / DT_ITEM_B) // worst case: 4 regions x (64*PPT px x envs / 64) batches
+// Quad-layout tile textures for the one-ray fast path (render.hip k_raster_q): per (texture, tile angle) pair one
+// block of S x S records of 16 bytes, record (x0, z0) = the four GL_LINEAR taps of the pre-rotated tile texture around
+// quad cell (x0, z0) as channel-planar bytes {R00 R10 R01 R11}, {G..}, {B..} + a meta dword (see DT_QMETA_*).
+#define DT_QRING 1                           // ring of off-grid cells around each map's tile table, in tiles
+// The pool starts with two single records every cell of a non-textured tile maps to: record 0 = off the grid (ground
+// quad / sky), record 1 = present but untextured tile (exact path).
+// DT_QMETA -- meta dword: low 16 bits = cells to the nearest tile boundary if the cell belongs to a textured tile (else 0),
+// high 16 bits = 1 if the cell is off the grid (else 0); 0 / 0 = always the exact path.
 static inline size_t dt_raster_tiles(int W, int H) {
   return (size_t)((W + DT_TILE_W - 1) / DT_TILE_W) * (size_t)((H + DT_TILE_H - 1) / DT_TILE_H);
 }
@@ -195,6 +207,14 @@ struct RenderParams {
   int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor; zeroed per render
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
+  // quad-layout fast path (null qtex: the generic k_raster is used)
+  const uint8_t* qtex;          // quad blocks, 16 B records
+  const uint32_t* qtiles;       // [n_qtiles][2] per padded-table cell: byte offset of its block, cell selector; maps concatenated
+  int32_t n_qtiles, qlog2;      // qlog2: log2(S), S = tile texture size
+  float q_per_m;                // quad cells per metre (S / tile_size), max over maps: scales the MSAA margin
+  int32_t qmax_tiles;           // largest padded grid extent over the maps (tiles)
+  void* dump;                   // 1 KB scratch: masked lanes of the unconditional frame store write here
+  void* pixtab;                 // [H*W] PixTab (16 B) then [H*W] SampTab (48 B): per-pixel tables of the shared camera
 };
 
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);

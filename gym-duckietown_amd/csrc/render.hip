@@ -42,6 +42,7 @@
 // Measured (profiles/): the pass is VALU-issue bound -- 64.8 vector instructions per pixel with the
 // vector ALUs saturated -- at 19.7 % of the HBM roofline; float32 shading, uint8 output.
 #include "dtsim_dev.h"
+#include <hip/hip_fp16.h>
 
 #define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT DT_PPT         // pixels per thread
@@ -50,7 +51,7 @@
 #define SLOT_X(k, l) (((k) * 64 + (l)) % WAVE_W)
 #define SLOT_Y(k, l) (((k) * 64 + (l)) / WAVE_W)
 #define WAVE_PIX (64 * PPT)
-#define ENVS_PER_BLOCK 32
+#define ENVS_PER_BLOCK DT_ENVS_PER_BLOCK
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
@@ -89,6 +90,19 @@ struct alignas(16) EnvFast {
 };
 static_assert(sizeof(EnvFast) == 64, "EnvFast is 64 bytes");
 
+// Per-env constants of the quad-layout fast path (k_raster_q): the tile-plane hit (lr, lf) of a pixel in the yaw-local
+// frame goes straight to padded quad coordinates  X = Cx + lr*A + lf*B,  Z = Cz + lr*B - lf*A  (tile units x S, +0.5
+// for the GL_LINEAR half-texel shift, + DT_QRING tiles of off-grid ring).  One 64-byte scalar load per env.
+struct alignas(16) EnvQ {
+  float A, B, Cx, Cz;
+  float Xhi, Zhi;              // clamp range [S/2, hi]: centres of the outermost ring cells
+  uint32_t tab_b, pitch4;      // the map's padded tile table inside the LDS copy (byte offset), row pitch in bytes (8-byte entries)
+  uint32_t hor_rgb;            // packed horizon colour
+  uint32_t sky[3];             // the horizon colour as the three dwords of four consecutive pixels (RGBR GBRG BRGB)
+  uint32_t pad[4];
+};
+static_assert(sizeof(EnvQ) == 64, "EnvQ is 64 bytes");
+
 // coverage-only part of a ScreenTri kept in LDS by k_resolve<true>; the winner's colours are fetched
 // from global memory.
 struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; int32_t pad; };   // == first half of ScreenTri
@@ -111,7 +125,7 @@ __device__ inline CamShared default_cam(float aspect) {
 }
 
 __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
-                            const RenderMapDev* __restrict__ maps) {
+                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
   if (e >= A.N) return;
@@ -187,6 +201,21 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
   }
   f.gw = m.grid_w; f.gh = m.grid_h; f.tile_off = m.tile_off;
   fast[e] = f;
+  if (envq) {
+    const float S = (float)(1 << qlog2);
+    EnvQ q;
+    q.A = f.A * S; q.B = f.B * S;
+    q.Cx = f.Cxi * S + 0.5f + (float)DT_QRING * S; q.Cz = f.Czi * S + 0.5f + (float)DT_QRING * S;
+    q.Xhi = ((float)(m.grid_w + 2 * DT_QRING) - 0.5f) * S; q.Zhi = ((float)(m.grid_h + 2 * DT_QRING) - 0.5f) * S;
+    q.tab_b = (uint32_t)m.qt_off * 8u; q.pitch4 = (uint32_t)m.qt_pitch * 8u;   // 8-byte table entries
+    q.hor_rgb = f.hor_rgb;
+    const uint32_t r = f.hor_rgb & 255u, g = (f.hor_rgb >> 8) & 255u, b = (f.hor_rgb >> 16) & 255u;
+    q.sky[0] = r | (g << 8) | (b << 16) | (r << 24);
+    q.sky[1] = g | (b << 8) | (r << 16) | (g << 24);
+    q.sky[2] = b | (r << 8) | (g << 16) | (b << 24);
+    q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = 0u;
+    envq[e] = q;
+  }
 }
 
 // ---- mesh objects -> per-env screen-space triangles ------------------------------------
@@ -988,6 +1017,654 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   }
 }
 
+
+// ---- per-pixel tables of the shared camera (env-invariant; built by k_pix_setup) ----------------------------------
+// PixTab: what k_raster_q keeps in registers per pixel.  lit: < 0 source pixel outside the image (BORDER_CONSTANT 0),
+// 0 sky for all four samples, > 0 the lit factor min(base + dif * N.L, 1) of the tile plane at the pixel-centre hit.
+// mi: low 16 bits = MSAA reach in quad cells (0xFFFF: never a one-ray pixel), high 16 = the reach in metres, fp16 rounded up.
+struct alignas(16) PixTab { float lr, lf, lit; uint32_t mi; };
+// SampTab: the four MSAA sample hits on the tile plane in the yaw-local frame (k_resolve_q), as fp16 offsets from the
+// pixel-centre hit (lr, lf) of the PixTab (a sample sits within a pixel footprint of the centre: an fp16 offset
+// places it to 5e-4 of that footprint; for pixels whose centre ray misses the planes the offsets are the hits
+// themselves).  flags: bit s = sample s hits the tile plane within [near, far], bit 4+s = it hits the ground plane
+// within [near, far] (ground hit = kg * tile-plane hit).
+struct alignas(16) SampTab { uint32_t dlr[2], dlf[2]; uint32_t flags; uint32_t pad[3]; };
+static_assert(sizeof(PixTab) == 16 && sizeof(SampTab) == 32, "table records");
+
+__global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixTab* __restrict__ pixtab, SampTab* __restrict__ samptab) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= R.W * R.H) return;
+  const float aspect = (float)R.W / (float)R.H;
+  const float ex_n = 0.375f * 2.f / (float)R.W * 1.01f, ey_n = 0.375f * 2.f / (float)R.H * 1.01f;
+  const CamShared cs = default_cam(aspect);
+  const float4 l = lut[pix];
+  const bool ok = l.z != 0.f;
+  const PixInv p = pix_inv(l.x, l.y, ok, cs.tx, cs.ty, cs.sth, cs.cth, cs.Cy, cs.L, ex_n, ey_n);
+  const bool cand = (p.flags & (PF_VALID | PF_SKY)) == PF_VALID;
+  const bool plain = cand && !(p.flags & PF_ALWAYS_EDGE) && (p.flags & PF_TILE_OK) && (p.flags & PF_GROUND_OK);
+  PixTab t;
+  t.lr = p.lr; t.lf = p.lf;
+  t.lit = !ok ? -1.f : !cand ? 0.f : fminf(fmaf(cs.dif, p.ndl, cs.base), 1.f);
+  // one-ray pixel  <=>  cells-to-boundary k > reach + 0.5  <=>  k > floor(reach + 0.5)   (k integer)
+  t.mi = plain ? (uint32_t)fminf(floorf(fmaf(p.mrg, R.q_per_m, 0.5f)), 65534.f) : 0xFFFFu;
+  t.mi |= (uint32_t)__half_as_ushort(__float2half_ru(fminf(p.mrg, 60000.f))) << 16;
+  pixtab[pix] = t;
+  SampTab sp;
+  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
+  sp.flags = 0u;
+  float dlr[4], dlf[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Ray r = make_ray(l.x + ox[k] * sxn, l.y - oy[k] * syn, cs.tx, cs.ty, cs.sth, cs.cth);
+    dlr[k] = dlf[k] = 0.f;
+    if (r.yla < 0.f) {
+      const float inv = frcp(-r.yla);
+      const float t = cs.Cy * inv, tg = (cs.Cy - GROUND_Y) * inv;
+      dlr[k] = fminf(fmaxf(t * r.xe - p.lr, -60000.f), 60000.f); dlf[k] = fminf(fmaxf(t * r.fwd - p.lf, -60000.f), 60000.f);
+      if (t >= NEAR_Z && t <= FAR_Z) sp.flags |= 1u << k;
+      if (tg >= NEAR_Z && tg <= FAR_Z) sp.flags |= 16u << k;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sp.dlr[j] = (uint32_t)__half_as_ushort(__float2half_rn(dlr[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(dlr[2 * j + 1])) << 16);
+    sp.dlf[j] = (uint32_t)__half_as_ushort(__float2half_rn(dlf[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(dlf[2 * j + 1])) << 16);
+  }
+  sp.pad[0] = sp.pad[1] = sp.pad[2] = 0u;
+  samptab[pix] = sp;
+}
+
+// ---- quad-layout fast path -------------------------------------------------------------------------------------
+// k_raster_q<OBJ>: same work decomposition, queue protocol and store path as k_raster<false, OBJ> (shared camera), with
+// the per-pixel cost cut to what the VALU issue rate of gfx950 allows (profiles/r02_ubench_valu_rates.txt: every
+// vector opcode costs one ~4-cycle issue slot per wavefront, only v_pk_*_f32 does two results per slot):
+//   * the tile lookup and the per-tile affine texture map are gone: tile textures are stored pre-rotated, per
+//     (texture, angle), as S x S "quad" records of 16 B -- the four GL_LINEAR taps around one cell, channel-planar,
+//     plus a meta dword -- and the hit goes from the yaw-local frame straight to padded quad coordinates (EnvQ);
+//     the only table read is the block offset of the cell's tile (LDS, 4 B per tile incl. an off-grid ring);
+//   * the bilinear filter is integer: weights -> u16 (v_cvt_pknorm_u16_f32, light folded in), split into hi / lo
+//     byte planes (v_perm_b32), 2 x v_dot4_u32_u8 per channel against the planar taps, (H << 8) + L, bits 16..23
+//     are the output byte.  Against the float filter the result differs by < 0.01 LSB before rounding;
+//   * interior / edge classification is one compare: meta.lo = cells to the nearest tile boundary (0 for anything
+//     that is not a textured tile) against the pixel's MSAA reach in cells, computed once per pixel (Mi).  Cell 0 of
+//     each axis straddles the seam (half of it belongs to the neighbour tile) and is always an edge;
+//   * all-sky wavefront blocks (env-invariant with the shared camera) take a three-store loop.
+// Anything that is not a fast tile pixel falls into a wave-uniform slow branch that decides ground-fast vs edge and
+// appends edge pixels to the queue exactly as k_raster does; k_resolve is unchanged.
+__device__ inline float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+#ifndef DT_Q_WAVES
+#define DT_Q_WAVES 4
+#endif
+#ifndef DT_Q_PIPE
+#define DT_Q_PIPE 0
+#endif
+#ifndef DT_Q_SCHED_BARRIER
+#define DT_Q_SCHED_BARRIER 1
+#endif
+template <bool OBJ, bool S256>
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, DT_Q_WAVES))) void k_raster_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
+                                                 const EnvQ* __restrict__ envq, uint8_t* __restrict__ frames,
+                                                 const uint8_t* __restrict__ qtex, const float4* __restrict__ lut, const PixTab* __restrict__ pixtab,
+                                                 const uint32_t* __restrict__ qtiles, uint16_t* __restrict__ queue,
+                                                 int32_t* __restrict__ qcount) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_qt = s_mem;                                                                   // [n_qtiles]
+  const int tid = threadIdx.x;
+  const int npix = R.W * R.H;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  const int tile = blockIdx.x % n_tiles;
+  const int chunk = blockIdx.x / n_tiles;
+  const int e0 = chunk * ENVS_PER_BLOCK;
+  const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
+  for (int i = tid; i < R.n_qtiles * 2; i += RB) s_qt[i] = qtiles[i];
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int tile_x0 = (tile % tiles_x) * DT_TILE_W;
+  const int wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
+  const int LS = R.qlog2;
+  const uint32_t SM = (1u << LS) - 1u;
+  const float lo = 0.5f * (float)(1 << LS);
+
+  // per-pixel invariants (shared camera) from the PixTab: hit in the yaw-local frame, lit factor, MSAA reach, flags
+  float lr[PPT], lf[PPT], lit[PPT];
+  uint32_t Mi[PPT];
+  bool cand[PPT], gok[PPT], valid[PPT];
+  float spx[PPT], spy[PPT];
+  float wbx0 = 1e30f, wbx1 = -1e30f, wby0 = 1e30f, wby1 = -1e30f;
+  bool any_cand = false;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    PixTab t{0.f, 0.f, -1.f, 0xFFFFu};
+    const bool inimg = tile_x0 + SLOT_X(k, lane) < R.W && wave_y0 + SLOT_Y(k, lane) < R.H;
+    const int pix = (wave_y0 + SLOT_Y(k, lane)) * R.W + tile_x0 + SLOT_X(k, lane);
+    if (inimg) t = pixtab[pix];
+    lr[k] = t.lr; lf[k] = t.lf; lit[k] = fmaxf(t.lit, 0.f); Mi[k] = t.mi;
+    valid[k] = t.lit >= 0.f; cand[k] = t.lit > 0.f; gok[k] = (t.mi & 0xFFFFu) != 0xFFFFu;
+    any_cand |= cand[k];
+    spx[k] = spy[k] = 0.f;
+    if (OBJ && inimg) {
+      const float4 l = lut[pix];
+      spx[k] = (l.x + 1.f) * 0.5f * (float)R.W; spy[k] = (1.f - l.y) * 0.5f * (float)R.H;
+      if (valid[k]) { wbx0 = fminf(wbx0, spx[k]); wbx1 = fmaxf(wbx1, spx[k]); wby0 = fminf(wby0, spy[k]); wby1 = fmaxf(wby1, spy[k]); }
+    }
+  }
+  if (OBJ) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      wbx0 = fminf(wbx0, __shfl_xor(wbx0, d)); wbx1 = fmaxf(wbx1, __shfl_xor(wbx1, d));
+      wby0 = fminf(wby0, __shfl_xor(wby0, d)); wby1 = fmaxf(wby1, __shfl_xor(wby1, d));
+    }
+  }
+
+  uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
+  int qn = 0;
+  uint32_t* s_px = s_mem + R.n_qtiles * 2 + wave * WAVE_PIX;
+  const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
+  // frame rows are dword aligned (W % 4 == 0: launch precondition; other widths take the generic k_raster)
+  const bool st_ok = lane * 4 < WAVE_PIX && st_x < R.W && st_y < R.H;
+  const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
+
+  const bool wave_sky = !OBJ && !__ballot(any_cand);
+  if (wave_sky) {
+    // ---- all sky / border for every env: the lane's 12 bytes are the horizon colour pattern, masked where the
+    // source pixel lies outside the rectilinear image.
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) s_px[k * 64 + lane] = valid[k] ? 0xFFFFFFFFu : 0u;
+    const uint4 vm = *reinterpret_cast<const uint4*>(s_px + (lane * 4) % WAVE_PIX);
+    const uint32_t m0 = (vm.x & 0x00FFFFFFu) | (vm.y << 24), m1 = ((vm.y >> 8) & 0xFFFFu) | (vm.z << 16), m2 = ((vm.z >> 16) & 0xFFu) | (vm.w << 8);
+    for (int e = e0; e < e1; ++e) {
+      const EnvQ f = envq[e];
+      if (st_ok) {
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)e * npix * 3 + st_off);
+        d32[0] = f.sky[0] & m0; d32[1] = f.sky[1] & m1; d32[2] = f.sky[2] & m2;
+      }
+    }
+    if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = 0;
+  } else {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static_assert(PPT % 2 == 0, "pixel slots are processed in pairs (packed fp32)");
+  f2 lr2[PPT / 2], lf2[PPT / 2], lit2[PPT / 2];
+#pragma unroll
+  for (int j = 0; j < PPT / 2; ++j) {
+    lr2[j] = f2{lr[2 * j], lr[2 * j + 1]}; lf2[j] = f2{lf[2 * j], lf[2 * j + 1]}; lit2[j] = f2{lit[2 * j], lit[2 * j + 1]};
+  }
+  const char* s_qtb = reinterpret_cast<const char*>(s_qt);
+  unsigned long long candm[PPT], validm[PPT], plainm[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) { candm[k] = __ballot(cand[k]); validm[k] = __ballot(valid[k]); plainm[k] = __ballot(gok[k]); }
+  // The env loop is software-pipelined two deep: the quad loads of env e+1 are issued BEFORE the frame stores of env e.
+  // gfx950 retires vector memory operations of a wavefront in issue order (one vmcnt for loads and stores), so a
+  // load issued after a store cannot be waited for without also waiting for that store's write acknowledge; with the
+  // loads of the next env ahead of the stores, a wavefront only ever waits for stores that are two envs old.
+  struct QStage { uint4 q[PPT]; f2 ax2[PPT / 2], az2[PPT / 2]; };
+  auto issue = [&](const EnvQ& f, QStage& st) __attribute__((always_inline)) {
+    const f2 vA = f2{f.A, f.A}, vB = f2{f.B, f.B}, vCx = f2{f.Cx, f.Cx}, vCz = f2{f.Cz, f.Cz};
+#pragma unroll
+    for (int j = 0; j < PPT / 2; ++j) {
+      // two pixels per packed op: X = Cx + lr*A + lf*B, Z = Cz + lr*B - lf*A
+      const f2 X2 = lf2[j] * vB + (lr2[j] * vA + vCx);
+      const f2 Z2 = lr2[j] * vB + (vCz - lf2[j] * vA);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * j + h;
+        const float X = med3f(h ? X2.y : X2.x, lo, f.Xhi), Z = med3f(h ? Z2.y : Z2.x, lo, f.Zhi);
+        const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
+        if (h) { st.ax2[j].y = __builtin_amdgcn_fractf(X); st.az2[j].y = __builtin_amdgcn_fractf(Z); }
+        else { st.ax2[j].x = __builtin_amdgcn_fractf(X); st.az2[j].x = __builtin_amdgcn_fractf(Z); }
+        // block offset of the cell's tile: LDS table, byte address = tab_b + (zi >> LS) * pitch4 + ((xi >> LS) << 2)
+        // The table entry is 8 bytes: the block's byte offset and how the cell index is formed -- for the two
+        // one-record blocks (off-grid, untextured) every cell maps to record 0, so they do not occupy cache lines.
+        uint32_t ta, local;
+        if (S256) {   // S = 256 and a padded grid under 256 tiles: tile = byte 1, cell = byte 0 of the coordinate
+          uint32_t t1, t2;
+          asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t1) : "v"(zi), "s"(f.pitch4));
+          asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t2) : "v"(xi));
+          ta = t1 + t2 + f.tab_b;
+        } else ta = ((xi >> LS) << 3) + (__umul24(zi >> LS, f.pitch4) + f.tab_b);
+        const uint2 te = *reinterpret_cast<const uint2*>(s_qtb + ta);
+        const uint32_t tb = te.x;
+        if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);                 // te.y: v_perm selector (z0 << 8) | x0, or 0
+        else local = (((zi & SM) << LS) | (xi & SM)) & te.y;                   // te.y: cell mask
+#ifdef DT_Q_NO_LOAD
+        st.q[k] = make_uint4(tb + local, tb ^ local, local, 0x00000080u);
+#elif defined(DT_Q_HOT_LOAD)
+        st.q[k] = *reinterpret_cast<const uint4*>(qtex + (tb + ((local & 0x3FFu) << 4)));   // ablation: L1-resident taps
+#else
+        st.q[k] = *reinterpret_cast<const uint4*>(qtex + (tb + (local << 4)));
+#endif
+      }
+    }
+  };
+  struct alignas(4) U3 { uint32_t a, b, c; };
+  // The lane's 12 bytes of frame e.  The store is unconditional (no branch around it, so that the wait counts the
+  // compiler derives for the texel loads do not have to cover it): lanes without pixels write to a dump slot.
+  uint8_t* const st_base = st_ok ? frames + (size_t)e0 * npix * 3 + st_off : reinterpret_cast<uint8_t*>(R.dump) + lane * 16;
+  const uint32_t st_stride = st_ok ? (uint32_t)npix * 3u : 0u;
+  auto store = [&](const int e, const U3& o) __attribute__((always_inline)) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(st_base + (size_t)(uint32_t)(e - e0) * st_stride);
+#if defined(DT_Q_NO_STORE)
+    if (o.a == 0x12345678u) *d = 1u;
+#elif defined(DT_Q_PLAIN_STORE)
+    *reinterpret_cast<U3*>(d) = o;
+#else
+    // non-temporal: the frame is written once and not read back by this pass; keep the taps in L2
+    __builtin_nontemporal_store(o.a, d); __builtin_nontemporal_store(o.b, d + 1); __builtin_nontemporal_store(o.c, d + 2);
+#endif
+  };
+  auto finish = [&](const int e, const uint32_t hor_rgb, const QStage& st) __attribute__((always_inline)) -> U3 {
+    U3 out{0u, 0u, 0u};
+    uint32_t px[PPT];
+    bool edge[PPT];
+    unsigned long long fastm[PPT];
+    const uint4* q = st.q;
+    const f2* ax2 = st.ax2; const f2* az2 = st.az2;
+    unsigned long long slow = 0ull;                  // lane masks live in SGPR pairs: predicate logic on the scalar unit
+#pragma unroll
+    for (int j = 0; j < PPT / 2; ++j) {
+#if DT_Q_SCHED_BARRIER
+      if (j) __builtin_amdgcn_sched_barrier(0);      // one pixel pair at a time: fewer live temporaries
+#endif
+      // bilinear weights with the lit factor folded in, two pixels per packed op
+      const f2 I2 = lit2[j];
+      const f2 axI = ax2[j] * I2, azI = az2[j] * I2;
+      const f2 w11 = axI * az2[j];
+      const f2 w10 = axI - w11, w01 = azI - w11;
+      const f2 w00 = (I2 - axI) - w01;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = 2 * j + h;
+        const unsigned long long fm = __ballot((q[k].w & 0xFFFFu) > (Mi[k] & 0xFFFFu));
+        fastm[k] = fm;
+        slow |= candm[k] & ~fm;
+        edge[k] = false;
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(h ? w00.y : w00.x, h ? w10.y : w10.x);
+        const us2 wb = __builtin_amdgcn_cvt_pknorm_u16(h ? w01.y : w01.x, h ? w11.y : w11.x);
+        uint32_t WA, WB;
+        __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+        const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+        const uint32_t vr = (__builtin_amdgcn_udot4(q[k].x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].x, wl, 32768u, false);
+        const uint32_t vg = (__builtin_amdgcn_udot4(q[k].y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].y, wl, 32768u, false);
+        const uint32_t vb = (__builtin_amdgcn_udot4(q[k].z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].z, wl, 32768u, false);
+        const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
+        const uint32_t rgb = __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
+        uint32_t base;                                   // horizon colour, 0 where the source pixel is outside the image
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(base) : "v"(hor_rgb), "s"(validm[k]));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(px[k]) : "v"(base), "v"(rgb), "s"(fm));
+      }
+    }
+    if (slow) {                                      // wave-uniform: some pixel is not a certain tile interior
+      // Per pixel slot, and only for the slots that have such lanes (scalar tests on lane masks):
+      //   off-grid cell: ground quad, if every sample stays off the grid and inside the quad;
+      //   anything else: queued for k_resolve -- the seam cell (half of it belongs to the neighbour tile, whose taps
+      //     the record does not hold), untextured tiles, the horizon band, and the textured cells the cell-granular
+      //     test rejected (conservative by up to a cell; k_resolve redoes it exactly on compacted lanes, which is
+      //     cheaper than refining here at a few live lanes per wavefront).
+      const EnvFast g = fasts[e];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const unsigned long long sk = candm[k] & ~fastm[k];
+        if (!sk) continue;                           // wave-uniform
+        const bool sl = (sk >> lane) & 1ull;
+        const unsigned long long gm = sk & __ballot((q[k].w >> 16) != 0u) & plainm[k];
+        edge[k] = sl;
+        if (gm) {
+          const float lrk = (k & 1) ? lr2[k / 2].y : lr2[k / 2].x, lfk = (k & 1) ? lf2[k / 2].y : lf2[k / 2].x;
+          const float mrgk = __half2float(__ushort_as_half((unsigned short)(Mi[k] >> 16)));
+          const EnvCam c = cams[e];
+          const float wx = c.Cx + lrk * c.sa + lfk * c.ca, wz = c.Cz + lrk * c.ca - lfk * c.sa;          // tile-plane hit, world
+          const float wxg = fmaf(g.kg, wx - c.Cx, c.Cx), wzg = fmaf(g.kg, wz - c.Cz, c.Cz);              // ground-quad hit
+          // every sample's tile-plane hit stays clear of the grid rectangle (an absent tile inside the grid goes to
+          // the exact path)
+          const bool clear = (wx < -mrgk) | (wx > g.gw_m + mrgk) | (wz < -mrgk) | (wz > g.gh_m + mrgk);
+          const bool inq = (fabsf(wxg) + 2.f * mrgk < GROUND_HALF) & (fabsf(wzg) + 2.f * mrgk < GROUND_HALF);
+          const bool gfast = ((gm >> lane) & 1ull) & clear & inq;
+          const float ndl = ground_ndl(c, wxg, wzg);
+          uint32_t rgb = 0;
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[0] * fminf(c.base[0] + c.dif[0] * ndl, 1.f), 0, rgb);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[1] * fminf(c.base[1] + c.dif[1] * ndl, 1.f), 1, rgb);
+          rgb = __builtin_amdgcn_cvt_pk_u8_f32(c.gnd[2] * fminf(c.base[2] + c.dif[2] * ndl, 1.f), 2, rgb);
+          px[k] = gfast ? rgb : px[k];
+          edge[k] = sl & !gfast;
+        }
+      }
+    }
+
+    if (OBJ) {
+      const ObjEnv oe = R.objenv[e];                 // wave-uniform
+      if (oe.n_tris > 0 && wbx1 >= oe.bx0 && wbx0 <= oe.bx1 && wby1 >= oe.by0 && wby0 <= oe.by1) {
+        const ObjBox* boxes = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
+        for (int o = 0; o < oe.n_obj; ++o) {
+          const ObjBox ob = boxes[o];                // wave-uniform
+          if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
+#pragma unroll
+          for (int k = 0; k < PPT; ++k)
+            if (valid[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
+        }
+      }
+    }
+
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) s_px[k * 64 + lane] = px[k];
+    const uint4 o = *reinterpret_cast<const uint4*>(s_px + (lane * 4) % WAVE_PIX);
+    out = U3{o.x | (o.y << 24), (o.y >> 8) | (o.z << 16), (o.z >> 16) | (o.w << 8)};
+
+    bool any_edge = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) any_edge |= edge[k];
+    if (__ballot(any_edge)) {                          // wave-uniform
+      const uint32_t etag = (uint32_t)(e - e0) << 8;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const bool ek = edge[k];
+        const unsigned long long mk = __ballot(ek);
+        if (ek) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          w_queue[qn + rank] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
+        }
+        qn += __popcll(mk);
+      }
+    }
+    return out;
+  };
+#if DT_Q_PIPE
+  {  // two stages: loads of env e+1 in flight while env e is filtered and stored
+    QStage sa, sb;
+    EnvQ fa = envq[e0], fb = envq[min(e0 + 1, e1 - 1)];
+    issue(fa, sa);
+    for (int e = e0; e < e1; e += 2) {
+      const uint32_t hor_a = fa.hor_rgb, hor_b = fb.hor_rgb;
+      issue(fb, sb);                                 // env e+1 (a harmless repeat of the last env past the end)
+      fa = envq[min(e + 2, e1 - 1)];
+      const U3 oa = finish(e, hor_a, sa);
+      store(e, oa);
+      if (e + 1 < e1) {
+        issue(fa, sa);                               // env e+2
+        fb = envq[min(e + 3, e1 - 1)];
+        const U3 ob = finish(e + 1, hor_b, sb);
+        store(e + 1, ob);
+      }
+    }
+  }
+#else
+  {  // one stage, deferred store: the 12 bytes of env e-1 are held in registers and stored right after the loads of
+     // env e have been issued, so that waiting for those loads never waits for a store of the same iteration.
+     // No branch between the loads and the store (first env peeled).
+    QStage sa;
+    EnvQ f = envq[e0];
+    issue(f, sa);
+    uint32_t hor = f.hor_rgb;
+    f = envq[min(e0 + 1, e1 - 1)];
+    U3 held = finish(e0, hor, sa);
+    for (int e = e0 + 1; e < e1; ++e) {
+      hor = f.hor_rgb;
+      issue(f, sa);
+      store(e - 1, held);
+      f = envq[min(e + 1, e1 - 1)];                  // next env's constants: the scalar load has the whole filter to land
+      held = finish(e, hor, sa);
+    }
+    store(e1 - 1, held);
+  }
+#endif
+  if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
+  }
+  __shared__ int s_nb[RB / 64];
+  if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
+  __syncthreads();
+  if (tid == 0) {
+    int nb = 0;
+#pragma unroll
+    for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
+    if (nb > 0) {
+      const int ni = (nb + ITEM_B - 1) / ITEM_B;
+      const int pos = atomicAdd(R.work, ni);
+      for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)blockIdx.x * ITEMS_PER_WG + (uint32_t)i;
+    }
+  }
+}
+
+// ---- k_resolve_q: exact path of the quad-layout pipeline (shared camera, no mesh objects) ------------------------
+// One workgroup per raster workgroup, wavefront w drains queue region w (the entries wavefront w of k_raster_q
+// appended) 64 entries at a time: no work list, no cursor atomics, nothing staged per item.  Per entry (one pixel
+// of one env):
+//   1. the pixel's centre hit -> padded quad coordinates -> its tile's table entry and quad record, as in k_raster_q;
+//   2. exact interior test (distance of the hit to the tile boundary, in cells, against the MSAA reach): the
+//      cell-granular test of k_raster_q is conservative by up to a cell and sends every pixel of the seam cell here;
+//      most entries pass and get the one-ray colour from the same integer filter (bit-identical to k_raster_q);
+//   3. otherwise the four samples: their tile-plane hits in the yaw-local frame are env-invariant (SampTab, built by
+//      k_pix_setup), so a sample costs one 2x2 transform and one table lookup.  Coverage per sample (tile if the
+//      tile plane is hit within [near, far] on a present tile; else the ground quad if hit within range and inside
+//      +-50 m; else the clear colour), shading once per distinct primitive at the pixel centre (GL semantics:
+//      simulator.py:1932-1934, graphics.py:172-251): a tile is shaded with ITS texture at the centre hit -- outside the
+//      tile the coordinate wraps (GL_REPEAT), which the quad records encode -- times the centre's lit factor.
+__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias) {
+  const float axI = ax * I, azI = az * I;
+  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
+  uint32_t WA, WB;
+  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+  // three 24-bit sums  sum(tap * w16)  packed as bytes 2 of (vr, vg, vb) when bias = 32768; callers that need the
+  // unrounded value pass bias = 0 and use quad_filter3
+  const uint32_t vr = (__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, bias, false);
+  const uint32_t vg = (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, bias, false);
+  const uint32_t vb = (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, bias, false);
+  const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
+  return __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
+}
+__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats
+  const float axI = ax * I, azI = az * I;
+  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
+  uint32_t WA, WB;
+  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+  const uint32_t v[3] = {(__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, 0u, false),
+                         (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, 0u, false),
+                         (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
+}
+
+#define RQ_LIST (ITEM_B * 64)                        // MSAA entries one work item can produce
+template <bool S256>
+__global__ __launch_bounds__(RB) void k_resolve_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
+                                                  const EnvQ* __restrict__ envq, const PixTab* __restrict__ pixtab,
+                                                  const SampTab* __restrict__ samptab, const uint8_t* __restrict__ qtex,
+                                                  const uint32_t* __restrict__ qtiles, const uint16_t* __restrict__ queue,
+                                                  const int32_t* __restrict__ qcount) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_qt = s_mem;                                                                   // [n_qtiles][2]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < R.n_qtiles * 2; i += RB) s_qt[i] = qtiles[i];
+  __syncthreads();
+  uint32_t* w_list = s_mem + R.n_qtiles * 2 + wave * RQ_LIST;                               // wavefront-local MSAA list
+  const int npix = R.W * R.H;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  const int LS = R.qlog2;
+  const uint32_t SM = (1u << LS) - 1u;
+  const float Sf = (float)(1 << LS), lo = 0.5f * Sf;
+  const char* qtb = reinterpret_cast<const char*>(s_qt);
+  const int n_items = R.work[0];                     // written by the raster launch (stream order)
+  const int n_waves = gridDim.x * (RB / 64);
+
+  // Table entry (block byte offset, cell selector) of the tile that OWNS padded quad coordinates (X, Z): tile
+  // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
+  // on (X - 0.5, Z - 0.5) -- unlike the record lookup, which goes by whole cells.  (ox, oz): the tile's origin.
+  auto tile_entry = [&](float X, float Z, const float Xhi, const float Zhi, const uint32_t tab_b, const uint32_t pitch4, uint32_t& ta,
+                        float& ox, float& oz) -> uint2 {
+    const float Xc = med3f(X - 0.5f, lo, Xhi), Zc = med3f(Z - 0.5f, lo, Zhi);
+    const uint32_t ti = (uint32_t)flr_i32(Xc) >> LS, tj = (uint32_t)flr_i32(Zc) >> LS;
+    ox = (float)(ti << LS) + 0.5f; oz = (float)(tj << LS) + 0.5f;
+    ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
+    return *reinterpret_cast<const uint2*>(qtb + ta);
+  };
+  // quad record of block entry `te` at the cell the (unclamped) coordinates fall into, wrapped into the tile
+  auto tile_quad = [&](const uint2 te, float X, float Z) -> uint4 {
+    const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
+    uint32_t local;
+    if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);
+    else local = (((zi & SM) << LS) | (xi & SM)) & te.y;
+    return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
+  };
+  auto store_rgb = [&](int e, int pix, uint32_t rgb) {
+#ifdef DT_RQ_NO_STORE
+    if (rgb != 0x12345678u) return;
+#endif
+    uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
+    // two stores: a 2-byte aligned half + one byte, whichever way the pixel's 3 bytes fall
+    const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;
+    uint8_t* p8 = odd ? dst : dst + 2;
+    uint16_t* p16 = reinterpret_cast<uint16_t*>(odd ? dst + 1 : dst);
+    *p8 = (uint8_t)(odd ? rgb : rgb >> 16);
+    *p16 = (uint16_t)(odd ? rgb >> 8 : rgb);
+  };
+
+  // Work items (ITEM_B consecutive 64-entry batches of one raster workgroup's four queue regions, flattened) are the
+  // ones k_raster_q appended to the list; wavefront w takes items w, w + n_waves, ... : a static map, no cursor atomic.
+  for (int it = blockIdx.x * (RB / 64) + wave; it < n_items; it += n_waves) {   // wave-uniform
+    const uint32_t item = R.items[it];
+    const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
+    const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
+    const int e0 = chunk * ENVS_PER_BLOCK;
+    const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
+    static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
+    int rn[4], rb[5];
+    rb[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rn[r] = qcount[rwg * 4 + r]; rb[r + 1] = rb[r] + ((rn[r] + 63) >> 6); }
+    const int b_end = min(rb[4], (part + 1) * ITEM_B);
+    int n_list = 0;                                  // wave-uniform
+    // ---- phase 1: per entry, the exact interior test; interior entries get the one-ray colour, the others are
+    // compacted into the wavefront's list for phase 2
+    for (int b = part * ITEM_B; b < b_end; ++b) {    // wave-uniform
+      const int reg = (b >= rb[1]) + (b >= rb[2]) + (b >= rb[3]);
+      const int q0 = (b - (reg == 0 ? rb[0] : reg == 1 ? rb[1] : reg == 2 ? rb[2] : rb[3])) * 64;
+      const int n = reg == 0 ? rn[0] : reg == 1 ? rn[1] : reg == 2 ? rn[2] : rn[3];
+      const uint16_t* w_queue = queue + ((size_t)rwg * 4 + reg) * QREGION;
+      const int wave_y0 = tile_y0 + reg * (WAVE_PIX / WAVE_W);
+      const bool have = q0 + lane < n;
+      const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
+      const int el = (int)(ent >> 8), lp = (int)(ent & 255u);
+      const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
+      const int e = min(e0 + el, R.N - 1);
+      const PixTab pt = pixtab[pix];
+      const EnvQ* fq = envq + e;
+      const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
+      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
+      uint32_t ta_c;
+      float ox, oz;
+      const uint2 te_c = tile_entry(Xu, Zu, Xhi, Zhi, tab_b, pitch4, ta_c, ox, oz);
+      // distance of the hit to the boundary of the tile that owns it, in cells, against the MSAA reach
+      const float mrg = __half2float(__ushort_as_half((unsigned short)(pt.mi >> 16)));   // metres, rounded up
+      const float ux = Xu - ox, uz = Zu - oz;          // in [0, S) inside the owner tile
+      const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
+      const bool in_range = Xu - 0.5f >= lo && Xu - 0.5f <= Xhi && Zu - 0.5f >= lo && Zu - 0.5f <= Zhi;
+      const bool interior = have && in_range && te_c.x >= 32u && pt.lit > 0.f && (pt.mi & 0xFFFFu) != 0xFFFFu && d > mrg * R.q_per_m;
+#ifndef DT_RQ_NO_INT
+      if (__ballot(interior)) {                        // wave-uniform
+        const uint4 qc = tile_quad(te_c, Xu, Zu);
+        const uint32_t rgb = quad_filter(qc, __builtin_amdgcn_fractf(Xu), __builtin_amdgcn_fractf(Zu), pt.lit, 32768u);
+        if (interior) store_rgb(e, pix, rgb);
+      }
+#endif
+#ifndef DT_RQ_NO_MSAA
+      const bool msaa = have && !interior;
+      const unsigned long long mm = __ballot(msaa);
+      if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix | ((uint32_t)el << 24);
+      n_list += __popcll(mm);
+#endif
+    }
+    // ---- phase 2: the four samples of the listed pixels, on dense lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int l0 = 0; l0 < n_list; l0 += 64) {          // wave-uniform
+      const bool have = l0 + lane < n_list;
+      const uint32_t le = have ? w_list[l0 + lane] : 0u;
+      const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
+      const int e = min(e0 + el, R.N - 1);
+      const PixTab pt = pixtab[pix];
+      const SampTab sp = samptab[pix];
+      const EnvQ* fq = envq + e;
+      const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
+      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const EnvCam* c = cams + e;
+      const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
+      const float kg = (wCy - GROUND_Y) / wCy;
+      const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
+      const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
+      const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
+      // coverage: per sample tile (tile plane hit within [near, far] on a present tile), else ground quad, else clear colour
+      uint32_t key[4];                                 // 0 sky, 1 ground, else 2 + table address of the tile
+      uint2 te[4];
+      int n_sky = 0, n_gnd = 0;
+      float gwx = 0.f, gwz = 0.f;                      // ground hit used for shading: the lowest-index ground sample's
+#pragma unroll
+      for (int s = 3; s >= 0; --s) {
+        const uint32_t hr = sp.dlr[s >> 1], hf = sp.dlf[s >> 1];
+        const float slr = pt.lr + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hr >> 16 : hr)));
+        const float slf = pt.lf + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hf >> 16 : hf)));
+        const float Xs = fmaf(slf, B, fmaf(slr, A, Cx)), Zs = fmaf(slf, -A, fmaf(slr, B, Cz));
+        uint32_t ta;
+        float sox, soz;
+        te[s] = tile_entry(Xs, Zs, Xhi, Zhi, tab_b, pitch4, ta, sox, soz);
+        const bool s_in = Xs - 0.5f >= lo && Xs - 0.5f <= Xhi && Zs - 0.5f >= lo && Zs - 0.5f <= Zhi;
+        const bool is_tile = ((sp.flags >> s) & 1u) && s_in && te[s].x != 0u;
+        // ground-quad hit of the sample (world): camera + kg * (tile-plane hit - camera)
+        const float wx = kg * (slr * sa + slf * ca) + wCx, wz = kg * (slr * ca - slf * sa) + wCz;
+        const bool is_gnd = !is_tile && ((sp.flags >> (4 + s)) & 1u) && fabsf(wx) <= GROUND_HALF && fabsf(wz) <= GROUND_HALF;
+        key[s] = !have ? 0u : is_tile ? 2u + ta : is_gnd ? 1u : 0u;
+        n_sky += key[s] == 0u; n_gnd += key[s] == 1u;
+        if (is_gnd) { gwx = wx; gwz = wz; }
+      }
+      // shading, once per primitive at the pixel centre
+      float acc[3];
+      acc[0] = (float)n_sky * c->hor[0]; acc[1] = (float)n_sky * c->hor[1]; acc[2] = (float)n_sky * c->hor[2];
+      if (__ballot(have && n_gnd > 0)) {               // wave-uniform
+        if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) {   // the centre ray hits the planes: shade at its ground hit
+          gwx = kg * (pt.lr * sa + pt.lf * ca) + wCx; gwz = kg * (pt.lr * ca - pt.lf * sa) + wCz;
+        }
+        const float a_ = fminf(fmaxf((gwx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+        const float b_ = fminf(fmaxf((gwz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+        const float n0 = c->gndl[0] + a_ * (c->gndl[1] - c->gndl[0]), n1 = c->gndl[2] + a_ * (c->gndl[3] - c->gndl[2]);
+        const float ndl = n0 + b_ * (n1 - n0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c->gnd[k] * fminf(c->base[k] + c->dif[k] * ndl, 1.f));
+      }
+      uint32_t todo = 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) todo |= key[s] >= 2u ? (1u << s) : 0u;
+      while (__ballot(todo != 0u)) {                   // wave-uniform: one pass per distinct tile over the lanes
+        const int s0 = todo ? __builtin_ctz(todo) : 0;
+        const uint32_t k0 = s0 == 0 ? key[0] : s0 == 1 ? key[1] : s0 == 2 ? key[2] : key[3];
+        uint2 t0;
+        t0.x = s0 == 0 ? te[0].x : s0 == 1 ? te[1].x : s0 == 2 ? te[2].x : te[3].x;
+        t0.y = s0 == 0 ? te[0].y : s0 == 1 ? te[1].y : s0 == 2 ? te[2].y : te[3].y;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
+        const uint4 qt = tile_quad(t0, Xu, Zu);
+        float col[3];
+        quad_filter3(qt, ax, az, lit, col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
+      }
+      const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
+      if (have) store_rgb(e0 + el, pix, pack_rgb(o));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
@@ -1141,8 +1818,11 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) {
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
+  EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
+  // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
+  const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0;
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
-                     (float)R.W / (float)R.H, cams, fasts, R.maps);
+                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
   (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
@@ -1155,10 +1835,29 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   const bool obj = R.max_tris > 0;
-  if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
+  if (quad) {
+    const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
+    PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
+    SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
+    hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
+#define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), grid, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
+                                           reinterpret_cast<const float4*>(R.lut), pixtab, R.qtiles, R.queue, R.qcount)
+    const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
+    if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
+    else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
+#undef LAUNCH_Q
+  } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
-  if (!R.no_msaa) {
+  if (quad && !obj) {
+    PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
+    SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
+    const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
+    const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 8));      // resident wavefronts striding over the work items
+    const size_t ldsr = (size_t)R.n_qtiles * 8 + (size_t)(RB / 64) * RQ_LIST * sizeof(uint32_t);
+    if (s256) hipLaunchKernelGGL((k_resolve_q<true>), rgrid, dim3(RB), ldsr, s, R, cams, fasts, envq, pixtab, samptab, R.qtex, R.qtiles, R.queue, R.qcount);
+    else hipLaunchKernelGGL((k_resolve_q<false>), rgrid, dim3(RB), ldsr, s, R, cams, fasts, envq, pixtab, samptab, R.qtex, R.qtiles, R.queue, R.qcount);
+  } else if (!R.no_msaa) {
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
     if (obj) hipLaunchKernelGGL(k_resolve<true>, rgrid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount);
