@@ -241,8 +241,8 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(frames %zu B): %s", h->frames_bytes, hipGetErrorString(e)); }
     h->frames = h->frames_own;
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
-    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64));   // EnvCam[N], EnvFast[N], EnvQ[N]
-    if (e == hipSuccess) e = hipMalloc(&h->d_pixtab, (size_t)cfg->cam_height * cfg->cam_width * 64 + 1024);   // PixTab + SampTab + 1 KB store dump
+    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64 + 4));   // EnvCam[N], EnvFast[N], EnvQ[N], render order [N]
+    if (e == hipSuccess) e = hipMalloc(&h->d_pixtab, (size_t)cfg->cam_height * cfg->cam_width * 64 + 2048);   // PixTab + SampTab + 1 KB store dump + debug counters
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
@@ -250,6 +250,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
       if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * DT_ITEMS_PER_WG * sizeof(uint32_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
+    (void)hipMemset((char*)h->d_pixtab + (size_t)cfg->cam_height * cfg->cam_width * 64, 0, 2048);
     if (!(cfg->flags & DTSIM_F_DISTORTION)) {
       // identity LUT: output pixel == rectilinear pixel
       int rc = dtsim_set_distortion_lut(h, nullptr, nullptr);
@@ -576,7 +577,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
               else {
                 int& b = block_of[(size_t)tx * 4 + (mp.tile_angle[t] & 3)];
                 if (b < 0) { b = n_blocks++; build_quad_block(qblocks, h->h_pool.data() + h->h_tex[tx].off, S, mp.tile_angle[t] & 3); }
-                off = (uint32_t)(32 + (size_t)(getenv("DTSIM_DEBUG_ONE_BLOCK") ? 0 : b) * block_bytes); sel = cell_sel;   // debug: L2-resident pool
+                off = (uint32_t)(32 + (size_t)b * block_bytes); sel = cell_sel;
               }
             }
           }
@@ -801,7 +802,11 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.distortion = (h->cfg.flags & DTSIM_F_DISTORTION) ? 1 : 0;
   R.domain_rand = (h->cfg.flags & DTSIM_F_DOMAIN_RAND) ? 1 : 0;
   R.n_maps = h->M.n_maps;
-  { const char* a = getenv("DTSIM_RASTER_NO_MSAA"); R.no_msaa = (a && a[0] == '1') ? 1 : 0; }
+#ifdef DT_RASTER_NO_MSAA   // profiling ablation, tools/build_variant.sh only: never in the product build
+  R.no_msaa = 1;
+#else
+  R.no_msaa = 0;
+#endif
   R.frames = h->frames; R.lut = h->d_lut; R.texels = segment ? h->d_texels_seg : h->d_texels; R.tex = h->d_tex;
   R.segment = segment ? 1 : 0; R.mesh_seg = h->d_mesh_seg;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
@@ -817,6 +822,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   R.qtex = h->d_qtex; R.qtiles = h->d_qtiles; R.n_qtiles = h->n_qtiles; R.qlog2 = h->qlog2; R.q_per_m = h->q_per_m;
   R.pixtab = h->d_pixtab;
+  R.envpos = reinterpret_cast<int32_t*>((char*)h->d_envcam + (size_t)h->N * (128 + 64 + 64));
   R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
   R.qmax_tiles = 0;
   for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);
@@ -827,6 +833,14 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   HIPCHK(hipGetLastError());
   if (getenv("DTSIM_DEBUG_QUEUE")) {   // profiling aid: how many pixels took the exact MSAA path
     HIPCHK(hipStreamSynchronize(h->stream));
+    {  // phase timers of the DT_Q_TIMING build variant (zero otherwise)
+      unsigned long long tc[4];
+      char* dbgp = (char*)h->d_pixtab + (size_t)R.W * R.H * 64 + 1024;
+      HIPCHK(hipMemcpy(tc, dbgp, sizeof tc, hipMemcpyDeviceToHost));
+      if (tc[3]) fprintf(stderr, "[dtsim] k_raster_q phase cycles per wavefront iteration: issue %.0f, wait for quads %.0f, filter+slow+transpose %.0f  (%llu iterations)\n",
+                         (double)tc[0] / tc[3], (double)tc[1] / tc[3], (double)tc[2] / tc[3], tc[3]);
+      HIPCHK(hipMemset(dbgp, 0, sizeof tc));
+    }
     const size_t npix = (size_t)R.W * R.H;
     const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
     std::vector<int32_t> qc(n_wg * 4);

@@ -172,7 +172,7 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 // Quad-layout tile textures for the one-ray fast path (render.hip k_raster_q): per (texture, tile angle) pair one
 // block of S x S records of 16 bytes, record (x0, z0) = the four GL_LINEAR taps of the pre-rotated tile texture around
 // quad cell (x0, z0) as channel-planar bytes {R00 R10 R01 R11}, {G..}, {B..} + a meta dword (see DT_QMETA_*).
-#define DT_QRING 1                           // ring of off-grid cells around each map's tile table, in tiles
+#define DT_QRING 4                           // ring of off-grid cells around each map's tile table, in tiles
 // The pool starts with two single records every cell of a non-textured tile maps to: record 0 = off the grid (ground
 // quad / sky), record 1 = present but untextured tile (exact path).
 // DT_QMETA -- meta dword: low 16 bits = cells to the nearest tile boundary if the cell belongs to a textured tile (else 0),
@@ -183,7 +183,7 @@ static inline size_t dt_raster_tiles(int W, int H) {
 
 struct RenderParams {
   int32_t N, W, H, distortion;
-  int32_t domain_rand, n_maps, n_tile_recs, no_msaa;   // no_msaa: profiling ablation only (DTSIM_RASTER_NO_MSAA=1)
+  int32_t domain_rand, n_maps, n_tile_recs, no_msaa;   // no_msaa: profiling ablation only (-DDT_RASTER_NO_MSAA build variant)
   int32_t tex_w, tex_h;           // all tile textures share one (power-of-two) size
   const TileLds* tile_recs;       // [n_tile_recs], maps concatenated (RenderMapDev.tile_off)
   uint8_t* frames;
@@ -213,6 +213,7 @@ struct RenderParams {
   int32_t n_qtiles, qlog2;      // qlog2: log2(S), S = tile texture size
   float q_per_m;                // quad cells per metre (S / tile_size), max over maps: scales the MSAA margin
   int32_t qmax_tiles;           // largest padded grid extent over the maps (tiles)
+  int32_t* envpos;              // [N] position of each env in the render order (k_env_sort)
   void* dump;                   // 1 KB scratch: masked lanes of the unconditional frame store write here
   void* pixtab;                 // [H*W] PixTab (16 B) then [H*W] SampTab (48 B): per-pixel tables of the shared camera
 };

@@ -43,6 +43,7 @@
 // vector ALUs saturated -- at 19.7 % of the HBM roofline; float32 shading, uint8 output.
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 #define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT DT_PPT         // pixels per thread
@@ -99,7 +100,9 @@ struct alignas(16) EnvQ {
   uint32_t tab_b, pitch4;      // the map's padded tile table inside the LDS copy (byte offset), row pitch in bytes (8-byte entries)
   uint32_t hor_rgb;            // packed horizon colour
   uint32_t sky[3];             // the horizon colour as the three dwords of four consecutive pixels (RGBR GBRG BRGB)
-  uint32_t pad[4];
+  uint32_t reach;              // cells from the camera to the border of the padded grid: hits closer than that need no clamp
+  uint32_t env;                // the env (frame index) at this position of the render order (k_env_sort)
+  uint32_t pad[2];
 };
 static_assert(sizeof(EnvQ) == 64, "EnvQ is 64 bytes");
 
@@ -124,8 +127,50 @@ __device__ inline CamShared default_cam(float aspect) {
   return s;
 }
 
+// Render order of the envs for the quad-layout path: envs standing on the same tile (and facing the same way) are
+// made neighbours, so that the 32 envs a raster workgroup loops over -- and, with the XCD-affine workgroup map of
+// k_raster_q, all the envs one XCD's L2 serves -- look at the same few texture blocks.  A counting sort by
+// (tile under the camera, heading quadrant) in one workgroup; the order inside a bin is arbitrary (frames are
+// independent, so the order never changes a result).  pos[e] = position of env e.
+#define SORT_BINS 4096
+__global__ __launch_bounds__(1024) void k_env_sort(SimArrays A, const RenderMapDev* __restrict__ maps, int32_t* __restrict__ pos) {
+  __shared__ int s_hist[SORT_BINS];
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SORT_BINS; i += 1024) s_hist[i] = 0;
+  __syncthreads();
+  auto bin_of = [&](int e) -> int {
+    const int mid = A.map_id[e] < 0 ? 0 : A.map_id[e];
+    const float its = maps[mid].inv_tile_size;
+    const double ang = A.angle[e];
+    const float px = (float)(A.pos_x[e] + DT_CAMERA_FORWARD_DIST * cos(ang)), pz = (float)(A.pos_z[e] - DT_CAMERA_FORWARD_DIST * sin(ang));
+    const int ti = min(max((int)floorf(px * its), 0), 31), tj = min(max((int)floorf(pz * its), 0), 31);
+    const int quad = ((int)floor(ang * (2.0 / 3.141592653589793) + 0.5)) & 3;
+    return ((((tj << 5) | ti) << 2) | quad) ^ ((mid * 1237) & (SORT_BINS - 1));
+  };
+  for (int e = tid; e < A.N; e += 1024) atomicAdd(&s_hist[bin_of(e)], 1);
+  __syncthreads();
+  // exclusive scan of the bins: each thread owns SORT_BINS / 1024 consecutive bins
+  int loc[SORT_BINS / 1024], sum = 0;
+#pragma unroll
+  for (int k = 0; k < SORT_BINS / 1024; ++k) { loc[k] = sum; sum += s_hist[tid * (SORT_BINS / 1024) + k]; }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  const int base = tid ? s_part[tid - 1] : 0;
+#pragma unroll
+  for (int k = 0; k < SORT_BINS / 1024; ++k) s_hist[tid * (SORT_BINS / 1024) + k] = base + loc[k];
+  __syncthreads();
+  for (int e = tid; e < A.N; e += 1024) pos[e] = atomicAdd(&s_hist[bin_of(e)], 1);
+}
+
 __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
-                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2) {
+                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2, const int32_t* __restrict__ pos) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
   if (e >= A.N) return;
@@ -213,8 +258,13 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
     q.sky[0] = r | (g << 8) | (b << 16) | (r << 24);
     q.sky[1] = g | (b << 8) | (r << 16) | (g << 24);
     q.sky[2] = b | (r << 8) | (g << 16) | (b << 24);
-    q.pad[0] = q.pad[1] = q.pad[2] = q.pad[3] = 0u;
-    envq[e] = q;
+    {
+      const float xmax = (float)(m.grid_w + 2 * DT_QRING) * S, zmax = (float)(m.grid_h + 2 * DT_QRING) * S;
+      const float r = fminf(fminf(q.Cx, xmax - q.Cx), fminf(q.Cz, zmax - q.Cz)) - 2.f;
+      q.reach = r > 0.f ? (uint32_t)fminf(r, 1.0e9f) : 0u;      // NaN / outside the padded grid -> 0: always clamp
+    }
+    q.env = (uint32_t)e; q.pad[0] = q.pad[1] = 0u;
+    envq[pos ? pos[e] : e] = q;
   }
 }
 
@@ -1115,9 +1165,16 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   const int tid = threadIdx.x;
   const int npix = R.W * R.H;
   const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
-  const int tile = blockIdx.x % n_tiles;
-  const int chunk = blockIdx.x / n_tiles;
-  const int e0 = chunk * ENVS_PER_BLOCK;
+  // XCD-affine workgroup map: workgroup b runs on XCD b % 8 (round-robin dispatch), and XCD x is given the x-th
+  // eighth of the env chunks (all frame tiles of each): with the envs in k_env_sort order, one L2 serves the envs of one
+  // region of the map for the whole launch.  The mapping only matters for speed.
+  const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK, cpx = (n_chunks + 7) / 8;
+  const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  const int tile = bi % n_tiles;
+  const int chunk = xcd * cpx + bi / n_tiles;
+  if (chunk >= n_chunks) return;                     // padding workgroups of the last XCD slices (whole workgroup)
+  const int rwg = chunk * n_tiles + tile;            // logical workgroup index: queue regions, counts, work items
+  const int e0 = chunk * ENVS_PER_BLOCK;             // positions in the render order
   const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
   for (int i = tid; i < R.n_qtiles * 2; i += RB) s_qt[i] = qtiles[i];
   __syncthreads();
@@ -1160,7 +1217,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     }
   }
 
-  uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
+  uint16_t* w_queue = queue + ((size_t)rwg * (RB / 64) + wave) * QREGION;
   int qn = 0;
   uint32_t* s_px = s_mem + R.n_qtiles * 2 + wave * WAVE_PIX;
   const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
@@ -1179,11 +1236,11 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     for (int e = e0; e < e1; ++e) {
       const EnvQ f = envq[e];
       if (st_ok) {
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)e * npix * 3 + st_off);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)f.env * npix * 3 + st_off);
         d32[0] = f.sky[0] & m0; d32[1] = f.sky[1] & m1; d32[2] = f.sky[2] & m2;
       }
     }
-    if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = 0;
+    if (lane == 0) qcount[rwg * (RB / 64) + wave] = 0;
   } else {
   typedef float f2 __attribute__((ext_vector_type(2)));
   static_assert(PPT % 2 == 0, "pixel slots are processed in pairs (packed fp32)");
@@ -1196,12 +1253,26 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   unsigned long long candm[PPT], validm[PPT], plainm[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) { candm[k] = __ballot(cand[k]); validm[k] = __ballot(valid[k]); plainm[k] = __ballot(gok[k]); }
+  uint32_t blk_reach;                                // farthest tile-plane hit of the wavefront's pixels from the camera, cells
+  {
+    float r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) r2 = fmaxf(r2, lr[k] * lr[k] + lf[k] * lf[k]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, d));
+    const float r = fsqrt_(r2) * R.q_per_m * 1.0001f + 1.f;
+    blk_reach = (uint32_t)__builtin_amdgcn_readfirstlane((int)(r < 1.0e9f ? (uint32_t)r : 0x7FFFFFFFu));
+  }
+  bool any_invalid = false;                          // wave-uniform
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) any_invalid |= validm[k] != ~0ull;
   // The env loop is software-pipelined two deep: the quad loads of env e+1 are issued BEFORE the frame stores of env e.
   // gfx950 retires vector memory operations of a wavefront in issue order (one vmcnt for loads and stores), so a
   // load issued after a store cannot be waited for without also waiting for that store's write acknowledge; with the
   // loads of the next env ahead of the stores, a wavefront only ever waits for stores that are two envs old.
   struct QStage { uint4 q[PPT]; f2 ax2[PPT / 2], az2[PPT / 2]; };
-  auto issue = [&](const EnvQ& f, QStage& st) __attribute__((always_inline)) {
+  auto issue_t = [&](const EnvQ& f, QStage& st, auto clamp_tag) __attribute__((always_inline)) {
+    constexpr bool CLAMP = decltype(clamp_tag)::value;
     const f2 vA = f2{f.A, f.A}, vB = f2{f.B, f.B}, vCx = f2{f.Cx, f.Cx}, vCz = f2{f.Cz, f.Cz};
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
@@ -1211,7 +1282,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 2 * j + h;
-        const float X = med3f(h ? X2.y : X2.x, lo, f.Xhi), Z = med3f(h ? Z2.y : Z2.x, lo, f.Zhi);
+        float X = h ? X2.y : X2.x, Z = h ? Z2.y : Z2.x;
+        if (CLAMP) { X = med3f(X, lo, f.Xhi); Z = med3f(Z, lo, f.Zhi); }
         const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
         if (h) { st.ax2[j].y = __builtin_amdgcn_fractf(X); st.az2[j].y = __builtin_amdgcn_fractf(Z); }
         else { st.ax2[j].x = __builtin_amdgcn_fractf(X); st.az2[j].x = __builtin_amdgcn_fractf(Z); }
@@ -1242,10 +1314,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   struct alignas(4) U3 { uint32_t a, b, c; };
   // The lane's 12 bytes of frame e.  The store is unconditional (no branch around it, so that the wait counts the
   // compiler derives for the texel loads do not have to cover it): lanes without pixels write to a dump slot.
-  uint8_t* const st_base = st_ok ? frames + (size_t)e0 * npix * 3 + st_off : reinterpret_cast<uint8_t*>(R.dump) + lane * 16;
+  uint8_t* const st_base = st_ok ? frames + st_off : reinterpret_cast<uint8_t*>(R.dump) + lane * 16;
   const uint32_t st_stride = st_ok ? (uint32_t)npix * 3u : 0u;
-  auto store = [&](const int e, const U3& o) __attribute__((always_inline)) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(st_base + (size_t)(uint32_t)(e - e0) * st_stride);
+  auto store = [&](const uint32_t env, const U3& o) __attribute__((always_inline)) {   // env: frame index
+    uint32_t* d = reinterpret_cast<uint32_t*>(st_base + (size_t)env * st_stride);
 #if defined(DT_Q_NO_STORE)
     if (o.a == 0x12345678u) *d = 1u;
 #elif defined(DT_Q_PLAIN_STORE)
@@ -1255,7 +1327,13 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     __builtin_nontemporal_store(o.a, d); __builtin_nontemporal_store(o.b, d + 1); __builtin_nontemporal_store(o.c, d + 2);
 #endif
   };
-  auto finish = [&](const int e, const uint32_t hor_rgb, const QStage& st) __attribute__((always_inline)) -> U3 {
+  // Clamping the coordinates into the padded grid (two v_med3 per pixel) is only needed when a hit of this block can
+  // leave it: the block's farthest hit (cells, env-invariant) against the camera's distance to the border (per env).
+  auto issue = [&](const EnvQ& f, QStage& st) __attribute__((always_inline)) {
+    if (f.reach > blk_reach) issue_t(f, st, std::false_type{});       // wave-uniform, scalar compare
+    else issue_t(f, st, std::true_type{});
+  };
+  auto finish = [&](const int e, const uint32_t env, const uint32_t hor_rgb, const QStage& st) __attribute__((always_inline)) -> U3 {   // e: position, env: frame
     U3 out{0u, 0u, 0u};
     uint32_t px[PPT];
     bool edge[PPT];
@@ -1263,6 +1341,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     const uint4* q = st.q;
     const f2* ax2 = st.ax2; const f2* az2 = st.az2;
     unsigned long long slow = 0ull;                  // lane masks live in SGPR pairs: predicate logic on the scalar unit
+    const uint32_t hor_v = hor_rgb;
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
 #if DT_Q_SCHED_BARRIER
@@ -1292,9 +1371,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
         const uint32_t vb = (__builtin_amdgcn_udot4(q[k].z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].z, wl, 32768u, false);
         const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
         const uint32_t rgb = __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
-        uint32_t base;                                   // horizon colour, 0 where the source pixel is outside the image
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(base) : "v"(hor_rgb), "s"(validm[k]));
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(px[k]) : "v"(base), "v"(rgb), "s"(fm));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(px[k]) : "v"(hor_v), "v"(rgb), "s"(fm));   // not a one-ray tile pixel: clear colour
       }
     }
     if (slow) {                                      // wave-uniform: some pixel is not a certain tile interior
@@ -1304,7 +1381,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
       //     the record does not hold), untextured tiles, the horizon band, and the textured cells the cell-granular
       //     test rejected (conservative by up to a cell; k_resolve redoes it exactly on compacted lanes, which is
       //     cheaper than refining here at a few live lanes per wavefront).
-      const EnvFast g = fasts[e];
+      const EnvFast g = fasts[env];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const unsigned long long sk = candm[k] & ~fastm[k];
@@ -1315,7 +1392,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
         if (gm) {
           const float lrk = (k & 1) ? lr2[k / 2].y : lr2[k / 2].x, lfk = (k & 1) ? lf2[k / 2].y : lf2[k / 2].x;
           const float mrgk = __half2float(__ushort_as_half((unsigned short)(Mi[k] >> 16)));
-          const EnvCam c = cams[e];
+          const EnvCam c = cams[env];
           const float wx = c.Cx + lrk * c.sa + lfk * c.ca, wz = c.Cz + lrk * c.ca - lfk * c.sa;          // tile-plane hit, world
           const float wxg = fmaf(g.kg, wx - c.Cx, c.Cx), wzg = fmaf(g.kg, wz - c.Cz, c.Cz);              // ground-quad hit
           // every sample's tile-plane hit stays clear of the grid rectangle (an absent tile inside the grid goes to
@@ -1335,9 +1412,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     }
 
     if (OBJ) {
-      const ObjEnv oe = R.objenv[e];                 // wave-uniform
+      const ObjEnv oe = R.objenv[env];               // wave-uniform
       if (oe.n_tris > 0 && wbx1 >= oe.bx0 && wbx0 <= oe.bx1 && wby1 >= oe.by0 && wby0 <= oe.by1) {
-        const ObjBox* boxes = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
+        const ObjBox* boxes = R.objbox + (size_t)env * DTSIM_MAX_OBJECTS;
         for (int o = 0; o < oe.n_obj; ++o) {
           const ObjBox ob = boxes[o];                // wave-uniform
           if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
@@ -1348,10 +1425,15 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
       }
     }
 
+    if (any_invalid) {                               // wave-uniform, rare: source pixels outside the rectilinear image are 0
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) px[k] = ((validm[k] >> lane) & 1ull) ? px[k] : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) s_px[k * 64 + lane] = px[k];
     const uint4 o = *reinterpret_cast<const uint4*>(s_px + (lane * 4) % WAVE_PIX);
-    out = U3{o.x | (o.y << 24), (o.y >> 8) | (o.z << 16), (o.z >> 16) | (o.w << 8)};
+    // 4 pixels 0x00BBGGRR -> 12 bytes: three byte permutes
+    out = U3{__builtin_amdgcn_perm(o.y, o.x, 0x04020100u), __builtin_amdgcn_perm(o.z, o.y, 0x05040201u), __builtin_amdgcn_perm(o.w, o.z, 0x06050402u)};
 
     bool any_edge = false;
 #pragma unroll
@@ -1377,40 +1459,62 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     EnvQ fa = envq[e0], fb = envq[min(e0 + 1, e1 - 1)];
     issue(fa, sa);
     for (int e = e0; e < e1; e += 2) {
-      const uint32_t hor_a = fa.hor_rgb, hor_b = fb.hor_rgb;
+      const uint32_t hor_a = fa.hor_rgb, hor_b = fb.hor_rgb, env_a = fa.env, env_b = fb.env;
       issue(fb, sb);                                 // env e+1 (a harmless repeat of the last env past the end)
       fa = envq[min(e + 2, e1 - 1)];
-      const U3 oa = finish(e, hor_a, sa);
-      store(e, oa);
+      const U3 oa = finish(e, env_a, hor_a, sa);
+      store(env_a, oa);
       if (e + 1 < e1) {
         issue(fa, sa);                               // env e+2
         fb = envq[min(e + 3, e1 - 1)];
-        const U3 ob = finish(e + 1, hor_b, sb);
-        store(e + 1, ob);
+        const U3 ob = finish(e + 1, env_b, hor_b, sb);
+        store(env_b, ob);
       }
     }
   }
 #else
+#ifdef DT_Q_TIMING
+#define TSTAMP() __builtin_readcyclecounter()
+  unsigned long long t_issue = 0, t_lds = 0, t_mem = 0, t_filt = 0, t_tail = 0, t_n = 0;
+#endif
   {  // one stage, deferred store: the 12 bytes of env e-1 are held in registers and stored right after the loads of
      // env e have been issued, so that waiting for those loads never waits for a store of the same iteration.
      // No branch between the loads and the store (first env peeled).
     QStage sa;
     EnvQ f = envq[e0];
     issue(f, sa);
-    uint32_t hor = f.hor_rgb;
+    uint32_t hor = f.hor_rgb, env = f.env, env_prev;
     f = envq[min(e0 + 1, e1 - 1)];
-    U3 held = finish(e0, hor, sa);
+    U3 held = finish(e0, env, hor, sa);
     for (int e = e0 + 1; e < e1; ++e) {
-      hor = f.hor_rgb;
+      env_prev = env; hor = f.hor_rgb; env = f.env;
+#ifdef DT_Q_TIMING
+      const unsigned long long t0 = TSTAMP();
+#endif
       issue(f, sa);
-      store(e - 1, held);
+      store(env_prev, held);
       f = envq[min(e + 1, e1 - 1)];                  // next env's constants: the scalar load has the whole filter to land
-      held = finish(e, hor, sa);
+#ifdef DT_Q_TIMING
+      const unsigned long long t1 = TSTAMP();
+      __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): all four quad records (and the store) have landed
+      const unsigned long long t2 = TSTAMP();
+#endif
+      held = finish(e, env, hor, sa);
+#ifdef DT_Q_TIMING
+      const unsigned long long t3 = TSTAMP();
+      t_issue += t1 - t0; t_mem += t2 - t1; t_filt += t3 - t2; t_n += 1;
+#endif
     }
-    store(e1 - 1, held);
+    store(env, held);
+#ifdef DT_Q_TIMING
+    if (lane == 0) {
+      unsigned long long* tc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.dump) + 1024);
+      atomicAdd(tc + 0, t_issue); atomicAdd(tc + 1, t_mem); atomicAdd(tc + 2, t_filt); atomicAdd(tc + 3, t_n);
+    }
+#endif
   }
 #endif
-  if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
+  if (lane == 0) qcount[rwg * (RB / 64) + wave] = qn;
   }
   __shared__ int s_nb[RB / 64];
   if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
@@ -1422,7 +1526,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     if (nb > 0) {
       const int ni = (nb + ITEM_B - 1) / ITEM_B;
       const int pos = atomicAdd(R.work, ni);
-      for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)blockIdx.x * ITEMS_PER_WG + (uint32_t)i;
+      for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)rwg * ITEMS_PER_WG + (uint32_t)i;
     }
   }
 }
@@ -1553,11 +1657,11 @@ __global__ __launch_bounds__(RB) void k_resolve_q(RenderParams R, const EnvCam* 
       const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
       const int el = (int)(ent >> 8), lp = (int)(ent & 255u);
       const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
-      const int e = min(e0 + el, R.N - 1);
       const PixTab pt = pixtab[pix];
-      const EnvQ* fq = envq + e;
+      const EnvQ* fq = envq + min(e0 + el, R.N - 1);   // position in the render order -> constants, frame index
       const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
       const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const int e = (int)fq->env;
       const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
       uint32_t ta_c;
       float ox, oz;
@@ -1590,12 +1694,12 @@ __global__ __launch_bounds__(RB) void k_resolve_q(RenderParams R, const EnvCam* 
       const bool have = l0 + lane < n_list;
       const uint32_t le = have ? w_list[l0 + lane] : 0u;
       const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
-      const int e = min(e0 + el, R.N - 1);
       const PixTab pt = pixtab[pix];
       const SampTab sp = samptab[pix];
-      const EnvQ* fq = envq + e;
+      const EnvQ* fq = envq + min(e0 + el, R.N - 1);
       const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
       const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const int e = (int)fq->env;
       const EnvCam* c = cams + e;
       const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
       const float kg = (wCy - GROUND_Y) / wCy;
@@ -1658,7 +1762,7 @@ __global__ __launch_bounds__(RB) void k_resolve_q(RenderParams R, const EnvCam* 
         for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
       }
       const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
-      if (have) store_rgb(e0 + el, pix, pack_rgb(o));
+      if (have) store_rgb(e, pix, pack_rgb(o));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1821,8 +1925,13 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0;
+  const bool obj = R.max_tris > 0;
+  // render order (k_env_sort): only the quad pipeline without mesh objects indexes by position (k_resolve<true> and
+  // k_obj_setup address envs directly)
+  int32_t* pos = (quad && !obj && R.envpos) ? R.envpos : nullptr;
+  if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
-                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2);
+                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos);
   if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
   (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
@@ -1831,16 +1940,16 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
   const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
+  const dim3 gridq((unsigned)(dt_raster_tiles(R.W, R.H) * ((n_chunks + 7) / 8) * 8));   // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
-  const bool obj = R.max_tris > 0;
   if (quad) {
     const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
     PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
     hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
-#define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), grid, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
+#define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, R.qtiles, R.queue, R.qcount)
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
     if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
