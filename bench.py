@@ -145,6 +145,63 @@ def main_c2(args):
     sim.close()
 
 
+def main_c1(args):
+    """BASELINE.json configs[0]: Duckietown-small_loop-v0, 1 env, random actions, 84x84 observations -- the reference's
+    CPU-runnable plumbing case.  Here: the drop-in gym_duckietown.DuckietownEnv (an N = 1 view of the HIP library) stepped
+    with reset-on-done like a gym loop, observations copied to the host every step as gym requires; beside it the CPU
+    oracle doing the same work (oracle physics + software raster at 84x84)."""
+    from gym_duckietown.envs import DuckietownEnv
+    K, Wm = args.steps, args.warmup
+    env = DuckietownEnv(map_name="small_loop", domain_rand=False, seed=1000, camera_width=84, camera_height=84,
+                        device=int(os.environ.get("LOCAL_RANK", "0")))
+    rng = np.random.default_rng(1234)
+    env.reset()
+    for _ in range(Wm):
+        _, _, d, _ = env.step(rng.uniform(-1, 1, 2))
+        if d:
+            env.reset()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        obs, _, d, _ = env.step(rng.uniform(-1, 1, 2))
+        if d:
+            env.reset()
+    dt = time.perf_counter() - t0
+    assert obs.shape == (84, 84, 3)
+    cpu = None
+    if args.cpu_steps > 0:
+        from dtsim import assets
+        from oracle import raster, sim as osim
+        ext = assets.mesh_extents(("duckie",))
+        o = osim.OracleSim(assets.get_map("small_loop"), ext, domain_rand=False, seed=1000)
+        kinds = {t["kind"] for t in o.map.grid if t is not None}
+        scene = raster.Scene(o.map, {k: assets.get_texture(k) for k in kinds},
+                             {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")})
+        n = max(4, args.cpu_steps)
+        t1 = time.perf_counter()
+        for _ in range(n):
+            _, dn, _ = o.step_vel_steer(rng.uniform(-1, 1, 2))
+            cam = raster.Camera(o.cur_pos, o.cur_angle, width=84, height=84, horizon_color=o.horizon_color, ground_color=o.ground_color)
+            raster.render_obs(cam, scene, "gouraud", None)
+            if dn:
+                o.reset()
+        cpu = {"value": n / (time.perf_counter() - t1), "unit": "env-steps/s", "cores": 1, "kind": "port",
+               "sample": f"{n} env-steps of small_loop at 84x84 on the numpy oracle (the reference's Pyglet path is not runnable here)"}
+    k_ms = 1e3 * dt / K
+    print(json.dumps({
+        "metric": "env-steps/sec (1 env, 84x84 obs, gym loop)", "value": K / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": K,
+        "warmup": Wm, "ms_per_step": k_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 raster -> u8 frames; f64 physics", "data": "synthetic",
+        "config": {"workload": "Duckietown-small_loop-v0 (fixture), 1 env through gym_duckietown.DuckietownEnv, random (vel, steer) "
+                               "actions, 84x84 observations copied to the host every step [BASELINE.json configs[0]]",
+                   "envs_per_gpu": 1, "camera": [84, 84]},
+        "roofline": {"bound": "hbm", "achieved": 84 * 84 * 3 / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                     "frac": 84 * 84 * 3 / (k_ms * 1e-3) / PEAK_HBM, "traffic": None,
+                     "note": "one env is launch- and host-round-trip bound (several kernel launches + a D2H copy per step); "
+                             "the roofline fraction is reported for completeness only"},
+        "cpu_baseline": cpu}), flush=True)
+    env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,8 +211,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=32, help="oracle env-steps for cpu_baseline (about 15 s on one host core)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="give up on the frame exchange after this many seconds")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5"],
-                    help="c3 (default, the headline): raster + fisheye; c2: dynamics+collision only, render off "
+    ap.add_argument("--config", default="c3", choices=["c3", "c1", "c2", "c4", "c5"],
+                    help="c3 (default, the headline): raster + fisheye; c1: ONE env through the gym facade, 84x84 observations, "
+                         "random actions, with the CPU oracle beside it (BASELINE.json configs[0], the plumbing case); "
+                         "c2: dynamics+collision only, render off "
                          "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch; "
                          "c4: loop_pedestrians + domain randomisation (configs[3]); c5: MultiMap, two maps alternating "
                          "per env slot (configs[4])")
@@ -163,6 +222,8 @@ def main():
     args = ap.parse_args()
     if args.config == "c2":
         return main_c2(args)
+    if args.config == "c1":
+        return main_c1(args)
 
     import torch
     import torch.distributed as dist
@@ -191,13 +252,13 @@ def main():
     N, K, Wm = args.envs, args.steps, args.warmup
     variant = {
         "c3": dict(maps="small_loop", dr=False, label="Duckietown-small_loop-v0 (fixture)", ref="configs[2]",
-                   kern="k_raster<DR=0,OBJ=0> + k_resolve<OBJ=0>", extra={}),
+                   kern="k_env_sort + k_pix_setup + k_raster_q<OBJ=0> + k_resolve_q", extra={}),
         "c4": dict(maps="loop_pedestrians", dr=True, label="Duckietown-loop_pedestrians-v0 (stand-in: loop_only_duckies with "
                    "static: False, 8 walking duckies), dynamic obstacles + domain randomisation", ref="configs[3]",
                    kern="k_obj_setup + k_raster<DR=1,OBJ=1> + k_resolve<OBJ=1>", extra={}),
         "c5": dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, label="MultiMap-v0 (loop_only_duckies / "
                    "small_loop_only_duckies alternating per env slot, multimap_env.py:17,44-49)", ref="configs[4]",
-                   kern="k_obj_setup + k_raster<DR=0,OBJ=1> + k_resolve<OBJ=1>", extra=dict(map_cycle=True)),
+                   kern="k_obj_setup + k_pix_setup + k_raster_q<OBJ=1> + k_resolve<OBJ=1>", extra=dict(map_cycle=True)),
     }[args.config]
     sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=True, camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
@@ -245,13 +306,22 @@ def main():
     def emit(gather_, cpu_=None):
         k_ms = ms_r / max(n_r, 1)
         achieved = N * FRAME_BYTES / (k_ms * 1e-3)
-        traffic = None
+        # HBM-side traffic and VALU instruction counts cannot be collected inside this process (rocprofv3 PMC passes
+        # wrap the whole command): they are read from the committed summary of the same command's counter runs and
+        # labelled with where they came from; null when that file is for another workload.
+        traffic = traffic_source = valu = None
         pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
         if os.path.exists(pj):
             try:
                 d = json.load(open(pj))
                 if d.get("envs") == N and args.config == "c3":
                     traffic = d.get("hbm_bytes_per_launch")
+                    traffic_source = d.get("source")
+                    if d.get("valu_per_pixel") is not None:
+                        clk = d.get("clock_ghz", 2.1) * 1e9
+                        valu = {"ops_per_pixel": d["valu_per_pixel"], "source": d.get("source"),
+                                "peak_lane_ops_per_s": 1024 * clk / 4 * 64,      # 1024 SIMDs, one wave64 op per 4 cycles (profiles/r02_ubench_valu_rates.txt)
+                                "achieved_lane_ops_per_s": d["valu_per_pixel"] * N * W * H / (k_ms * 1e-3)}
             except Exception:
                 pass
         line = {
@@ -273,14 +343,9 @@ def main():
                        "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
-                         "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
-                         "step_kernel_ms": ms_s / max(n_s, 1),
-                         # the pass is VALU-issue bound, not HBM bound: PMC SQ_INSTS_VALU of k_raster
-                         # = 64.8 lane-operations per pixel (profiles/r01e_raster_sq_ta_pmc_summary.txt) against
-                         # 1024 SIMDs x 2.1 GHz / 4 cycles x 64 lanes
-                         "valu": {"ops_per_pixel": 64.8, "peak_lane_ops_per_s": 1024 * 2.1e9 / 4 * 64,
-                                  "achieved_lane_ops_per_s": 64.8 * N * W * H / (k_ms * 1e-3) if args.config == "c3" else None}},
+                         "step_kernel_ms": ms_s / max(n_s, 1), "valu": valu},
             "cpu_baseline": cpu_,
             "gather": gather_,
             "episodes_per_env": done_frac,

@@ -149,6 +149,7 @@ size_t layout_arrays(SimArrays& A, int N, char* base) {
   A.ob_light = carve<uint8_t>(p, n * DTSIM_MAX_OBJECTS);
   A.tl_time = carve<double>(p, n);
   A.ob_cy = carve<double>(p, n * DTSIM_MAX_DYNAMIC);
+  A.ob_ext = carve<double>(p, n * DTSIM_MAX_DYNAMIC * 5);
   return (size_t)(p - base);
 }
 
@@ -759,7 +760,12 @@ int dtsim_set_spawn_pool(dtsim_t* h, const dtsim_init_state* pool, int n_pool) {
 }
 
 int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_device) {
+  return dtsim_step_ex(h, actions, n_steps, actions_on_device, 0u);
+}
+
+int dtsim_step_ex(dtsim_t* h, const void* actions, int n_steps, int actions_on_device, uint32_t flags) {
   if (!h || !actions || n_steps <= 0) return fail(DTSIM_E_INVALID, "bad argument");
+  if (flags & ~(uint32_t)(DTSIM_STEP_ONE_UPDATE | DTSIM_STEP_POSE_ONLY)) return fail(DTSIM_E_INVALID, "unknown step flags 0x%x", flags);
   if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_step before dtsim_set_maps/dtsim_reset");
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t esz = (h->cfg.flags & DTSIM_F_ACTIONS_F64) ? 8 : 4;
@@ -780,7 +786,9 @@ int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_devi
   }
   {
     ProfScope ps(h, DTSIM_KERNEL_STEP);
-    dt_launch_step(h->stream, h->A, h->M, step_params(h, n_steps), dptr, h->d_pool);
+    StepParams sp = step_params(h, n_steps);
+    sp.step_flags = flags;
+    dt_launch_step(h->stream, h->A, h->M, sp, dptr, h->d_pool);
   }
   HIPCHK(hipGetLastError());
   return DTSIM_OK;
@@ -996,6 +1004,9 @@ bool field_desc(dtsim* h, int field, FieldDesc& d) {
     case DTSIM_FIELD_OBJ_LIGHT: d = {A.ob_light, 1, DTSIM_MAX_OBJECTS, N, true}; return true;
     case DTSIM_FIELD_OBJ_Y: d = {A.ob_cy, 8, DTSIM_MAX_DYNAMIC, N, true}; return true;
     case DTSIM_FIELD_EPISODE: d = {A.episode, 4, 1, N, true}; return true;
+    case DTSIM_FIELD_CAMERA: d = {A.cam, 4, 6, N, true}; return true;
+    case DTSIM_FIELD_COLORS: d = {A.colors, 4, 16, N, true}; return true;
+    case DTSIM_FIELD_WHEEL_DIST: d = {A.wheel_dist, 8, 1, N, true}; return true;
     default: return false;
   }
 }
@@ -1007,6 +1018,7 @@ size_t public_bytes(const dtsim* h, int field) {
     case DTSIM_FIELD_TILE: return N * 2 * 4;
     case DTSIM_FIELD_OBJ_CENTER: return N * DTSIM_MAX_DYNAMIC * 2 * 8;
     case DTSIM_FIELD_OBJ_PARAMS: return N * DTSIM_MAX_DYNAMIC * 3 * 8;
+    case DTSIM_FIELD_OBJ_EXTRA: return N * DTSIM_MAX_DYNAMIC * 5 * 8;
     case DTSIM_FIELD_STATE_BLOB: return h->slab_bytes;
     default: {
       FieldDesc d;
@@ -1065,6 +1077,10 @@ int field_xfer(dtsim* h, int field, void* host, size_t bytes, bool to_host) {
     case DTSIM_FIELD_OBJ_PARAMS:
       for (int d = 0; d < DTSIM_MAX_DYNAMIC; ++d) { bases.push_back(A.ob_vel + d * N); bases.push_back(A.ob_wait + d * N); bases.push_back(A.ob_wiggle + d * N); }
       return xfer_planar(h, bases.data(), DTSIM_MAX_DYNAMIC * 3, 8, host, to_host);
+    case DTSIM_FIELD_OBJ_EXTRA:
+      for (int d = 0; d < DTSIM_MAX_DYNAMIC; ++d)
+        for (int k = 0; k < 5; ++k) bases.push_back(A.ob_ext + ((size_t)k * DTSIM_MAX_DYNAMIC + d) * N);
+      return xfer_planar(h, bases.data(), DTSIM_MAX_DYNAMIC * 5, 8, host, to_host);
     default: {
       FieldDesc d;
       field_desc(h, field, d);

@@ -80,12 +80,15 @@ struct SimArrays {
   uint8_t *ob_visible;     // [DTSIM_MAX_OBJECTS][N]
   uint8_t *ob_light;       // [DTSIM_MAX_OBJECTS][N] TrafficLightObj.pattern
   double *ob_cy;           // [DTSIM_MAX_DYNAMIC][N] centre height (CheckerboardObj; 0 for the others)
+  double *ob_ext;          // [5][DTSIM_MAX_DYNAMIC][N] DuckiebotObj follow_dist, radius, wheel_dist, robot_width, robot_length
   double *tl_time;         // [N] TrafficLightObj.time (object clock: not reset with the env, objects.py:441,459)
 };
 
 struct StepParams {
   int32_t n_steps, frame_skip, max_steps, delay_steps;
   int32_t action_mode, actions_f64, auto_reset, n_pool;
+  uint32_t step_flags;                  // DTSIM_STEP_*
+  int32_t pad_;
   const dtsim_reset_sampler* sampler;   // device copy, or null: device-side reset sampling (N2)
   double delta_time, robot_speed;
   double gain, trim, radius, k, limit;

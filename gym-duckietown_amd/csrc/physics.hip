@@ -390,8 +390,11 @@ __device__ inline void duckiebot_step(const SimArrays& A, const MapView& m, cons
   const double px = A.ob_cx[ix], pz = A.ob_cz[ix], ang = A.ob_angle[ix];
   const Lane c0 = lane_pos(m, px, pz, ang);
   if (!c0.in_lane) return;          // the reference raises here; the follower is left where it is
-  const double follow_dist = di.walk_distance, velocity = di.vel, gain = di.wait_time, trim = di.wiggle;
-  const double radius = 0.0318, kk = 27.0, limit = 1.0, wheel_dist = 0.102;
+  // per-env parameters (objects.py:198-215: constants, or drawn per instance under domain randomisation)
+  const double velocity = A.ob_vel[ix], gain = A.ob_wait[ix], trim = A.ob_wiggle[ix];
+  const double follow_dist = A.ob_ext[((size_t)0 * DTSIM_MAX_DYNAMIC + d) * N + e], radius = A.ob_ext[((size_t)1 * DTSIM_MAX_DYNAMIC + d) * N + e];
+  const double wheel_dist = A.ob_ext[((size_t)2 * DTSIM_MAX_DYNAMIC + d) * N + e];
+  const double kk = 27.0, limit = 1.0;
   double lookup = follow_dist;
   Lane c1;
   c1.in_lane = false;
@@ -431,7 +434,7 @@ __device__ inline void duckiebot_step(const SimArrays& A, const MapView& m, cons
   A.ob_yrot[ix] = A.ob_yrot[ix] + rot * 180 / 3.141592653589793;
   // agent_boundbox(pos, robot_width, robot_length, dir, right) collision.py:9-34
   const double ndx = cos(nang), ndz = -sin(nang), nrx = sin(nang), nrz = cos(nang);
-  const double hw = 0.5 * DT_ROBOT_WIDTH, hl = 0.5 * DT_ROBOT_LENGTH;
+  const double hw = 0.5 * A.ob_ext[((size_t)3 * DTSIM_MAX_DYNAMIC + d) * N + e], hl = 0.5 * A.ob_ext[((size_t)4 * DTSIM_MAX_DYNAMIC + d) * N + e];
   const double cx4[4] = {(npx - hw * nrx) - hl * ndx, (npx + hw * nrx) - hl * ndx, (npx + hw * nrx) + hl * ndx, (npx - hw * nrx) + hl * ndx};
   const double cz4[4] = {(npz - hw * nrz) - hl * ndz, (npz + hw * nrz) - hl * ndz, (npz + hw * nrz) + hl * ndz, (npz - hw * nrz) + hl * ndz};
 #pragma unroll
@@ -521,6 +524,21 @@ __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, co
           A.ob_vel[ix] = fabs(rng_normal(g, 0.02, 0.005));                // np.abs(np.random.normal(0.02, 0.005))
         }
         A.ob_wiggle[ix] = 3.141592653589793 / (double)(14 + rng_below(g, 3));   // np.pi / choice([14, 15, 16]): always drawn
+      }
+      {  // DuckiebotObj.__init__ (objects.py:198-215): DynInit carries follow_dist / velocity / gain / trim of the non-DR branch
+        double ext[5] = {dyn[d].walk_distance, 0.0318, 0.102, DT_ROBOT_WIDTH, DT_ROBOT_LENGTH};
+        if (rs != nullptr && rs->domain_rand && dyn[d].kind == 2) {   // the DR branch, device sampler only (np.random there: unseeded)
+          Philox g = philox_object(rs->seed, (uint32_t)e, (uint32_t)A.episode[e], (uint32_t)d, DT_OBJ_EVENT_CREATE);
+          ext[0] = rng_uniform(g, 0.3, 0.4);                              // follow_dist
+          A.ob_vel[ix] = rng_uniform(g, 0.05, 0.15);                      // velocity
+          A.ob_wait[ix] = dyn[d].wait_time + rng_uniform(g, -0.3, 0.3);   // gain + U(-0.3, 0.3)
+          A.ob_wiggle[ix] = dyn[d].wiggle + rng_uniform(g, -0.1, 0.1) + 2;   // trim + U(-0.1, 0.1) + 2   (objects.py:203, sic)
+          ext[1] = 0.0318 + 0.0002 * rng_uniform(g, -1.0, 1.0);
+          ext[2] = 0.102 + 0.01 * rng_uniform(g, -1.0, 1.0);
+          ext[3] = DT_ROBOT_WIDTH + 0.01 * rng_uniform(g, -1.0, 1.0);
+          ext[4] = DT_ROBOT_LENGTH + 0.01 * rng_uniform(g, -1.0, 1.0);
+        }
+        for (int k = 0; k < 5; ++k) A.ob_ext[((size_t)k * DTSIM_MAX_DYNAMIC + d) * N + e] = ext[k];
       }
       A.ob_yrot[ix] = dyn[d].angle * (180 / 3.141592653589793);
       A.ob_active[ix] = 0;
@@ -619,6 +637,11 @@ __device__ inline dtsim_init_state sample_init(const SimArrays& A, const MapSet&
   // spawn loop (simulator.py:692-738)
   const double ts = m.h->tile_size, M_deg = rs.accept_start_angle_deg;
   st.pos[0] = 1.0; st.pos[1] = 0.0; st.pos[2] = 1.0; st.angle = 1.0;                 // fallback pose :732-736
+  if (rs.has_start_pose[map_id]) {                   // the map specifies a starting pose (simulator.py:679-688): no rejection loop
+    st.pos[0] = ti * ts + rs.start_pose[map_id][0]; st.pos[2] = tj * ts + rs.start_pose[map_id][1];
+    st.angle = rs.start_pose[map_id][2];
+    return st;
+  }
   for (int a = 0; a < rs.max_attempts; ++a) {
     const double x = rng_uniform(g, ti, ti + 1) * ts, z = rng_uniform(g, tj, tj + 1) * ts;
     const double ang = rng_uniform(g, 0.0, 6.283185307179586);
@@ -679,10 +702,12 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
   const int N = A.N;
   if (e >= N) return;
   const double dt = P.delta_time;
+  const bool pose_only = (P.step_flags & DTSIM_STEP_POSE_ONLY) != 0;     // `_update_pos` (simulator.py:2076-2088)
+  const int n_updates = (P.step_flags & (DTSIM_STEP_ONE_UPDATE | DTSIM_STEP_POSE_ONLY)) ? 1 : P.frame_skip;
 
   for (int s = 0; s < P.n_steps; ++s) {
     // ---- auto reset (DTSIM_F_AUTO_RESET): the caller's reset() after a done=True
-    if (P.auto_reset && A.done[e]) {
+    if (P.auto_reset && !pose_only && A.done[e]) {
       const int ep = A.episode[e] + 1;
       A.episode[e] = ep;
       if (SAMPLER) {                                 // device-side sampling (takes precedence over the pool)
@@ -708,7 +733,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     if (P.actions_f64) { a0 = ((const double*)actions)[aoff]; a1 = ((const double*)actions)[aoff + 1]; }
     else { a0 = (double)((const float*)actions)[aoff]; a1 = (double)((const float*)actions)[aoff + 1]; }
     double left, right;
-    if (P.action_mode == DTSIM_ACTION_VEL_STEER) {
+    if (P.action_mode == DTSIM_ACTION_VEL_STEER && !pose_only) {
       const double vel = a0, steer = a1, baseline = A.wheel_dist[e];
       const double k_r_inv = (P.gain + P.trim) / P.k, k_l_inv = (P.gain - P.trim) / P.k;
       const double omega_r = (vel + 0.5 * steer * baseline) / P.radius;
@@ -717,9 +742,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       right = fmax(fmin(u_r, P.limit), -P.limit);
       left = fmax(fmin(u_l, P.limit), -P.limit);
     } else { left = a0; right = a1; }
-    left = fmin(fmax(left, -1.0), 1.0);   // np.clip(action, -1, 1) simulator.py:1670
-    right = fmin(fmax(right, -1.0), 1.0);
-    A.wheels[e] = left; A.wheels[(size_t)N + e] = right;
+    if (!pose_only) {
+      left = fmin(fmax(left, -1.0), 1.0);   // np.clip(action, -1, 1) simulator.py:1670 (Simulator.step only)
+      right = fmin(fmax(right, -1.0), 1.0);
+      A.wheels[e] = left; A.wheels[(size_t)N + e] = right;
+    }
 
     // ---- frame_skip x update_physics (simulator.py:1551-1584)
     Dyn q = {A.q_x[e], A.q_y[e], A.q_c[e], A.q_s[e], A.vel_u[e], A.vel_w[e]};
@@ -729,7 +756,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     int sc = A.step_count[e];
     double ts_ = A.timestamp[e], speed = A.speed[e];
     const double Hts = m.h->grid_h * m.h->tile_size;
-    for (int f = 0; f < P.frame_skip; ++f) {
+    for (int f = 0; f < n_updates; ++f) {
       double l_use = left, r_use = right;
       if (P.delay_steps > 0) {  // ApplyDelay: command issued delay_steps ago
         l_use = A.ring[(size_t)(2 * head) * N + e];
@@ -743,6 +770,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       const double nx = q.x, nz = Hts - q.y;
       const double ddx = nx - px, ddz = nz - pz;
       px = nx; pz = nz; ang = atan2(q.s, q.c);
+      if (pose_only) continue;                         // `_update_pos` stops here
       sc += 1; ts_ += dt;
       speed = sqrt((ddx * ddx + 0.0) + ddz * ddz) / dt;
       for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
@@ -764,6 +792,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     A.q_x[e] = q.x; A.q_y[e] = q.y; A.q_c[e] = q.c; A.q_s[e] = q.s; A.vel_u[e] = q.u; A.vel_w[e] = q.w;
     A.pos_x[e] = px; A.pos_z[e] = pz; A.angle[e] = ang;
     A.ring_head[e] = head; A.step_count[e] = sc; A.timestamp[e] = ts_; A.speed[e] = speed;
+    if (pose_only) continue;
 
     // ---- _compute_done_reward (simulator.py:1685-1705)
     int ti, tj;

@@ -1126,6 +1126,236 @@ __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixT
   samptab[pix] = sp;
 }
 
+__device__ inline float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+// ---- resolve_region: exact path of the quad-layout pipeline (shared camera, no mesh objects) ----------------------
+// Called by every wavefront of k_raster_q at the end of its env loop on ITS OWN queue region (the entries it appended):
+// no second launch, no work list, no atomics -- and the gather-bound resolve of one wavefront overlaps the VALU-bound
+// env loops of the other wavefronts on the CU.  Per entry (one pixel of one env):
+//   1. the pixel's centre hit -> padded quad coordinates -> its tile's table entry and quad record, as in k_raster_q;
+//   2. exact interior test (distance of the hit to the tile boundary, in cells, against the MSAA reach): the
+//      cell-granular test of k_raster_q is conservative by up to a cell and sends every pixel of the seam cell here;
+//      most entries pass and get the one-ray colour from the same integer filter (bit-identical to k_raster_q);
+//   3. otherwise the four samples: their tile-plane hits in the yaw-local frame are env-invariant (SampTab, built by
+//      k_pix_setup), so a sample costs one 2x2 transform and one table lookup.  Coverage per sample (tile if the
+//      tile plane is hit within [near, far] on a present tile; else the ground quad if hit within range and inside
+//      +-50 m; else the clear colour), shading once per distinct primitive at the pixel centre (GL semantics:
+//      simulator.py:1932-1934, graphics.py:172-251): a tile is shaded with ITS texture at the centre hit -- outside the
+//      tile the coordinate wraps (GL_REPEAT), which the quad records encode -- times the centre's lit factor.
+__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias) {
+  const float axI = ax * I, azI = az * I;
+  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
+  uint32_t WA, WB;
+  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+  // three 24-bit sums  sum(tap * w16)  packed as bytes 2 of (vr, vg, vb) when bias = 32768; callers that need the
+  // unrounded value pass bias = 0 and use quad_filter3
+  const uint32_t vr = (__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, bias, false);
+  const uint32_t vg = (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, bias, false);
+  const uint32_t vb = (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, bias, false);
+  const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
+  return __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
+}
+__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats
+  const float axI = ax * I, azI = az * I;
+  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
+  uint32_t WA, WB;
+  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+  const uint32_t v[3] = {(__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, 0u, false),
+                         (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, 0u, false),
+                         (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
+}
+
+#define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
+template <bool S256>
+__device__ inline void resolve_region(const RenderParams& R, const EnvCam* __restrict__ cams, const EnvQ* __restrict__ envq,
+                                      const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
+                                      const uint8_t* __restrict__ qtex, const uint32_t* s_qt, uint32_t* w_list,
+                                      const uint16_t* w_queue, const int n, const int e0, const int tile_x0, const int wave_y0,
+                                      const int lane) {
+  const int npix = R.W * R.H;
+  const int LS = R.qlog2;
+  const uint32_t SM = (1u << LS) - 1u;
+  const float Sf = (float)(1 << LS), lo = 0.5f * Sf;
+  const char* qtb = reinterpret_cast<const char*>(s_qt);
+
+  // Table entry (block byte offset, cell selector) of the tile that OWNS padded quad coordinates (X, Z): tile
+  // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
+  // on (X - 0.5, Z - 0.5) -- unlike the record lookup, which goes by whole cells.  (ox, oz): the tile's origin.
+  auto tile_entry = [&](float X, float Z, const float Xhi, const float Zhi, const uint32_t tab_b, const uint32_t pitch4, uint32_t& ta,
+                        float& ox, float& oz) -> uint2 {
+    const float Xc = med3f(X - 0.5f, lo, Xhi), Zc = med3f(Z - 0.5f, lo, Zhi);
+    const uint32_t ti = (uint32_t)flr_i32(Xc) >> LS, tj = (uint32_t)flr_i32(Zc) >> LS;
+    ox = (float)(ti << LS) + 0.5f; oz = (float)(tj << LS) + 0.5f;
+    ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
+    return *reinterpret_cast<const uint2*>(qtb + ta);
+  };
+  // quad record of block entry `te` at the cell the (unclamped) coordinates fall into, wrapped into the tile
+  auto tile_quad = [&](const uint2 te, float X, float Z) -> uint4 {
+    const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
+    uint32_t local;
+    if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);
+    else local = (((zi & SM) << LS) | (xi & SM)) & te.y;
+    return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
+  };
+  auto store_rgb = [&](int e, int pix, uint32_t rgb) {
+    uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
+    // two stores: a 2-byte aligned half + one byte, whichever way the pixel's 3 bytes fall
+    const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;
+    uint8_t* p8 = odd ? dst : dst + 2;
+    uint16_t* p16 = reinterpret_cast<uint16_t*>(odd ? dst + 1 : dst);
+    *p8 = (uint8_t)(odd ? rgb : rgb >> 16);
+    *p16 = (uint16_t)(odd ? rgb >> 8 : rgb);
+  };
+
+  for (int r0 = 0; r0 < n; r0 += RQ_LIST) {          // wave-uniform: rounds of up to RQ_LIST entries
+    int n_list = 0;                                  // wave-uniform
+    // ---- phase 1: per entry, the exact interior test; interior entries get the one-ray colour, the others are
+    // compacted into the wavefront's list for phase 2
+    // The four 64-entry batches of the round go through every stage together, so that each dependent memory round trip
+    // (entry -> tables -> tile entry -> quad record -> store) is paid once per 256 entries: the phase is latency bound.
+    constexpr int U = RQ_LIST / 64;
+    bool have[U], interior[U];
+    int pix[U], el[U], env[U];
+    PixTab pt[U];
+    float Xu[U], Zu[U];
+    uint2 te_c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      have[u] = r0 + u * 64 + lane < n;
+      // the entries were written by this wavefront a moment ago: bypass the (possibly stale) L1 line
+      const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + u * 64 + lane) : 0u;
+      el[u] = (int)(ent >> 8);
+      const int lp = (int)(ent & 255u);
+      pix[u] = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
+    }
+    float4 qa[U];
+    uint4 qb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pt[u] = pixtab[pix[u]];
+      const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
+      qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
+      qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
+      env[u] = (int)fq->env;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float A = qa[u].x, B = qa[u].y, Cx = qa[u].z, Cz = qa[u].w;
+      const float Xhi = __uint_as_float(qb[u].x), Zhi = __uint_as_float(qb[u].y);
+      Xu[u] = fmaf(pt[u].lf, B, fmaf(pt[u].lr, A, Cx)); Zu[u] = fmaf(pt[u].lf, -A, fmaf(pt[u].lr, B, Cz));
+      uint32_t ta_c;
+      float ox, oz;
+      te_c[u] = tile_entry(Xu[u], Zu[u], Xhi, Zhi, qb[u].z, qb[u].w, ta_c, ox, oz);
+      // distance of the hit to the boundary of the tile that owns it, in cells, against the MSAA reach
+      const float mrg = __half2float(__ushort_as_half((unsigned short)(pt[u].mi >> 16)));   // metres, rounded up
+      const float ux = Xu[u] - ox, uz = Zu[u] - oz;        // in [0, S) inside the owner tile
+      const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
+      const bool in_range = Xu[u] - 0.5f >= lo && Xu[u] - 0.5f <= Xhi && Zu[u] - 0.5f >= lo && Zu[u] - 0.5f <= Zhi;
+      interior[u] = have[u] && in_range && te_c[u].x >= 32u && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
+    }
+    uint4 qc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]);   // always in bounds (record 0 / 1 for non-tiles)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
+      if (interior[u]) store_rgb(env[u], pix[u], rgb);
+      const bool msaa = have[u] && !interior[u];
+      const unsigned long long mm = __ballot(msaa);
+      if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix[u] | ((uint32_t)el[u] << 24);
+      n_list += __popcll(mm);
+    }
+    // ---- phase 2: the four samples of the listed pixels, on dense lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int l0 = 0; l0 < n_list; l0 += 64) {          // wave-uniform
+      const bool have = l0 + lane < n_list;
+      const uint32_t le = have ? w_list[l0 + lane] : 0u;
+      const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
+      const PixTab pt = pixtab[pix];
+      const SampTab sp = samptab[pix];
+      const EnvQ* fq = envq + min(e0 + el, R.N - 1);
+      const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
+      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const int e = (int)fq->env;
+      const EnvCam* c = cams + e;
+      const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
+      const float kg = (wCy - GROUND_Y) / wCy;
+      const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
+      const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
+      const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
+      // coverage: per sample tile (tile plane hit within [near, far] on a present tile), else ground quad, else clear colour
+      uint32_t key[4];                                 // 0 sky, 1 ground, else 2 + table address of the tile
+      uint2 te[4];
+      int n_sky = 0, n_gnd = 0;
+      float gwx = 0.f, gwz = 0.f;                      // ground hit used for shading: the lowest-index ground sample's
+#pragma unroll
+      for (int s = 3; s >= 0; --s) {
+        const uint32_t hr = sp.dlr[s >> 1], hf = sp.dlf[s >> 1];
+        const float slr = pt.lr + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hr >> 16 : hr)));
+        const float slf = pt.lf + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hf >> 16 : hf)));
+        const float Xs = fmaf(slf, B, fmaf(slr, A, Cx)), Zs = fmaf(slf, -A, fmaf(slr, B, Cz));
+        uint32_t ta;
+        float sox, soz;
+        te[s] = tile_entry(Xs, Zs, Xhi, Zhi, tab_b, pitch4, ta, sox, soz);
+        const bool s_in = Xs - 0.5f >= lo && Xs - 0.5f <= Xhi && Zs - 0.5f >= lo && Zs - 0.5f <= Zhi;
+        const bool is_tile = ((sp.flags >> s) & 1u) && s_in && te[s].x != 0u;
+        // ground-quad hit of the sample (world): camera + kg * (tile-plane hit - camera)
+        const float wx = kg * (slr * sa + slf * ca) + wCx, wz = kg * (slr * ca - slf * sa) + wCz;
+        const bool is_gnd = !is_tile && ((sp.flags >> (4 + s)) & 1u) && fabsf(wx) <= GROUND_HALF && fabsf(wz) <= GROUND_HALF;
+        key[s] = !have ? 0u : is_tile ? 2u + ta : is_gnd ? 1u : 0u;
+        n_sky += key[s] == 0u; n_gnd += key[s] == 1u;
+        if (is_gnd) { gwx = wx; gwz = wz; }
+      }
+      // shading, once per primitive at the pixel centre
+      float acc[3];
+      acc[0] = (float)n_sky * c->hor[0]; acc[1] = (float)n_sky * c->hor[1]; acc[2] = (float)n_sky * c->hor[2];
+      if (__ballot(have && n_gnd > 0)) {               // wave-uniform
+        if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) {   // the centre ray hits the planes: shade at its ground hit
+          gwx = kg * (pt.lr * sa + pt.lf * ca) + wCx; gwz = kg * (pt.lr * ca - pt.lf * sa) + wCz;
+        }
+        const float a_ = fminf(fmaxf((gwx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+        const float b_ = fminf(fmaxf((gwz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+        const float n0 = c->gndl[0] + a_ * (c->gndl[1] - c->gndl[0]), n1 = c->gndl[2] + a_ * (c->gndl[3] - c->gndl[2]);
+        const float ndl = n0 + b_ * (n1 - n0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c->gnd[k] * fminf(c->base[k] + c->dif[k] * ndl, 1.f));
+      }
+      uint32_t todo = 0u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) todo |= key[s] >= 2u ? (1u << s) : 0u;
+      while (__ballot(todo != 0u)) {                   // wave-uniform: one pass per distinct tile over the lanes
+        const int s0 = todo ? __builtin_ctz(todo) : 0;
+        const uint32_t k0 = s0 == 0 ? key[0] : s0 == 1 ? key[1] : s0 == 2 ? key[2] : key[3];
+        uint2 t0;
+        t0.x = s0 == 0 ? te[0].x : s0 == 1 ? te[1].x : s0 == 2 ? te[2].x : te[3].x;
+        t0.y = s0 == 0 ? te[0].y : s0 == 1 ? te[1].y : s0 == 2 ? te[2].y : te[3].y;
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
+        const uint4 qt = tile_quad(t0, Xu, Zu);
+        float col[3];
+        quad_filter3(qt, ax, az, lit, col);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
+      }
+      const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
+      if (have) store_rgb(e, pix, pack_rgb(o));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- quad-layout fast path -------------------------------------------------------------------------------------
 // k_raster_q<OBJ>: same work decomposition, queue protocol and store path as k_raster<false, OBJ> (shared camera), with
 // the per-pixel cost cut to what the VALU issue rate of gfx950 allows (profiles/r02_ubench_valu_rates.txt: every
@@ -1143,13 +1373,15 @@ __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixT
 //   * all-sky wavefront blocks (env-invariant with the shared camera) take a three-store loop.
 // Anything that is not a fast tile pixel falls into a wave-uniform slow branch that decides ground-fast vs edge and
 // appends edge pixels to the queue exactly as k_raster does; k_resolve is unchanged.
-__device__ inline float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 #ifndef DT_Q_WAVES
-#define DT_Q_WAVES 4
+#define DT_Q_WAVES 5                                 // wavefronts per SIMD the register allocation is held to (96 VGPRs)
 #endif
 #ifndef DT_Q_PIPE
 #define DT_Q_PIPE 0
+#endif
+#ifndef DT_Q_TILE_GROUP
+#define DT_Q_TILE_GROUP 10
 #endif
 #ifndef DT_Q_SCHED_BARRIER
 #define DT_Q_SCHED_BARRIER 1
@@ -1157,7 +1389,7 @@ __device__ inline float med3f(float x, float lo, float hi) { return __builtin_am
 template <bool OBJ, bool S256>
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, DT_Q_WAVES))) void k_raster_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
                                                  const EnvQ* __restrict__ envq, uint8_t* __restrict__ frames,
-                                                 const uint8_t* __restrict__ qtex, const float4* __restrict__ lut, const PixTab* __restrict__ pixtab,
+                                                 const uint8_t* __restrict__ qtex, const float4* __restrict__ lut, const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
                                                  const uint32_t* __restrict__ qtiles, uint16_t* __restrict__ queue,
                                                  int32_t* __restrict__ qcount) {
   extern __shared__ uint32_t s_mem[];
@@ -1169,10 +1401,16 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   // eighth of the env chunks (all frame tiles of each): with the envs in k_env_sort order, one L2 serves the envs of one
   // region of the map for the whole launch.  The mapping only matters for speed.
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK, cpx = (n_chunks + 7) / 8;
+  // Within an XCD: groups of DT_Q_TILE_GROUP frame tiles, all chunks of the slice for one group before the next group,
+  // so that a tile's PixTab slice (16 KB) is read from HBM once per XCD instead of once per chunk, while the workgroups
+  // in flight still belong to few chunks.
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int tile = bi % n_tiles;
-  const int chunk = xcd * cpx + bi / n_tiles;
-  if (chunk >= n_chunks) return;                     // padding workgroups of the last XCD slices (whole workgroup)
+  const int per_group = DT_Q_TILE_GROUP * cpx;
+  const int grp = bi / per_group, gi = bi % per_group;
+  const int g_tiles = min(DT_Q_TILE_GROUP, n_tiles - grp * DT_Q_TILE_GROUP);        // the last group may be short
+  const int tile = grp * DT_Q_TILE_GROUP + gi % g_tiles;
+  const int chunk = xcd * cpx + gi / g_tiles;
+  if (gi >= g_tiles * cpx || chunk >= n_chunks) return;   // padding workgroups (whole workgroup)
   const int rwg = chunk * n_tiles + tile;            // logical workgroup index: queue regions, counts, work items
   const int e0 = chunk * ENVS_PER_BLOCK;             // positions in the render order
   const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
@@ -1515,257 +1753,27 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   }
 #endif
   if (lane == 0) qcount[rwg * (RB / 64) + wave] = qn;
+  if (!OBJ && qn > 0) {
+    // exact path for this wavefront's own edge pixels, right here (the frame stores of the env loop are ordered
+    // before the byte patches: same wavefront, same addresses)
+    __builtin_amdgcn_s_waitcnt(0);                 // queue stores have left the wavefront
+    resolve_region<S256>(R, cams, envq, pixtab, samptab, qtex, s_qt, s_px, w_queue, qn, e0, tile_x0, wave_y0, lane);
   }
-  __shared__ int s_nb[RB / 64];
-  if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
-  __syncthreads();
-  if (tid == 0) {
-    int nb = 0;
-#pragma unroll
-    for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
-    if (nb > 0) {
-      const int ni = (nb + ITEM_B - 1) / ITEM_B;
-      const int pos = atomicAdd(R.work, ni);
-      for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)rwg * ITEMS_PER_WG + (uint32_t)i;
-    }
   }
-}
-
-// ---- k_resolve_q: exact path of the quad-layout pipeline (shared camera, no mesh objects) ------------------------
-// One workgroup per raster workgroup, wavefront w drains queue region w (the entries wavefront w of k_raster_q
-// appended) 64 entries at a time: no work list, no cursor atomics, nothing staged per item.  Per entry (one pixel
-// of one env):
-//   1. the pixel's centre hit -> padded quad coordinates -> its tile's table entry and quad record, as in k_raster_q;
-//   2. exact interior test (distance of the hit to the tile boundary, in cells, against the MSAA reach): the
-//      cell-granular test of k_raster_q is conservative by up to a cell and sends every pixel of the seam cell here;
-//      most entries pass and get the one-ray colour from the same integer filter (bit-identical to k_raster_q);
-//   3. otherwise the four samples: their tile-plane hits in the yaw-local frame are env-invariant (SampTab, built by
-//      k_pix_setup), so a sample costs one 2x2 transform and one table lookup.  Coverage per sample (tile if the
-//      tile plane is hit within [near, far] on a present tile; else the ground quad if hit within range and inside
-//      +-50 m; else the clear colour), shading once per distinct primitive at the pixel centre (GL semantics:
-//      simulator.py:1932-1934, graphics.py:172-251): a tile is shaded with ITS texture at the centre hit -- outside the
-//      tile the coordinate wraps (GL_REPEAT), which the quad records encode -- times the centre's lit factor.
-__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias) {
-  const float axI = ax * I, azI = az * I;
-  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
-  uint32_t WA, WB;
-  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-  // three 24-bit sums  sum(tap * w16)  packed as bytes 2 of (vr, vg, vb) when bias = 32768; callers that need the
-  // unrounded value pass bias = 0 and use quad_filter3
-  const uint32_t vr = (__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, bias, false);
-  const uint32_t vg = (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, bias, false);
-  const uint32_t vb = (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, bias, false);
-  const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
-  return __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
-}
-__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats
-  const float axI = ax * I, azI = az * I;
-  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
-  uint32_t WA, WB;
-  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-  const uint32_t v[3] = {(__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, 0u, false),
-                         (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, 0u, false),
-                         (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
+  if (OBJ) {   // mesh objects: k_resolve<true> drains the regions -- work items for it
+    __shared__ int s_nb[RB / 64];
+    if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
+    __syncthreads();
+    if (tid == 0) {
+      int nb = 0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
-}
-
-#define RQ_LIST (ITEM_B * 64)                        // MSAA entries one work item can produce
-template <bool S256>
-__global__ __launch_bounds__(RB) void k_resolve_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
-                                                  const EnvQ* __restrict__ envq, const PixTab* __restrict__ pixtab,
-                                                  const SampTab* __restrict__ samptab, const uint8_t* __restrict__ qtex,
-                                                  const uint32_t* __restrict__ qtiles, const uint16_t* __restrict__ queue,
-                                                  const int32_t* __restrict__ qcount) {
-  extern __shared__ uint32_t s_mem[];
-  uint32_t* s_qt = s_mem;                                                                   // [n_qtiles][2]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < R.n_qtiles * 2; i += RB) s_qt[i] = qtiles[i];
-  __syncthreads();
-  uint32_t* w_list = s_mem + R.n_qtiles * 2 + wave * RQ_LIST;                               // wavefront-local MSAA list
-  const int npix = R.W * R.H;
-  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
-  const int LS = R.qlog2;
-  const uint32_t SM = (1u << LS) - 1u;
-  const float Sf = (float)(1 << LS), lo = 0.5f * Sf;
-  const char* qtb = reinterpret_cast<const char*>(s_qt);
-  const int n_items = R.work[0];                     // written by the raster launch (stream order)
-  const int n_waves = gridDim.x * (RB / 64);
-
-  // Table entry (block byte offset, cell selector) of the tile that OWNS padded quad coordinates (X, Z): tile
-  // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
-  // on (X - 0.5, Z - 0.5) -- unlike the record lookup, which goes by whole cells.  (ox, oz): the tile's origin.
-  auto tile_entry = [&](float X, float Z, const float Xhi, const float Zhi, const uint32_t tab_b, const uint32_t pitch4, uint32_t& ta,
-                        float& ox, float& oz) -> uint2 {
-    const float Xc = med3f(X - 0.5f, lo, Xhi), Zc = med3f(Z - 0.5f, lo, Zhi);
-    const uint32_t ti = (uint32_t)flr_i32(Xc) >> LS, tj = (uint32_t)flr_i32(Zc) >> LS;
-    ox = (float)(ti << LS) + 0.5f; oz = (float)(tj << LS) + 0.5f;
-    ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
-    return *reinterpret_cast<const uint2*>(qtb + ta);
-  };
-  // quad record of block entry `te` at the cell the (unclamped) coordinates fall into, wrapped into the tile
-  auto tile_quad = [&](const uint2 te, float X, float Z) -> uint4 {
-    const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
-    uint32_t local;
-    if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);
-    else local = (((zi & SM) << LS) | (xi & SM)) & te.y;
-    return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
-  };
-  auto store_rgb = [&](int e, int pix, uint32_t rgb) {
-#ifdef DT_RQ_NO_STORE
-    if (rgb != 0x12345678u) return;
-#endif
-    uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
-    // two stores: a 2-byte aligned half + one byte, whichever way the pixel's 3 bytes fall
-    const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;
-    uint8_t* p8 = odd ? dst : dst + 2;
-    uint16_t* p16 = reinterpret_cast<uint16_t*>(odd ? dst + 1 : dst);
-    *p8 = (uint8_t)(odd ? rgb : rgb >> 16);
-    *p16 = (uint16_t)(odd ? rgb >> 8 : rgb);
-  };
-
-  // Work items (ITEM_B consecutive 64-entry batches of one raster workgroup's four queue regions, flattened) are the
-  // ones k_raster_q appended to the list; wavefront w takes items w, w + n_waves, ... : a static map, no cursor atomic.
-  for (int it = blockIdx.x * (RB / 64) + wave; it < n_items; it += n_waves) {   // wave-uniform
-    const uint32_t item = R.items[it];
-    const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
-    const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
-    const int e0 = chunk * ENVS_PER_BLOCK;
-    const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
-    static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
-    int rn[4], rb[5];
-    rb[0] = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { rn[r] = qcount[rwg * 4 + r]; rb[r + 1] = rb[r] + ((rn[r] + 63) >> 6); }
-    const int b_end = min(rb[4], (part + 1) * ITEM_B);
-    int n_list = 0;                                  // wave-uniform
-    // ---- phase 1: per entry, the exact interior test; interior entries get the one-ray colour, the others are
-    // compacted into the wavefront's list for phase 2
-    for (int b = part * ITEM_B; b < b_end; ++b) {    // wave-uniform
-      const int reg = (b >= rb[1]) + (b >= rb[2]) + (b >= rb[3]);
-      const int q0 = (b - (reg == 0 ? rb[0] : reg == 1 ? rb[1] : reg == 2 ? rb[2] : rb[3])) * 64;
-      const int n = reg == 0 ? rn[0] : reg == 1 ? rn[1] : reg == 2 ? rn[2] : rn[3];
-      const uint16_t* w_queue = queue + ((size_t)rwg * 4 + reg) * QREGION;
-      const int wave_y0 = tile_y0 + reg * (WAVE_PIX / WAVE_W);
-      const bool have = q0 + lane < n;
-      const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
-      const int el = (int)(ent >> 8), lp = (int)(ent & 255u);
-      const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
-      const PixTab pt = pixtab[pix];
-      const EnvQ* fq = envq + min(e0 + el, R.N - 1);   // position in the render order -> constants, frame index
-      const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
-      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
-      const int e = (int)fq->env;
-      const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
-      uint32_t ta_c;
-      float ox, oz;
-      const uint2 te_c = tile_entry(Xu, Zu, Xhi, Zhi, tab_b, pitch4, ta_c, ox, oz);
-      // distance of the hit to the boundary of the tile that owns it, in cells, against the MSAA reach
-      const float mrg = __half2float(__ushort_as_half((unsigned short)(pt.mi >> 16)));   // metres, rounded up
-      const float ux = Xu - ox, uz = Zu - oz;          // in [0, S) inside the owner tile
-      const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
-      const bool in_range = Xu - 0.5f >= lo && Xu - 0.5f <= Xhi && Zu - 0.5f >= lo && Zu - 0.5f <= Zhi;
-      const bool interior = have && in_range && te_c.x >= 32u && pt.lit > 0.f && (pt.mi & 0xFFFFu) != 0xFFFFu && d > mrg * R.q_per_m;
-#ifndef DT_RQ_NO_INT
-      if (__ballot(interior)) {                        // wave-uniform
-        const uint4 qc = tile_quad(te_c, Xu, Zu);
-        const uint32_t rgb = quad_filter(qc, __builtin_amdgcn_fractf(Xu), __builtin_amdgcn_fractf(Zu), pt.lit, 32768u);
-        if (interior) store_rgb(e, pix, rgb);
+      for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
+      if (nb > 0) {
+        const int ni = (nb + ITEM_B - 1) / ITEM_B;
+        const int pos = atomicAdd(R.work, ni);
+        for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)rwg * ITEMS_PER_WG + (uint32_t)i;
       }
-#endif
-#ifndef DT_RQ_NO_MSAA
-      const bool msaa = have && !interior;
-      const unsigned long long mm = __ballot(msaa);
-      if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix | ((uint32_t)el << 24);
-      n_list += __popcll(mm);
-#endif
     }
-    // ---- phase 2: the four samples of the listed pixels, on dense lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int l0 = 0; l0 < n_list; l0 += 64) {          // wave-uniform
-      const bool have = l0 + lane < n_list;
-      const uint32_t le = have ? w_list[l0 + lane] : 0u;
-      const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
-      const PixTab pt = pixtab[pix];
-      const SampTab sp = samptab[pix];
-      const EnvQ* fq = envq + min(e0 + el, R.N - 1);
-      const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
-      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
-      const int e = (int)fq->env;
-      const EnvCam* c = cams + e;
-      const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
-      const float kg = (wCy - GROUND_Y) / wCy;
-      const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
-      const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
-      const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
-      // coverage: per sample tile (tile plane hit within [near, far] on a present tile), else ground quad, else clear colour
-      uint32_t key[4];                                 // 0 sky, 1 ground, else 2 + table address of the tile
-      uint2 te[4];
-      int n_sky = 0, n_gnd = 0;
-      float gwx = 0.f, gwz = 0.f;                      // ground hit used for shading: the lowest-index ground sample's
-#pragma unroll
-      for (int s = 3; s >= 0; --s) {
-        const uint32_t hr = sp.dlr[s >> 1], hf = sp.dlf[s >> 1];
-        const float slr = pt.lr + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hr >> 16 : hr)));
-        const float slf = pt.lf + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hf >> 16 : hf)));
-        const float Xs = fmaf(slf, B, fmaf(slr, A, Cx)), Zs = fmaf(slf, -A, fmaf(slr, B, Cz));
-        uint32_t ta;
-        float sox, soz;
-        te[s] = tile_entry(Xs, Zs, Xhi, Zhi, tab_b, pitch4, ta, sox, soz);
-        const bool s_in = Xs - 0.5f >= lo && Xs - 0.5f <= Xhi && Zs - 0.5f >= lo && Zs - 0.5f <= Zhi;
-        const bool is_tile = ((sp.flags >> s) & 1u) && s_in && te[s].x != 0u;
-        // ground-quad hit of the sample (world): camera + kg * (tile-plane hit - camera)
-        const float wx = kg * (slr * sa + slf * ca) + wCx, wz = kg * (slr * ca - slf * sa) + wCz;
-        const bool is_gnd = !is_tile && ((sp.flags >> (4 + s)) & 1u) && fabsf(wx) <= GROUND_HALF && fabsf(wz) <= GROUND_HALF;
-        key[s] = !have ? 0u : is_tile ? 2u + ta : is_gnd ? 1u : 0u;
-        n_sky += key[s] == 0u; n_gnd += key[s] == 1u;
-        if (is_gnd) { gwx = wx; gwz = wz; }
-      }
-      // shading, once per primitive at the pixel centre
-      float acc[3];
-      acc[0] = (float)n_sky * c->hor[0]; acc[1] = (float)n_sky * c->hor[1]; acc[2] = (float)n_sky * c->hor[2];
-      if (__ballot(have && n_gnd > 0)) {               // wave-uniform
-        if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) {   // the centre ray hits the planes: shade at its ground hit
-          gwx = kg * (pt.lr * sa + pt.lf * ca) + wCx; gwz = kg * (pt.lr * ca - pt.lf * sa) + wCz;
-        }
-        const float a_ = fminf(fmaxf((gwx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-        const float b_ = fminf(fmaxf((gwz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-        const float n0 = c->gndl[0] + a_ * (c->gndl[1] - c->gndl[0]), n1 = c->gndl[2] + a_ * (c->gndl[3] - c->gndl[2]);
-        const float ndl = n0 + b_ * (n1 - n0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c->gnd[k] * fminf(c->base[k] + c->dif[k] * ndl, 1.f));
-      }
-      uint32_t todo = 0u;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) todo |= key[s] >= 2u ? (1u << s) : 0u;
-      while (__ballot(todo != 0u)) {                   // wave-uniform: one pass per distinct tile over the lanes
-        const int s0 = todo ? __builtin_ctz(todo) : 0;
-        const uint32_t k0 = s0 == 0 ? key[0] : s0 == 1 ? key[1] : s0 == 2 ? key[2] : key[3];
-        uint2 t0;
-        t0.x = s0 == 0 ? te[0].x : s0 == 1 ? te[1].x : s0 == 2 ? te[2].x : te[3].x;
-        t0.y = s0 == 0 ? te[0].y : s0 == 1 ? te[1].y : s0 == 2 ? te[2].y : te[3].y;
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
-        const uint4 qt = tile_quad(t0, Xu, Zu);
-        float col[3];
-        quad_filter3(qt, ax, az, lit, col);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
-      }
-      const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
-      if (have) store_rgb(e, pix, pack_rgb(o));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1940,7 +1948,8 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
   const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
-  const dim3 gridq((unsigned)(dt_raster_tiles(R.W, R.H) * ((n_chunks + 7) / 8) * 8));   // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks
+  // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of DT_Q_TILE_GROUP (the last group padded)
+  const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + DT_Q_TILE_GROUP - 1) / DT_Q_TILE_GROUP) * DT_Q_TILE_GROUP * ((n_chunks + 7) / 8) * 8));
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
@@ -1950,7 +1959,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
     hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
 #define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
-                                           reinterpret_cast<const float4*>(R.lut), pixtab, R.qtiles, R.queue, R.qcount)
+                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
     if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
     else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
@@ -1959,13 +1968,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
   if (quad && !obj) {
-    PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
-    SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
-    const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
-    const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 8));      // resident wavefronts striding over the work items
-    const size_t ldsr = (size_t)R.n_qtiles * 8 + (size_t)(RB / 64) * RQ_LIST * sizeof(uint32_t);
-    if (s256) hipLaunchKernelGGL((k_resolve_q<true>), rgrid, dim3(RB), ldsr, s, R, cams, fasts, envq, pixtab, samptab, R.qtex, R.qtiles, R.queue, R.qcount);
-    else hipLaunchKernelGGL((k_resolve_q<false>), rgrid, dim3(RB), ldsr, s, R, cams, fasts, envq, pixtab, samptab, R.qtex, R.qtiles, R.queue, R.qcount);
+    // the exact path ran inside k_raster_q (resolve_region)
   } else if (!R.no_msaa) {
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));

@@ -13,10 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 56, 8, 64
-MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 8, 96, 64
+MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
 F_RENDER, F_DISTORTION, F_DOMAIN_RAND, F_AUTO_RESET, F_ACTIONS_F64, F_PROFILE = 1, 2, 4, 8, 16, 32
 ACTION_WHEELS, ACTION_VEL_STEER = 0, 1
 DONE_IN_PROGRESS, DONE_INVALID_POSE, DONE_MAX_STEPS = 0, 1, 2
@@ -29,16 +29,18 @@ TILE_OTHER = 10
 (FIELD_POS, FIELD_ANGLE, FIELD_REWARD, FIELD_DONE, FIELD_DONE_CODE, FIELD_STEP_COUNT, FIELD_TILE,
  FIELD_LANE, FIELD_IN_LANE, FIELD_PROX, FIELD_SPEED, FIELD_TIMESTAMP, FIELD_WHEELS, FIELD_MAP_ID,
  FIELD_OBJ_CENTER, FIELD_OBJ_ACTIVE, FIELD_OBJ_YROT, FIELD_OBJ_PARAMS, FIELD_OBJ_VISIBLE,
- FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT, FIELD_OBJ_Y) = range(23)
+ FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT, FIELD_OBJ_Y, FIELD_OBJ_EXTRA, FIELD_CAMERA, FIELD_COLORS,
+ FIELD_WHEEL_DIST) = range(27)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 RENDER_SEGMENT = 1
+STEP_ONE_UPDATE, STEP_POSE_ONLY = 1, 2        # dtsim_step_ex flags
 MAP_RELOAD = 0x40000000
 
 EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
-    "dtsim_set_spawn_pool", "dtsim_step", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
+    "dtsim_set_spawn_pool", "dtsim_step", "dtsim_step_ex", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
     "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
@@ -102,6 +104,7 @@ class ResetSampler(C.Structure):
         ("seed", C.c_uint64), ("domain_rand", C.c_int32), ("dynamics_rand", C.c_int32), ("map_cycle", C.c_int32),
         ("max_attempts", C.c_int32), ("accept_start_angle_deg", C.c_double),
         ("color_sky", C.c_double * 3), ("color_ground", C.c_double * 3), ("start_tile", (C.c_int32 * 2) * 8),
+        ("has_start_pose", C.c_int32 * 8), ("start_pose", (C.c_double * 3) * 8),
     ]
 
 
@@ -161,6 +164,7 @@ def load(path: str | None = None):
         "dtsim_reset": (ci, [vp, C.POINTER(C.c_uint8), C.POINTER(InitState)]),
         "dtsim_set_spawn_pool": (ci, [vp, C.POINTER(InitState), ci]),
         "dtsim_step": (ci, [vp, vp, ci, ci]),
+        "dtsim_step_ex": (ci, [vp, vp, ci, ci, C.c_uint32]),
         "dtsim_render": (ci, [vp]),
         "dtsim_render_ex": (ci, [vp, C.c_uint32]),
         "dtsim_set_segment_assets": (ci, [vp, C.POINTER(Texture), ci, C.POINTER(C.c_uint8), ci]),

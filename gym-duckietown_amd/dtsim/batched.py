@@ -37,7 +37,7 @@ class BatchedSimulator:
                  # DuckietownEnv (envs/duckietown_env.py:15)
                  action_mode: str = "wheels", gain=1.0, trim=0.0, radius=0.0318, k=27.0, limit=1.0,
                  # batched / device options
-                 render: bool = True, auto_reset: bool = False, delay_steps: int = 5, device: int = 0,
+                 render: bool = True, auto_reset: bool = False, delay_steps: Optional[int] = None, device: int = 0,
                  stream: Optional[int] = None, profile: bool = False, actions_f64: bool = False,
                  map_cycle: bool = False, map_random: bool = False, transform_uses_width: bool = False,
                  map_data: Optional[dict] = None,
@@ -51,6 +51,13 @@ class BatchedSimulator:
         self.max_steps, self.domain_rand = max_steps, bool(domain_rand)
         self.frame_rate, self.frame_skip = frame_rate, int(frame_skip)
         self.delta_time = 1.0 / frame_rate
+        if delay_steps is None:
+            # the DB18 model's actuation delay is 0.15 s of simulated time (simulator.py:745-755, get_DB18_nominal(delay=0.15)):
+            # the smallest k with k * delta_time >= 0.15 -- 5 steps at the default 30 Hz
+            delay_steps = int(math.ceil(0.15 * frame_rate - 1e-9))
+        if not 0 <= int(delay_steps) <= _ffi.MAX_DELAY:
+            raise ValueError(f"delay_steps {delay_steps} (0.15 s at frame_rate {frame_rate}) outside [0, {_ffi.MAX_DELAY}] (DTSIM_MAX_DELAY)")
+        self.delay_steps = int(delay_steps)
         self.camera_width, self.camera_height = int(camera_width), int(camera_height)
         self.robot_speed = robot_speed
         self.accept_start_angle_deg = accept_start_angle_deg
@@ -150,6 +157,7 @@ class BatchedSimulator:
             farr[i] = mt.to_ffi(mesh_ids, self.light_tex if render else (-1, -1))
         _ffi.check(self._lib, self._lib.dtsim_set_maps(self._h, farr, len(self.maps)))
         self.undistort = bool(undistort and distortion)
+        self._skip_distort = False
         if render and distortion:
             # undistort=True: UndistortWrapper(env) -- the simulator's fisheye is skipped (env.undistort, simulator.py:1969)
             # and the wrapper's rectify map is the per-pixel source map instead (wrappers.py:209-227)
@@ -192,6 +200,10 @@ class BatchedSimulator:
                 elif self.maps[m].start_tile is not None:
                     tile = tuple(int(v) for v in self.maps[m].start_tile)
             rs.start_tile[m][0], rs.start_tile[m][1] = tile
+            sp = self.maps[m].start_pose if m < len(self.maps) else None
+            rs.has_start_pose[m] = 0 if sp is None else 1
+            if sp is not None:                          # [[x, y, z], angle] relative to the start tile (simulator.py:679-688)
+                rs.start_pose[m][0], rs.start_pose[m][1], rs.start_pose[m][2] = float(sp[0][0]), float(sp[0][2]), float(sp[1])
         _ffi.check(self._lib, self._lib.dtsim_set_reset_sampler(self._h, C.byref(rs)))
         self._sampler = rs
 
@@ -354,19 +366,33 @@ class BatchedSimulator:
         self._pool = pool
         return pool
 
+    def skip_distort(self, flag: bool):
+        """`env.undistort = True` (simulator.py:1968-1970, 2001; set by UndistortWrapper, wrappers.py:209): render_obs
+        returns the rectilinear image, i.e. the per-pixel source map becomes the identity; False restores the fisheye."""
+        flag = bool(flag) and self.distortion and self.render_enabled
+        if flag == self._skip_distort:
+            return
+        self._skip_distort = flag
+        fp = C.POINTER(C.c_float)
+        if flag:
+            _ffi.check(self._lib, self._lib.dtsim_set_distortion_lut(self._h, fp(), fp()))
+        else:
+            _ffi.check(self._lib, self._lib.dtsim_set_distortion_lut(self._h, self.rmapx.ctypes.data_as(fp), self.rmapy.ctypes.data_as(fp)))
+
     # ------------------------------------------------------------------- step --
-    def step(self, actions, n_steps: int = 1):
+    def step(self, actions, n_steps: int = 1, flags: int = 0):
         """actions: [n_steps, N, 2] or [N, 2] (float32, or float64 with actions_f64);
-        numpy array (host) or an object with __cuda_array_interface__ (device)."""
+        numpy array (host) or an object with __cuda_array_interface__ (device).
+        flags: _ffi.STEP_ONE_UPDATE (one update_physics, no frame_skip) / _ffi.STEP_POSE_ONLY (`_update_pos`)."""
         if hasattr(actions, "__cuda_array_interface__"):
             ptr = actions.__cuda_array_interface__["data"][0]
-            _ffi.check(self._lib, self._lib.dtsim_step(self._h, C.c_void_p(ptr), int(n_steps), 1))
+            _ffi.check(self._lib, self._lib.dtsim_step_ex(self._h, C.c_void_p(ptr), int(n_steps), 1, int(flags)))
             return
         dt = np.float64 if self.actions_f64 else np.float32
         a = np.ascontiguousarray(np.asarray(actions, dtype=dt))
         if a.size != n_steps * self.num_envs * 2:
             raise ValueError(f"actions has {a.size} elements, expected {n_steps}*{self.num_envs}*2")
-        _ffi.check(self._lib, self._lib.dtsim_step(self._h, a.ctypes.data_as(C.c_void_p), int(n_steps), 0))
+        _ffi.check(self._lib, self._lib.dtsim_step_ex(self._h, a.ctypes.data_as(C.c_void_p), int(n_steps), 0, int(flags)))
 
     def render(self, segment: bool = False):
         """render_obs() of every env into the frame batch; `segment=True` is the reference's segmentation render
@@ -471,6 +497,8 @@ class BatchedSimulator:
         _ffi.FIELD_OBJ_YROT: ("f8", (_ffi.MAX_DYNAMIC,)), _ffi.FIELD_OBJ_PARAMS: ("f8", (_ffi.MAX_DYNAMIC, 3)),
         _ffi.FIELD_OBJ_VISIBLE: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_EPISODE: ("i4", ()),
         _ffi.FIELD_OBJ_LIGHT: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_OBJ_Y: ("f8", (_ffi.MAX_DYNAMIC,)),
+        _ffi.FIELD_OBJ_EXTRA: ("f8", (_ffi.MAX_DYNAMIC, 5)), _ffi.FIELD_CAMERA: ("f4", (6,)), _ffi.FIELD_COLORS: ("f4", (16,)),
+        _ffi.FIELD_WHEEL_DIST: ("f8", ()),
     }
 
     def read(self, field: int) -> np.ndarray:

@@ -58,21 +58,34 @@ class ShardedSimulator:
     """BatchedSimulator for the env range this rank owns (rank/world from torch.distributed)."""
 
     def __init__(self, map_name, total_envs: int, *, seed: Optional[int] = None, device: Optional[int] = None,
-                 rank: Optional[int] = None, world: Optional[int] = None, **kw):
+                 rank: Optional[int] = None, world: Optional[int] = None, sim_factory=None, **kw):
+        """sim_factory(map_name, n_local, seed=, device=, **kw): the per-rank simulator; BatchedSimulator unless a test
+        injects a stand-in (the CPU tests run this class on gloo without a GPU)."""
         import os
-        from .batched import BatchedSimulator
+        if sim_factory is None:
+            from .batched import BatchedSimulator as sim_factory
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
         self.lo, self.hi = shard_range(self.rank, self.world, total_envs)
         dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
-        self.sim = BatchedSimulator(map_name, self.hi - self.lo, seed=env_seed(seed, self.lo), device=dev, **kw)
+        self.sim = sim_factory(map_name, self.hi - self.lo, seed=env_seed(seed, self.lo), device=dev, **kw)
 
     def local_actions(self, global_actions: np.ndarray) -> np.ndarray:
         """Slice [..., N_total, 2] actions to this rank's envs."""
         return np.ascontiguousarray(global_actions[..., self.lo:self.hi, :])
 
-    def gather_frames(self, dst: Optional[int] = None, group=None):
+    def step(self, global_actions: np.ndarray, n_steps: int = 1):
+        """Step this rank's envs with their slice of the job-wide action array."""
+        self.sim.step(self.local_actions(global_actions), n_steps)
+
+    def local_frames(self):
+        """This rank's frame batch as a torch tensor (device memory of the simulator, no copy)."""
         import torch
+        if hasattr(self.sim, "frames_tensor"):           # stand-in simulators of the CPU tests
+            return self.sim.frames_tensor()
         frames = torch.as_tensor(self.sim.frames_device(), device=f"cuda:{self.sim.device_index}")
         self.sim.sync()
-        return gather_batch(frames, self.world, group, dst)
+        return frames
+
+    def gather_frames(self, dst: Optional[int] = None, group=None):
+        return gather_batch(self.local_frames(), self.world, group, dst)

@@ -124,7 +124,7 @@ class Simulator(_EnvBase):
         self.accept_start_angle_deg = accept_start_angle_deg
         self.distortion = distortion and not draw_bbox
         self.camera_rand = False
-        self.undistort = False
+        self._undistort = False
         self.dynamics_rand = dynamics_rand
         self.user_tile_start = user_tile_start
         self.style = style
@@ -196,13 +196,42 @@ class Simulator(_EnvBase):
     def _f(self, field):
         return self._sim.read(field)[0]
 
+    if gym is None:
+        @property
+        def unwrapped(self):                          # gym.Env.unwrapped
+            return self
+
+    @property
+    def undistort(self) -> bool:
+        """simulator.py:1968-1970, 2001: when set (UndistortWrapper does, wrappers.py:209), render_obs / render skip
+        camera_model.distort and return the rectilinear image."""
+        return self._undistort
+
+    @undistort.setter
+    def undistort(self, flag):
+        self._undistort = bool(flag)
+        if hasattr(self, "_sim"):
+            self._sim.skip_distort(self._undistort)
+
     @property
     def cur_pos(self):
         return self._f(_ffi.FIELD_POS).copy()
 
+    @cur_pos.setter
+    def cur_pos(self, pos):                           # `self.cur_pos, self.cur_angle = _update_pos(self, action)`
+        arr = self._sim.read(_ffi.FIELD_POS).copy()
+        arr[0] = np.asarray(pos, np.float64)
+        self._sim.write(_ffi.FIELD_POS, arr)
+
     @property
     def cur_angle(self):
         return float(self._f(_ffi.FIELD_ANGLE))
+
+    @cur_angle.setter
+    def cur_angle(self, angle):
+        arr = self._sim.read(_ffi.FIELD_ANGLE).copy()
+        arr[0] = float(angle)
+        self._sim.write(_ffi.FIELD_ANGLE, arr)
 
     @property
     def speed(self):
@@ -250,7 +279,11 @@ class Simulator(_EnvBase):
         action = np.clip(action, -1, 1) if self._ACTION_MODE == "wheels" else np.asarray(action)
         action = np.array(action, dtype=np.float64)
         self._sim.step(action.reshape(1, 2))
-        self.last_action = action
+        # Simulator.step receives the clipped wheel duties [u_l, u_r] (DuckietownEnv.step computes them from
+        # (vel, steering), envs/duckietown_env.py:36-61); update_physics keeps them as last_action / wheelVels (:1555, 1564)
+        wheels = np.array(self._f(_ffi.FIELD_WHEELS), dtype=np.float64)
+        self.last_action = wheels
+        self.wheelVels = wheels * self.robot_speed
         obs = self.render_obs()
         misc = self.get_agent_info()
         d = self._compute_done_reward()
@@ -420,9 +453,18 @@ class Simulator(_EnvBase):
                               done_code=_ffi.DONE_CODES[code])
 
     def update_physics(self, action, delta_time: float = None):
-        """simulator.py:1551: one dynamics/objects step without reward bookkeeping semantics
-        changes -- runs dtsim_step (which also refreshes done/reward, harmlessly)."""
-        self._sim.step(np.asarray(action, np.float64).reshape(1, 2))
+        """simulator.py:1551-1584: ONE physics update (frame_skip is Simulator.step's loop, :1674): the pose advances by
+        `_update_pos`, step_count += 1, timestamp += delta_time, speed, last_action / wheelVels, every object stepped once.
+        dtsim_step_ex(DTSIM_STEP_ONE_UPDATE); reward / done are refreshed for the new state (pure functions of it; the
+        reference evaluates them on demand in _compute_done_reward).  `delta_time` other than the env's own is not
+        supported: `_update_pos` ignores it in the reference too (:2084), only timestamp / speed / objects would differ."""
+        if delta_time is not None and abs(delta_time - self.delta_time) > 1e-12:
+            raise NotImplementedError("update_physics(delta_time != env.delta_time)")
+        action = np.asarray(action, np.float64)
+        self.wheelVels = action * self.robot_speed * 1
+        mode = self._ACTION_MODE
+        self._sim.step(action.reshape(1, 2), flags=_ffi.STEP_ONE_UPDATE)
+        self.last_action = action if mode == "wheels" else np.array(self._f(_ffi.FIELD_WHEELS), dtype=np.float64)
 
     def get_agent_info(self) -> dict:
         info = {"action": list(self.last_action)}
@@ -474,6 +516,9 @@ def get_agent_corners(pos, angle):
 
 
 def _update_pos(self, action):
-    """simulator.py:2076: advance the dynamics by one delta_time on the device; returns (pos, angle)."""
-    self._sim.step(np.asarray(action, np.float64).reshape(1, 2))
+    """simulator.py:2076-2088: advance the dynamics state by one delta_time with the wheel pair `action` and return
+    (pos, angle).  dtsim_step_ex(DTSIM_STEP_POSE_ONLY): step_count, timestamp, speed, the objects, reward and done are
+    untouched.  The device pose fields already hold the returned pose (the reference leaves `self.cur_pos` to the
+    caller's assignment, `self.cur_pos, self.cur_angle = _update_pos(self, action)`, which is accepted and a no-op here)."""
+    self._sim.step(np.asarray(action, np.float64).reshape(1, 2), flags=_ffi.STEP_POSE_ONLY)
     return self.cur_pos, self.cur_angle

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 4
+#define DTSIM_ABI_VERSION 5
 
 /* error codes */
 #define DTSIM_OK 0
@@ -47,7 +47,7 @@ extern "C" {
 #define DTSIM_MAX_STATIC 56         /* collidable static objects per map */
 #define DTSIM_MAX_DYNAMIC 8         /* dynamic objects (DuckieObj + DuckiebotObj) per map */
 #define DTSIM_MAX_OBJECTS 64        /* renderable objects per map */
-#define DTSIM_MAX_DELAY 8           /* dynamics command delay, in steps */
+#define DTSIM_MAX_DELAY 16          /* dynamics command delay, in steps (0.15 s: up to 106 Hz) */
 #define DTSIM_MAX_TEXTURES 96
 #define DTSIM_MAX_MESHES 64
 
@@ -235,7 +235,12 @@ enum {
   DTSIM_FIELD_STATE_BLOB = 20,/* opaque: full SoA state, dtsim_state_bytes() bytes (checkpoint) */
   DTSIM_FIELD_OBJ_LIGHT = 21, /* uint8  [N][DTSIM_MAX_OBJECTS] TrafficLightObj.pattern (0 for other objects) */
   DTSIM_FIELD_OBJ_Y = 22,     /* double [N][DTSIM_MAX_DYNAMIC] height of the object centre (CheckerboardObj moves in y) */
-  DTSIM_FIELD__COUNT = 23
+  DTSIM_FIELD_OBJ_EXTRA = 23, /* double [N][DTSIM_MAX_DYNAMIC][5] DuckiebotObj follow_dist, radius, wheel_dist, robot_width,
+                               * robot_length (objects.py:198-215; its velocity, gain, trim are OBJ_PARAMS) */
+  DTSIM_FIELD_CAMERA = 24,    /* float  [N][6]  cam_height, cam_angle[0] (rad), cam_fov_y (rad), camera_noise xyz (simulator.py:596-614) */
+  DTSIM_FIELD_COLORS = 25,    /* float  [N][16] horizon rgb, ground rgb, light ambient rgb, diffuse rgb, light_pos xyzw (:551-594) */
+  DTSIM_FIELD_WHEEL_DIST = 26,/* double [N]     wheel_dist (:597) */
+  DTSIM_FIELD__COUNT = 27
 };
 
 /* kernels for dtsim_profile_read */
@@ -281,6 +286,8 @@ typedef struct dtsim_reset_sampler {
   double accept_start_angle_deg;    /* simulator.py:724-728 */
   double color_sky[3], color_ground[3];
   int32_t start_tile[DTSIM_MAX_MAPS][2];  /* user_tile_start / the map's start_tile; -1 = a random drivable tile */
+  int32_t has_start_pose[DTSIM_MAX_MAPS]; /* the map defines start_pose: spawn at tile * tile_size + pose, no rejection loop */
+  double start_pose[DTSIM_MAX_MAPS][3];   /* (x offset, z offset, angle): simulator.py:679-688 */
 } dtsim_reset_sampler;
 int dtsim_set_reset_sampler(dtsim_t* h, const dtsim_reset_sampler* sampler);   /* NULL uninstalls */
 /* Reset, with the installed sampler, every env whose done flag is set (the mask is read on the device: no
@@ -297,6 +304,19 @@ int dtsim_set_spawn_pool(dtsim_t* h, const dtsim_init_state* pool, int n_pool);
  * actions: [n_steps][num_envs][2], float (or double with DTSIM_F_ACTIONS_F64), host or
  * device pointer (actions_on_device).  Asynchronous. */
 int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_device);
+
+/* dtsim_step with flags; dtsim_step(...) == dtsim_step_ex(..., 0).
+ *   DTSIM_STEP_ONE_UPDATE  one `Simulator.update_physics(action)` (simulator.py:1551-1584) per step: like dtsim_step but
+ *                          frame_skip is not applied (step_count += 1, timestamp += delta_time, speed, every object
+ *                          stepped once; reward / done are refreshed for the new state -- they are pure functions of it,
+ *                          `_compute_done_reward` :1685 evaluates them on demand in the reference).
+ *   DTSIM_STEP_POSE_ONLY   the module-level `_update_pos(self, action)` (simulator.py:2076-2088): the dynamics state
+ *                          (incl. the delayed-command queue) advances by one delta_time and the resulting pose is
+ *                          written to the pose fields; step_count, timestamp, speed, objects, reward and done are
+ *                          left alone, DuckietownEnv's (vel, steering) kinematics and auto-reset do not apply (the
+ *                          action is the wheel pair `_update_pos` takes, simulator.py:2083). */
+enum { DTSIM_STEP_ONE_UPDATE = 1u, DTSIM_STEP_POSE_ONLY = 2u };
+int dtsim_step_ex(dtsim_t* h, const void* actions, int n_steps, int actions_on_device, uint32_t flags);
 
 /* Simulator.render_obs (simulator.py:1953-1972) = _render_img (:1707-1951) + distort:
  * writes [num_envs][cam_height][cam_width][3] uint8, row 0 = image top.  Asynchronous. */

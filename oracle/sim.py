@@ -652,8 +652,10 @@ class OracleSim:
                  frame_rate=30, frame_skip=1, robot_speed=DEFAULT_ROBOT_SPEED,
                  accept_start_angle_deg=60, seed=None, dynamics_rand=False, camera_rand=False,
                  user_tile_start=None, num_tris_distractors=12, color_ground=(0.15, 0.15, 0.15),
-                 color_sky=BLUE_SKY, delay_steps=5, transform_uses_width=False,
+                 color_sky=BLUE_SKY, delay_steps=None, transform_uses_width=False,
                  gain=1.0, trim=0.0, radius=0.0318, k=27.0, limit=1.0, do_reset=True):
+        if delay_steps is None:   # 0.15 s of simulated time (get_DB18_nominal(delay=0.15)): smallest k with k * dt >= 0.15
+            delay_steps = int(math.ceil(0.15 * frame_rate - 1e-9))
         self.map = OracleMap(map_data, mesh_extents, transform_uses_width)
         self._map_args = (map_data, mesh_extents, transform_uses_width)
         self.max_steps = max_steps

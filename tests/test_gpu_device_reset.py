@@ -129,3 +129,125 @@ def test_device_sampler_randomises_walking_duckies():
     ph = host.read(_ffi.FIELD_OBJ_PARAMS)[:, :nd]
     assert (ph[..., 1] == 8).all() and (ph[..., 0] == 0.02).all()
     host.close()
+
+
+# ---- the distributions of the reference's reset(), as constants (pinned against the reference's own files by
+# tests/test_oracle_vs_reference.py::test_dr_constants_match_the_reference when /root/reference is present)
+DR_CONFIG = {   # randomization/config/default_dr.json == randomizer.py:8-16 DEFAULT_CONFIG
+    "horz_mode": {"type": "int", "low": 0, "high": 4},
+    "light_pos": {"type": "uniform", "low": [-150, 170, -150], "high": [150, 220, 150], "size": 3},
+    "camera_noise": {"type": "uniform", "low": -0.005, "high": 0.005, "size": 3},
+    "trim": {"type": "normal", "loc": 0, "scale": 0.02},
+    "camera_height": {"type": "uniform", "low": 0.92, "high": 1.08},
+    "camera_angle": {"type": "uniform", "low": 0.8, "high": 1.2},
+    "camera_fov_y": {"type": "uniform", "low": 0.8, "high": 1.2},
+}
+CAMERA_FLOOR_DIST, CAMERA_ANGLE, CAMERA_FOV_Y, WHEEL_DIST = 0.108, 19.15, 75.0, 0.102   # simulator.py:119-131, 137
+
+
+def _uniform_ok(x, lo, hi, tol=0.02):
+    """samples of U(lo, hi): inside the interval, mean and spread of a uniform (N >= 16k: 2 % of the width is > 5 sigma)"""
+    x = np.asarray(x, np.float64)
+    w = hi - lo
+    e = 1e-6 * max(abs(lo), abs(hi), 1e-3)
+    assert x.min() >= lo - e and x.max() <= hi + e, (x.min(), x.max(), lo, hi)
+    assert abs(x.mean() - 0.5 * (lo + hi)) < tol * w and abs(x.std() - w / np.sqrt(12)) < tol * w
+    assert x.min() < lo + 0.01 * w and x.max() > hi - 0.01 * w
+
+
+def test_device_sampler_draws_the_reference_dr_distributions():
+    """simulator.py:546-614 + randomizer.py:36-91 + _perturb :1065-1085: every domain-randomised quantity the device
+    sampler draws, read back for 32768 envs and checked against the reference's ranges."""
+    N = 32768
+    sky, gnd = (0.45, 0.82, 1.0), (0.15, 0.15, 0.15)
+    sim = BatchedSimulator("small_loop", N, render=False, domain_rand=True, seed=11, device_reset=True)
+    cam, col, wd = sim.read(_ffi.FIELD_CAMERA), sim.read(_ffi.FIELD_COLORS), sim.read(_ffi.FIELD_WHEEL_DIST)
+    c = DR_CONFIG
+    _uniform_ok(cam[:, 0], CAMERA_FLOOR_DIST * c["camera_height"]["low"], CAMERA_FLOOR_DIST * c["camera_height"]["high"])
+    _uniform_ok(np.degrees(cam[:, 1]), CAMERA_ANGLE * c["camera_angle"]["low"], CAMERA_ANGLE * c["camera_angle"]["high"])
+    _uniform_ok(np.degrees(cam[:, 2]), CAMERA_FOV_Y * c["camera_fov_y"]["low"], CAMERA_FOV_Y * c["camera_fov_y"]["high"])
+    for k in range(3):
+        _uniform_ok(cam[:, 3 + k], c["camera_noise"]["low"], c["camera_noise"]["high"])
+        _uniform_ok(col[:, 12 + k], c["light_pos"]["low"][k], c["light_pos"]["high"][k])
+        _uniform_ok(col[:, 3 + k], gnd[k] * 0.7, gnd[k] * 1.3)          # ground_color = _perturb(color_ground, 0.3)
+        _uniform_ok(col[:, 6 + k], 0.25 * 0.7, 0.25 * 1.3)              # ambient = _perturb(0.5 * DIM, 0.3), DIM = 0.5
+        _uniform_ok(col[:, 9 + k], 0.35 * 0.01, 0.35 * 1.99)            # diffuse = _perturb(0.7 * DIM, 0.99)
+    assert (col[:, 15] == 0).all()                                      # 3-component light_pos -> directional
+    _uniform_ok(wd, WHEEL_DIST * 0.9, WHEEL_DIST * 1.1)                 # _perturb(WHEEL_DIST)
+    # horizon colour: horz_mode in {0..3} uniformly, each a perturbed base colour (simulator.py:551-560)
+    modes = [(sky, 0.1), ((0.64, 0.71, 0.28), 0.1), ((0.15,) * 3, 0.4), ((0.9,) * 3, 0.4)]
+    hit = np.zeros((N, 4), bool)
+    for m, (base, s) in enumerate(modes):
+        b = np.array(base)
+        hit[:, m] = ((col[:, 0:3] >= b * (1 - s) - 1e-6) & (col[:, 0:3] <= b * (1 + s) + 1e-6)).all(axis=1)
+    assert hit.any(axis=1).all()
+    only = hit & (hit.sum(axis=1, keepdims=True) == 1)                  # boxes of modes 0 / 3 overlap a little: count the unambiguous ones
+    frac = only.sum(axis=0) / N
+    assert (frac > 0.17).all() and (frac < 0.27).all(), frac
+    sim.close()
+    # without domain randomisation nothing is perturbed
+    sim = BatchedSimulator("small_loop", 64, render=False, domain_rand=False, seed=11, device_reset=True)
+    cam, col, wd = sim.read(_ffi.FIELD_CAMERA), sim.read(_ffi.FIELD_COLORS), sim.read(_ffi.FIELD_WHEEL_DIST)
+    assert np.allclose(cam[:, 0], CAMERA_FLOOR_DIST) and np.allclose(np.degrees(cam[:, 1]), CAMERA_ANGLE, atol=1e-4)
+    assert np.allclose(col[:, 0:3], sky, atol=1e-6) and np.allclose(col[:, 12:16], [0, 3, 0, 1]) and (wd == WHEEL_DIST).all()
+    sim.close()
+
+
+@pytest.mark.parametrize("map_name", ["small_loop_only_duckies", "loop_pedestrians"])
+def test_device_reset_spawns_pass_the_oracles_acceptance_test(map_name):
+    """The spawn acceptance test of simulator.py:692-738, evaluated by the ORACLE (not by the library's own query
+    kernel) on poses the device sampler produced."""
+    from util import make_oracle
+    from oracle import sim as osim
+    N = 512
+    sim = BatchedSimulator(map_name, N, render=False, domain_rand=False, seed=9, device_reset=True, accept_start_angle_deg=60)
+    pos, ang = sim.read(_ffi.FIELD_POS), sim.read(_ffi.FIELD_ANGLE)
+    o = make_oracle(map_name, domain_rand=False, seed=0)
+    for e in range(0, N, 2):
+        p, a = pos[e], float(ang[e])
+        assert not o._inconvenient_spawn(p), e
+        assert o._valid_pose(p, a, safety_factor=1.3), e
+        lp = o.get_lane_pos2(p, a)                         # raises NotInLane if the sampler accepted an off-lane pose
+        assert -60 < lp[2] < 60, (e, lp)
+    sim.close()
+
+
+def test_device_sampler_randomises_follower_duckiebots():
+    """DuckiebotObj.__init__ under domain randomisation (objects.py:198-207): follow_dist ~ U(0.3, 0.4), velocity ~
+    U(0.05, 0.15), gain = 2 + U(-0.3, 0.3), trim = 0 + U(-0.1, 0.1) + 2, radius / wheel_dist / robot size jittered."""
+    N = 16384
+    sim = BatchedSimulator("loop_dyn_duckiebots", N, render=False, domain_rand=True, seed=5, device_reset=True)
+    mt = sim.maps[0]
+    par, ext = sim.read(_ffi.FIELD_OBJ_PARAMS), sim.read(_ffi.FIELD_OBJ_EXTRA)
+    bots = [o.dyn_slot for o in mt.objects if o.dyn_kind == 2]
+    assert len(bots) == 4
+    for d in bots:
+        _uniform_ok(par[:, d, 0], 0.05, 0.15)
+        _uniform_ok(par[:, d, 1], 2.0 - 0.3, 2.0 + 0.3)
+        _uniform_ok(par[:, d, 2], 2.0 - 0.1, 2.0 + 0.1)
+        _uniform_ok(ext[:, d, 0], 0.3, 0.4)
+        _uniform_ok(ext[:, d, 1], 0.0318 - 0.0002, 0.0318 + 0.0002)
+        _uniform_ok(ext[:, d, 2], 0.102 - 0.01, 0.102 + 0.01)
+        _uniform_ok(ext[:, d, 3], 0.15 - 0.01, 0.15 + 0.01)
+        _uniform_ok(ext[:, d, 4], 0.18 - 0.01, 0.18 + 0.01)
+    sim.close()
+    sim = BatchedSimulator("loop_dyn_duckiebots", 8, render=False, domain_rand=False, seed=5, device_reset=True)
+    par, ext = sim.read(_ffi.FIELD_OBJ_PARAMS), sim.read(_ffi.FIELD_OBJ_EXTRA)
+    for d in bots:                                        # the non-DR branch (objects.py:208-216)
+        assert np.allclose(par[:, d], [0.1, 2.0, 0.0]) and np.allclose(ext[:, d], [0.3, 0.0318, 0.102, 0.15, 0.18])
+    sim.close()
+
+
+def test_device_sampler_honours_the_maps_start_pose():
+    """simulator.py:679-688: a map with `start_pose` spawns at start_tile * tile_size + pose, deterministically -- on the
+    device sampler as on the host path."""
+    from dtsim import assets
+    md = assets.get_map("small_loop")
+    md["start_tile"] = [1, 2]
+    md["start_pose"] = [[0.35, 0.0, 0.29], 1.5707]
+    host = BatchedSimulator("small_loop", 4, map_data=md, render=False, domain_rand=False, seed=1)
+    dev = BatchedSimulator("small_loop", 4, map_data=md, render=False, domain_rand=False, seed=1, device_reset=True)
+    want = np.array([1 * 0.585 + 0.35, 0.0, 2 * 0.585 + 0.29])
+    for s in (host, dev):
+        assert np.allclose(s.read(_ffi.FIELD_POS), want, atol=1e-12) and np.allclose(s.read(_ffi.FIELD_ANGLE), 1.5707)
+        s.close()

@@ -226,3 +226,98 @@ def test_batched_random_maps_device_sampler():
     sim.reset()
     assert not sim.read(_ffi.FIELD_OBJ_ACTIVE).any()
     sim.close()
+
+
+def test_update_physics_and_update_pos_follow_the_reference_semantics():
+    """simulator.py:1551-1584: update_physics is ONE physics update (frame_skip belongs to step(), :1674) that advances
+    step_count / timestamp / speed / the objects; simulator.py:2076-2088: the module-level _update_pos only integrates the
+    dynamics state and returns the pose -- no counters, no objects, no reward."""
+    from gym_duckietown.simulator import Simulator, _update_pos
+    env = Simulator(map_name="loop_pedestrians", domain_rand=False, seed=3, frame_skip=3, camera_width=64, camera_height=48)
+    o = make_oracle("loop_pedestrians", domain_rand=False, seed=3, frame_skip=3)
+    assert np.array_equal(env.cur_pos, o.cur_pos)     # both constructors reset once
+    a = np.array([0.5, 0.3])
+    # step(): frame_skip updates
+    env.step(a)
+    o.step(a)
+    assert env.step_count == o.step_count == 3 and np.allclose(env.cur_pos, o.cur_pos, atol=1e-9)
+    # update_physics(): exactly one
+    env.update_physics(a)
+    o.update_physics(a)
+    assert env.step_count == o.step_count == 4 and abs(env.timestamp - o.timestamp) < 1e-12
+    assert np.allclose(env.cur_pos, o.cur_pos, atol=1e-9) and abs(env.cur_angle - o.cur_angle) < 1e-9
+    assert abs(env.speed - o.speed) < 1e-9
+    assert np.allclose(env.wheelVels, a * env.robot_speed) and np.allclose(env.last_action, a)
+    d, r, _ = o._compute_done_reward()
+    dr = env._compute_done_reward()
+    assert dr.done == d and abs(dr.reward - r) < 1e-9
+    obj_c = env._sim.read(_ffi.FIELD_OBJ_CENTER)[0].copy()
+    # _update_pos(): pose only
+    sc, ts, rew, spd = env.step_count, env.timestamp, env._compute_done_reward().reward, env.speed
+    pos, ang = _update_pos(env, a)
+    o.state.integrate(o.delta_time, a[0], a[1])
+    opos = np.asarray([o.state.x, 0, o.map.grid_height * o.map.tile_size - o.state.y])
+    assert np.allclose(pos, opos, atol=1e-9) and abs(ang - o.state.angle()) < 1e-9
+    assert env.step_count == sc and env.timestamp == ts and env.speed == spd
+    assert env._compute_done_reward().reward == rew                      # not recomputed
+    assert np.array_equal(env._sim.read(_ffi.FIELD_OBJ_CENTER)[0], obj_c)  # objects not stepped
+    env.cur_pos, env.cur_angle = pos, ang                               # the reference's call pattern (:1558)
+    assert np.array_equal(env.cur_pos, pos) and env.cur_angle == ang
+    env.close()
+
+
+def test_undistort_property_skips_the_fisheye_like_the_reference():
+    """simulator.py:1968-1970: env.undistort = True (set by UndistortWrapper, wrappers.py:209) makes render_obs return
+    the rectilinear image; the wrapper then remaps that.  Same bytes as the fisheye-free render / as the folded
+    BatchedSimulator(undistort=True) path."""
+    from gym_duckietown.simulator import Simulator
+    from gym_duckietown.wrappers import UndistortWrapper
+    kw = dict(map_name="small_loop_only_duckies", domain_rand=False, seed=5, camera_width=160, camera_height=120)
+    env = Simulator(distortion=True, **kw)
+    plain = Simulator(distortion=False, **kw)
+    fish = env.render_obs().copy()
+    rect = plain.render_obs().copy()
+    assert not np.array_equal(fish, rect)
+    env.undistort = True
+    assert np.array_equal(env.render_obs(), rect)
+    env.undistort = False
+    assert np.array_equal(env.render_obs(), fish)
+    w = UndistortWrapper(env)
+    assert env.undistort is True
+    folded = BatchedSimulator(kw["map_name"], 1, domain_rand=False, seed=5, camera_width=160, camera_height=120,
+                              distortion=True, undistort=True)
+    folded.render()
+    assert np.array_equal(w.observation(env.render_obs()), folded.frames_host()[0])
+    env.close(); plain.close()
+
+
+def test_actuation_delay_follows_the_frame_rate():
+    """The DB18 delay is 0.15 s of simulated time (simulator.py:745-755): 5 steps at 30 Hz, 2 at 10 Hz, 9 at 60 Hz --
+    not a fixed step count."""
+    for fr, k in ((30, 5), (10, 2), (20, 3), (60, 9)):
+        sim = BatchedSimulator("small_loop", 2, domain_rand=False, seed=1, frame_rate=fr, render=False, actions_f64=True)
+        assert sim.delay_steps == k
+        o = make_oracle("small_loop", domain_rand=False, seed=1, frame_rate=fr)
+        assert o.delay_steps == k
+        assert np.array_equal(sim.read(_ffi.FIELD_POS)[0], o.cur_pos)
+        for i in range(12):
+            a = np.array([0.6, 0.2 + 0.05 * i])
+            sim.step(np.tile(a, (2, 1)))
+            o.step(a)
+            assert np.allclose(sim.read(_ffi.FIELD_POS)[0], o.cur_pos, atol=1e-9)
+    with pytest.raises(ValueError):
+        BatchedSimulator("small_loop", 1, frame_rate=120, render=False)     # 18 steps > DTSIM_MAX_DELAY = 16
+
+
+def test_vel_steer_env_reports_the_wheel_duties_as_last_action():
+    """DuckietownEnv.step hands [u_l, u_r] to Simulator.step (envs/duckietown_env.py:61), which keeps them as
+    last_action / wheelVels (simulator.py:1555,1564) and reports them in info['Simulator']['action']."""
+    from gym_duckietown.envs import DuckietownEnv
+    env = DuckietownEnv(map_name="small_loop", domain_rand=False, seed=2, camera_width=64, camera_height=48)
+    o = make_oracle("small_loop", domain_rand=False, seed=2)
+    act = np.array([0.7, -1.3])
+    _, _, _, info = env.step(act)
+    wheels = np.clip(o.wheels_from_vel_steer(act), -1, 1)
+    assert np.allclose(info["Simulator"]["action"], wheels, atol=1e-12)
+    assert np.allclose(env.last_action, wheels, atol=1e-12) and np.allclose(env.wheelVels, wheels * env.robot_speed, atol=1e-12)
+    env.close()

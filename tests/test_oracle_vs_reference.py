@@ -278,3 +278,34 @@ def test_collision_and_proximity_against_moving_objects(m, steps):
             assert r._inconvenient_spawn(pos) == o._inconvenient_spawn(pos)
             n_col += int(col)
         assert n_col > 30
+
+
+def test_dr_constants_match_the_reference():
+    """The distribution table tests/test_gpu_device_reset.py checks the device sampler against IS the reference's:
+    randomization/config/default_dr.json, randomizer.py DEFAULT_CONFIG, and the camera / wheel constants of simulator.py."""
+    import ast, json, os, re
+    import test_gpu_device_reset as T
+    root = "/root/reference/src/gym_duckietown"
+    with open(os.path.join(root, "randomization/config/default_dr.json")) as f:
+        assert json.load(f) == T.DR_CONFIG
+    src = open(os.path.join(root, "randomization/randomizer.py")).read()
+    m = re.search(r"DEFAULT_CONFIG = (\{.*?\n\})", src, re.S)
+    assert ast.literal_eval(m.group(1)) == T.DR_CONFIG
+    sim = open(os.path.join(root, "simulator.py")).read()
+    for name, val in (("CAMERA_FLOOR_DIST", T.CAMERA_FLOOR_DIST), ("CAMERA_ANGLE", T.CAMERA_ANGLE), ("CAMERA_FOV_Y", T.CAMERA_FOV_Y),
+                      ("WHEEL_DIST", T.WHEEL_DIST)):
+        mm = re.search(rf"^{name} = ([0-9.]+)", sim, re.M)
+        assert mm and float(mm.group(1)) == val, name
+    # the perturbation scales and base colours used in the device test (simulator.py:551-597)
+    for frag in ("self._perturb(self.color_sky)", "self._perturb(WALL_COLOR)", "self._perturb([0.15, 0.15, 0.15], 0.4)",
+                 "self._perturb([0.9, 0.9, 0.9], 0.4)", "self._perturb(ambient, 0.3)", "self._perturb(diffuse, 0.99)",
+                 "self._perturb(np.array(self.color_ground), 0.3)", "self._perturb(WHEEL_DIST)", "DIM = 0.5",
+                 "WALL_COLOR = np.array([0.64, 0.71, 0.28])", "BLUE_SKY = np.array([0.45, 0.82, 1])"):
+        assert frag in sim, frag
+    obj = open(os.path.join(root, "objects.py")).read()
+    for frag in ("self.follow_dist = np.random.uniform(0.3, 0.4)", "self.velocity = np.random.uniform(0.05, 0.15)",
+                 "self.gain = gain + np.random.uniform(-0.3, 0.3)", "self.trim = trim + np.random.uniform(-0.1, 0.1) + 2",
+                 "self.radius = radius + 0.0002 * np.random.uniform(-1, 1)", "self.wheel_dist = wheel_dist + 0.01 * np.random.uniform(-1, 1)",
+                 "self.robot_width = robot_width + 0.01 * np.random.uniform(-1, 1)",
+                 "self.robot_length = robot_length + 0.01 * np.random.uniform(-1, 1)"):
+        assert frag in obj, frag

@@ -29,6 +29,23 @@ def _fake_frames(lo, hi, h=6, w=8):
     return ((e * 7 + yy * 3 + xx * 5 + cc * 11) % 251).to(torch.uint8)
 
 
+class _FakeSim:
+    """Stand-in for BatchedSimulator on CPU: remembers what it was given; its 'frames' are those of the global envs
+    its seed says it owns (sharding.env_seed: seed = base + first global env)."""
+    BASE = 5000
+
+    def __init__(self, map_name, n, seed=None, device=0, **kw):
+        self.n, self.seed, self.device_index = n, seed, device
+        self.last_actions = None
+
+    def step(self, actions, n_steps=1):
+        self.last_actions = np.asarray(actions)
+
+    def frames_tensor(self):
+        lo = self.seed - self.BASE
+        return _fake_frames(lo, lo + self.n)
+
+
 def _worker(rank, world, port, total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,8 +63,24 @@ def _worker(rank, world, port, total, q):
         # per-env seeds are a function of the GLOBAL env index
         seeds = [sharding.env_seed(1000, e) for e in range(lo, hi)]
         ok = ok and seeds == list(range(1000 + lo, 1000 + hi))
-        acts = np.arange(2 * total * 2, dtype=np.float32).reshape(2, total, 2)
-        ok = ok and np.array_equal(acts[:, lo:hi], np.ascontiguousarray(acts[..., lo:hi, :]))
+        # ShardedSimulator itself: rank / world from the environment, its env range, the seed of its first env, the
+        # action slice it feeds its simulator, and the frame exchange -- with a stand-in simulator that keys
+        # everything by GLOBAL env id (seed - base), so a wrong range or slice shows up in the values
+        base = 5000
+        ss = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+        ok = ok and (ss.rank, ss.world, ss.lo, ss.hi) == (rank, world, lo, hi)
+        ok = ok and ss.sim.n == hi - lo and ss.sim.seed == base + lo
+        acts = np.zeros((3, total, 2), np.float32)
+        acts[..., 0] = np.arange(total)[None, :] * 10 + np.arange(3)[:, None]        # value encodes (global env, step)
+        acts[..., 1] = -acts[..., 0]
+        ss.step(acts, n_steps=3)
+        got = ss.sim.last_actions
+        want_env = np.arange(lo, hi)[None, :] * 10 + np.arange(3)[:, None]
+        ok = ok and got.shape == (3, hi - lo, 2) and got.flags["C_CONTIGUOUS"] and np.array_equal(got[..., 0], want_env)
+        allf2 = ss.gather_frames()
+        ok = ok and bool(torch.equal(allf2, _fake_frames(0, total)))
+        rootf = ss.gather_frames(dst=0)
+        ok = ok and ((rank == 0 and bool(torch.equal(rootf, _fake_frames(0, total)))) or (rank != 0 and rootf is None))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -17,13 +17,17 @@ def counters(db):
     return acc
 
 out_dir, envs = sys.argv[1], int(sys.argv[2])
+source = sys.argv[3] if len(sys.argv) > 3 else out_dir          # label carried into bench.py's roofline.traffic_source
+valu_per_pixel = float(sys.argv[4]) if len(sys.argv) > 4 else None
+clock_ghz = float(sys.argv[5]) if len(sys.argv) > 5 else None
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 detail = {}
 for db in glob.glob(os.path.join(out_dir, "*", "*.db")):
     for k, cs in counters(db).items():
-        if "k_raster" not in k and "k_resolve" not in k and "k_cam_setup" not in k:
+        names = ("k_raster", "k_resolve", "k_cam_setup", "k_pix_setup", "k_env_sort", "k_obj_setup")
+        if not any(n in k for n in names):
             continue
-        short = "k_raster" if "k_raster" in k else ("k_resolve" if "k_resolve" in k else "k_cam_setup")
+        short = next(n for n in names if n in k)
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if c in cs:
                 v = sum(cs[c].values()) / len(cs[c])       # mean per launch
@@ -31,6 +35,7 @@ for db in glob.glob(os.path.join(out_dir, "*", "*.db")):
                 tot[c] += v
 hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 json.dump({"envs": envs, "hbm_bytes_per_launch": hbm, "fetch_KB_raw": tot["FETCH_SIZE"], "write_KB": tot["WRITE_SIZE"],
-           "per_kernel": detail, "note": "render pass = k_cam_setup + k_raster + k_resolve; FETCH_SIZE doubled per MI355X_MICROARCH.md"},
+           "per_kernel": detail, "source": source, "valu_per_pixel": valu_per_pixel, "clock_ghz": clock_ghz,
+           "note": "render pass = every kernel dtsim_render launches; FETCH_SIZE doubled per MI355X_MICROARCH.md"},
           open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "raster_pmc_latest.json"), "w"), indent=1)
 print("hbm bytes per render pass:", hbm, detail)
