@@ -554,44 +554,35 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if ((h->cfg.flags & DTSIM_F_RENDER) && tex_w == tex_h && tex_w >= 2) {
     const int S = tex_w;
     qlog2 = 0; while ((1 << qlog2) < S) ++qlog2;
-    std::vector<int> block_of((size_t)std::max(h->n_tex, 1), -1);
-    // the two one-record blocks: off-grid (meta high half 1) and untextured (meta 0, white taps); then the S x S blocks
-    const uint32_t special[8] = {0u, 0u, 0u, 1u << 16, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+    std::vector<int> block_of((size_t)std::max(h->n_tex, 1) * 4, -1);
+    // the two one-record blocks: off-grid (meta high half 1) and untextured (meta 0); then the S x S blocks
+    const uint32_t special[8] = {0u, 0u, 0u, 1u << 16, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};   // untextured: white vertex colour
     qblocks.assign(special, special + 8);
     const size_t block_bytes = (size_t)S * S * 16;
-    const bool s256 = qlog2 == 8;
+    const uint32_t cell_sel = (qlog2 == 8) ? 0x0c0c0400u : (uint32_t)(S * S - 1);   // v_perm selector (S = 256) / cell mask
+    const uint32_t zero_sel = (qlog2 == 8) ? 0x0c0c0c0cu : 0u;
     int n_blocks = 0;
-    // QTile fields per tile angle (render.hip QTile; derivation in DESIGN.md 3): cell (x0, z0) of a tile rotated by
-    // angle a is cell (x0', z0') of the angle-0 block, a = 1: (S - z0, x0), a = 2: (S - x0, S - z0), a = 3: (z0, S - x0)
-    // (mod S), and the stored taps [t00' t10' t01' t11'] take the weights a = 1: [w01 w00 w11 w10], a = 2: [w11 w01 w10 w00],
-    // a = 3: [w10 w11 w00 w01].
-    const uint32_t SEL1[4] = {0x0c040c00u, 0x0c000c04u, 0x0c040c00u, 0x0c000c04u};     // S = 256: spread / swap the cell bytes
-    const uint32_t MUL[4] = {0x00010001u, 0x0001FFFFu, 0xFFFFFFFFu, 0xFFFF0001u};      // (x' multiplier) | (z' multiplier) << 16
-    const uint32_t WLO[4] = {0x06040200u, 0x02060004u, 0x00020406u, 0x04000602u};
     for (int mi = 0; mi < n_maps; ++mi) {
       const dtsim_map& mp = maps[mi];
       RenderMapDev& rm = rmaps[mi];
-      rm.qt_off = (int32_t)(qtiles.size() / 8); rm.qt_pitch = mp.grid_w + 2 * DT_QRING;
+      rm.qt_off = (int32_t)(qtiles.size() / 2); rm.qt_pitch = mp.grid_w + 2 * DT_QRING;
       q_per_m = std::max(q_per_m, (float)((double)S / mp.tile_size));
       for (int j = -DT_QRING; j < mp.grid_h + DT_QRING; ++j)
         for (int i = -DT_QRING; i < mp.grid_w + DT_QRING; ++i) {
-          uint32_t qt[8] = {0u, s256 ? 0x0c0c0c0cu : 0u, 0x00010001u, WLO[0], WLO[0] | 0x01010101u, 0u, 0u, 0u};   // record 0: off-grid
+          uint32_t off = 0u, sel = zero_sel;        // record 0: off-grid
           if (i >= 0 && j >= 0 && i < mp.grid_w && j < mp.grid_h) {
             const int t = j * mp.grid_w + i;
             if (mp.tile_kind[t] != DTSIM_TILE_EMPTY) {
               const int tx = mp.tile_tex[t];
-              if (tx < 0 || tx >= (int)h->h_tex.size()) qt[0] = 16u;   // record 1: present but untextured
+              if (tx < 0 || tx >= (int)h->h_tex.size()) off = 16u;   // record 1: present but untextured
               else {
-                int& b = block_of[(size_t)tx];
-                if (b < 0) { b = n_blocks++; build_quad_block(qblocks, h->h_pool.data() + h->h_tex[tx].off, S, 0); }
-                const int a = mp.tile_angle[t] & 3;
-                qt[0] = (uint32_t)(32 + (size_t)b * block_bytes);
-                qt[1] = s256 ? SEL1[a] : ((uint32_t)(a & 1) | 0x80000000u);
-                qt[2] = MUL[a]; qt[3] = WLO[a]; qt[4] = WLO[a] | 0x01010101u;
+                int& b = block_of[(size_t)tx * 4 + (mp.tile_angle[t] & 3)];
+                if (b < 0) { b = n_blocks++; build_quad_block(qblocks, h->h_pool.data() + h->h_tex[tx].off, S, mp.tile_angle[t] & 3); }
+                off = (uint32_t)(32 + (size_t)b * block_bytes); sel = cell_sel;
               }
             }
           }
-          qtiles.insert(qtiles.end(), qt, qt + 8);
+          qtiles.push_back(off); qtiles.push_back(sel);
         }
     }
     if (32 + (size_t)n_blocks * block_bytes >= ((size_t)1 << 32)) qlog2 = -1;   // 32-bit block offsets
@@ -611,7 +602,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     HIPCHK(hipMemcpy(h->d_qtex, qblocks.data(), qblocks.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->d_qtiles, qtiles.size() * 4));
     HIPCHK(hipMemcpy(h->d_qtiles, qtiles.data(), qtiles.size() * 4, hipMemcpyHostToDevice));
-    h->n_qtiles = (int)qtiles.size() / 8; h->qlog2 = qlog2; h->q_per_m = q_per_m;
+    h->n_qtiles = (int)qtiles.size() / 2; h->qlog2 = qlog2; h->q_per_m = q_per_m;
   }
   HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
   if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));

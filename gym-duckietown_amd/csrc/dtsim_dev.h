@@ -172,11 +172,10 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 #endif
 #define DT_ITEM_B 8                          // 64-entry edge batches per k_resolve work item
 #define DT_ITEMS_PER_WG (4 * (DT_PPT * DT_ENVS_PER_BLOCK) / DT_ITEM_B) // worst case: 4 regions x (64*PPT px x envs / 64) batches
-// Quad-layout tile textures for the one-ray fast path (render.hip k_raster_q): per tile texture one block of S x S
-// records of 16 bytes in the tile frame of angle 0, record (x0, z0) = the four GL_LINEAR taps around quad cell (x0, z0)
-// as channel-planar bytes {R00 R10 R01 R11}, {G..}, {B..} + a meta dword (DT_QMETA); the tile angle is applied through
-// the per-tile table entry (render.hip QTile).
-#define DT_QRING 2                           // ring of off-grid cells around each map's tile table, in tiles
+// Quad-layout tile textures for the one-ray fast path (render.hip k_raster_q): per (texture, tile angle) pair one
+// block of S x S records of 16 bytes, record (x0, z0) = the four GL_LINEAR taps of the pre-rotated tile texture around
+// quad cell (x0, z0) as channel-planar bytes {R00 R10 R01 R11}, {G..}, {B..} + a meta dword (see DT_QMETA_*).
+#define DT_QRING 4                           // ring of off-grid cells around each map's tile table, in tiles
 // The pool starts with two single records every cell of a non-textured tile maps to: record 0 = off the grid (ground
 // quad / sky), record 1 = present but untextured tile (exact path).
 // DT_QMETA -- meta dword: low 16 bits = cells to the nearest tile boundary if the cell belongs to a textured tile (else 0),
@@ -213,7 +212,7 @@ struct RenderParams {
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
   // quad-layout fast path (null qtex: the generic k_raster is used)
   const uint8_t* qtex;          // quad blocks, 16 B records
-  const uint32_t* qtiles;       // [n_qtiles][8] per padded-table cell: render.hip QTile (block offset, rotation, weight order); maps concatenated
+  const uint32_t* qtiles;       // [n_qtiles][2] per padded-table cell: byte offset of its block, cell selector; maps concatenated
   int32_t n_qtiles, qlog2;      // qlog2: log2(S), S = tile texture size
   float q_per_m;                // quad cells per metre (S / tile_size), max over maps: scales the MSAA margin
   int32_t qmax_tiles;           // largest padded grid extent over the maps (tiles)

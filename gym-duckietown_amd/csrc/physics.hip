@@ -22,7 +22,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef STEP_BLOCK
 #define STEP_BLOCK 64
+#endif
 
 namespace {
 

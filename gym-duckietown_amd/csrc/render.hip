@@ -252,7 +252,7 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
     q.A = f.A * S; q.B = f.B * S;
     q.Cx = f.Cxi * S + 0.5f + (float)DT_QRING * S; q.Cz = f.Czi * S + 0.5f + (float)DT_QRING * S;
     q.Xhi = ((float)(m.grid_w + 2 * DT_QRING) - 0.5f) * S; q.Zhi = ((float)(m.grid_h + 2 * DT_QRING) - 0.5f) * S;
-    q.tab_b = (uint32_t)m.qt_off * 32u; q.pitch4 = (uint32_t)m.qt_pitch * 32u;   // 32-byte table entries (QTile)
+    q.tab_b = (uint32_t)m.qt_off * 8u; q.pitch4 = (uint32_t)m.qt_pitch * 8u;   // 8-byte table entries
     q.hor_rgb = f.hor_rgb;
     const uint32_t r = f.hor_rgb & 255u, g = (f.hor_rgb >> 8) & 255u, b = (f.hor_rgb >> 16) & 255u;
     q.sky[0] = r | (g << 8) | (b << 16) | (r << 24);
@@ -1128,32 +1128,6 @@ __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixT
 
 __device__ inline float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
-// Padded-table entry of one tile (32 bytes, LDS): where its texture's quad block is and how the tile's orientation maps
-// onto it.  One block per TEXTURE is stored (the tile frame of angle 0); a tile rotated by angle * 90 degrees reads the
-// same records through a rotation of the cell index -- swap of the axes (sel1, a v_perm selector that also spreads the
-// two cell bytes into 16-bit halves), negation modulo S of either axis (mul, packed 16-bit multipliers 1 / 0xFFFF) --
-// and a permutation of the four bilinear weights (wsel_lo / wsel_hi, the selectors that split the u16 weights into byte
-// planes).  The pool is then 1 MB per texture and stays in the 4 MB L2 of an XCD.  The two one-record blocks (off-grid,
-// untextured) have sel1 = all-zero bytes, so every cell maps to record 0.
-struct alignas(16) QTile { uint32_t base, sel1, mul, wsel_lo, wsel_hi, pad[3]; };
-static_assert(sizeof(QTile) == 32, "QTile is 32 bytes");
-template <bool S256>
-__device__ inline uint32_t qtile_cell(const uint32_t xi, const uint32_t zi, const uint32_t sel1, const uint32_t mul, const int LS) {
-  if (S256) {
-    const uint32_t h = __builtin_amdgcn_perm(zi, xi, sel1);            // (x source byte) | (z source byte) << 16
-    uint32_t r;
-    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(h), "v"(mul));    // negation modulo 65536 where the multiplier is 0xFFFF
-    return __builtin_amdgcn_perm(r, r, 0x0c0c0200u);                   // (z' & 255) << 8 | (x' & 255)
-  } else {   // any power-of-two S: sel1 bit 0 = swap, bit 31 = textured block; mul as above
-    const uint32_t SM = (1u << LS) - 1u;
-    const uint32_t x0 = xi & SM, z0 = zi & SM;
-    const uint32_t xs = (sel1 & 1u) ? z0 : x0, zs = (sel1 & 1u) ? x0 : z0;
-    const uint32_t xr = ((mul & 0xFFFFu) == 0xFFFFu ? 0u - xs : xs) & SM, zr = ((mul >> 16) == 0xFFFFu ? 0u - zs : zs) & SM;
-    return (sel1 >> 31) ? ((zr << LS) | xr) : 0u;
-  }
-}
-
-
 // ---- resolve_region: exact path of the quad-layout pipeline (shared camera, no mesh objects) ----------------------
 // Called by every wavefront of k_raster_q at the end of its env loop on ITS OWN queue region (the entries it appended):
 // no second launch, no work list, no atomics -- and the gather-bound resolve of one wavefront overlaps the VALU-bound
@@ -1168,14 +1142,14 @@ __device__ inline uint32_t qtile_cell(const uint32_t xi, const uint32_t zi, cons
 //      +-50 m; else the clear colour), shading once per distinct primitive at the pixel centre (GL semantics:
 //      simulator.py:1932-1934, graphics.py:172-251): a tile is shaded with ITS texture at the centre hit -- outside the
 //      tile the coordinate wraps (GL_REPEAT), which the quad records encode -- times the centre's lit factor.
-__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias, uint32_t wsel_lo, uint32_t wsel_hi) {
+__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias) {
   const float axI = ax * I, azI = az * I;
   const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
   uint32_t WA, WB;
   __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, wsel_lo), wh = __builtin_amdgcn_perm(WB, WA, wsel_hi);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
   // three 24-bit sums  sum(tap * w16)  packed as bytes 2 of (vr, vg, vb) when bias = 32768; callers that need the
   // unrounded value pass bias = 0 and use quad_filter3
   const uint32_t vr = (__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, bias, false);
@@ -1184,14 +1158,14 @@ __device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float
   const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
   return __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
 }
-__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, uint32_t wsel_lo, uint32_t wsel_hi, float out[3]) {   // 0..255 floats
+__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats
   const float axI = ax * I, azI = az * I;
   const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
   uint32_t WA, WB;
   __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, wsel_lo), wh = __builtin_amdgcn_perm(WB, WA, wsel_hi);
+  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
   const uint32_t v[3] = {(__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, 0u, false),
                          (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, 0u, false),
                          (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
@@ -1208,6 +1182,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
                                       const int lane) {
   const int npix = R.W * R.H;
   const int LS = R.qlog2;
+  const uint32_t SM = (1u << LS) - 1u;
   const float Sf = (float)(1 << LS), lo = 0.5f * Sf;
   const char* qtb = reinterpret_cast<const char*>(s_qt);
 
@@ -1215,19 +1190,19 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
   // on (X - 0.5, Z - 0.5) -- unlike the record lookup, which goes by whole cells.  (ox, oz): the tile's origin.
   auto tile_entry = [&](float X, float Z, const float Xhi, const float Zhi, const uint32_t tab_b, const uint32_t pitch4, uint32_t& ta,
-                        float& ox, float& oz) -> uint2 {   // (block base, table byte address): the rest of the entry is read on demand
+                        float& ox, float& oz) -> uint2 {
     const float Xc = med3f(X - 0.5f, lo, Xhi), Zc = med3f(Z - 0.5f, lo, Zhi);
     const uint32_t ti = (uint32_t)flr_i32(Xc) >> LS, tj = (uint32_t)flr_i32(Zc) >> LS;
     ox = (float)(ti << LS) + 0.5f; oz = (float)(tj << LS) + 0.5f;
-    ta = (ti << 5) + __umul24(tj, pitch4) + tab_b;
-    return make_uint2(*reinterpret_cast<const uint32_t*>(qtb + ta), ta);
+    ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
+    return *reinterpret_cast<const uint2*>(qtb + ta);
   };
   // quad record of block entry `te` at the cell the (unclamped) coordinates fall into, wrapped into the tile
-  auto tile_quad = [&](const uint2 te, float X, float Z, uint32_t& wsel_lo, uint32_t& wsel_hi) -> uint4 {
-    const QTile* qt = reinterpret_cast<const QTile*>(qtb + te.y);
+  auto tile_quad = [&](const uint2 te, float X, float Z) -> uint4 {
     const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
-    const uint32_t local = qtile_cell<S256>(xi, zi, qt->sel1, qt->mul, LS);
-    wsel_lo = qt->wsel_lo; wsel_hi = qt->wsel_hi;
+    uint32_t local;
+    if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);
+    else local = (((zi & SM) << LS) | (xi & SM)) & te.y;
     return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
   };
   auto store_rgb = [&](int e, int pix, uint32_t rgb) {
@@ -1287,12 +1262,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       interior[u] = have[u] && in_range && te_c[u].x >= 32u && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
     }
     uint4 qc[U];
-    uint32_t wlo[U], whi[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u], wlo[u], whi[u]);   // always in bounds (record 0 / 1 for non-tiles)
+    for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]);   // always in bounds (record 0 / 1 for non-tiles)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u, wlo[u], whi[u]);
+      const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
       if (interior[u]) store_rgb(env[u], pix[u], rgb);
       const bool msaa = have[u] && !interior[u];
       const unsigned long long mm = __ballot(msaa);
@@ -1368,10 +1342,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         int cnt = 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
-        uint32_t wlo, whi;
-        const uint4 qt = tile_quad(t0, Xu, Zu, wlo, whi);
+        const uint4 qt = tile_quad(t0, Xu, Zu);
         float col[3];
-        quad_filter3(qt, ax, az, lit, wlo, whi, col);
+        quad_filter3(qt, ax, az, lit, col);
 #pragma unroll
         for (int k = 0; k < 3; ++k) acc[k] += (float)cnt * col[k];
       }
@@ -1441,7 +1414,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   const int rwg = chunk * n_tiles + tile;            // logical workgroup index: queue regions, counts, work items
   const int e0 = chunk * ENVS_PER_BLOCK;             // positions in the render order
   const int e1 = min(e0 + ENVS_PER_BLOCK, R.N);
-  for (int i = tid; i < R.n_qtiles * 8; i += RB) s_qt[i] = qtiles[i];
+  for (int i = tid; i < R.n_qtiles * 2; i += RB) s_qt[i] = qtiles[i];
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -1484,7 +1457,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
 
   uint16_t* w_queue = queue + ((size_t)rwg * (RB / 64) + wave) * QREGION;
   int qn = 0;
-  uint32_t* s_px = s_mem + R.n_qtiles * 8 + wave * WAVE_PIX;
+  uint32_t* s_px = s_mem + R.n_qtiles * 2 + wave * WAVE_PIX;
   const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
   // frame rows are dword aligned (W % 4 == 0: launch precondition; other widths take the generic k_raster)
   const bool st_ok = lane * 4 < WAVE_PIX && st_x < R.W && st_y < R.H;
@@ -1535,7 +1508,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   // gfx950 retires vector memory operations of a wavefront in issue order (one vmcnt for loads and stores), so a
   // load issued after a store cannot be waited for without also waiting for that store's write acknowledge; with the
   // loads of the next env ahead of the stores, a wavefront only ever waits for stores that are two envs old.
-  struct QStage { uint4 q[PPT]; f2 ax2[PPT / 2], az2[PPT / 2]; uint32_t wlo[PPT], whi[PPT]; };
+  struct QStage { uint4 q[PPT]; f2 ax2[PPT / 2], az2[PPT / 2]; };
   auto issue_t = [&](const EnvQ& f, QStage& st, auto clamp_tag) __attribute__((always_inline)) {
     constexpr bool CLAMP = decltype(clamp_tag)::value;
     const f2 vA = f2{f.A, f.A}, vB = f2{f.B, f.B}, vCx = f2{f.Cx, f.Cx}, vCz = f2{f.Cz, f.Cz};
@@ -1555,18 +1528,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
         // block offset of the cell's tile: LDS table, byte address = tab_b + (zi >> LS) * pitch4 + ((xi >> LS) << 2)
         // The table entry is 8 bytes: the block's byte offset and how the cell index is formed -- for the two
         // one-record blocks (off-grid, untextured) every cell maps to record 0, so they do not occupy cache lines.
-        uint32_t ta;
+        uint32_t ta, local;
         if (S256) {   // S = 256 and a padded grid under 256 tiles: tile = byte 1, cell = byte 0 of the coordinate
           uint32_t t1, t2;
           asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t1) : "v"(zi), "s"(f.pitch4));
-          asm("v_lshlrev_b32_sdwa %0, 5, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t2) : "v"(xi));
+          asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t2) : "v"(xi));
           ta = t1 + t2 + f.tab_b;
-        } else ta = ((xi >> LS) << 5) + (__umul24(zi >> LS, f.pitch4) + f.tab_b);
-        const QTile* qt = reinterpret_cast<const QTile*>(s_qtb + ta);
-        const uint4 te = *reinterpret_cast<const uint4*>(qt);                  // base, sel1, mul, wsel_lo
-        st.wlo[k] = te.w; st.whi[k] = qt->wsel_hi;
+        } else ta = ((xi >> LS) << 3) + (__umul24(zi >> LS, f.pitch4) + f.tab_b);
+        const uint2 te = *reinterpret_cast<const uint2*>(s_qtb + ta);
         const uint32_t tb = te.x;
-        const uint32_t local = qtile_cell<S256>(xi, zi, te.y, te.z, LS);
+        if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);                 // te.y: v_perm selector (z0 << 8) | x0, or 0
+        else local = (((zi & SM) << LS) | (xi & SM)) & te.y;                   // te.y: cell mask
 #ifdef DT_Q_NO_LOAD
         st.q[k] = make_uint4(tb + local, tb ^ local, local, 0x00000080u);
 #elif defined(DT_Q_HOT_LOAD)
@@ -1631,7 +1603,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
         const us2 wb = __builtin_amdgcn_cvt_pknorm_u16(h ? w01.y : w01.x, h ? w11.y : w11.x);
         uint32_t WA, WB;
         __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-        const uint32_t wl = __builtin_amdgcn_perm(WB, WA, st.wlo[k]), wh = __builtin_amdgcn_perm(WB, WA, st.whi[k]);
+        const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
         const uint32_t vr = (__builtin_amdgcn_udot4(q[k].x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].x, wl, 32768u, false);
         const uint32_t vg = (__builtin_amdgcn_udot4(q[k].y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].y, wl, 32768u, false);
         const uint32_t vb = (__builtin_amdgcn_udot4(q[k].z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].z, wl, 32768u, false);
@@ -1960,7 +1932,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
-  const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 32 <= 40960 && (R.W & 3) == 0;
+  const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0;
   const bool obj = R.max_tris > 0;
   // render order (k_env_sort): only the quad pipeline without mesh objects indexes by position (k_resolve<true> and
   // k_obj_setup address envs directly)
@@ -1982,7 +1954,7 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
   if (quad) {
-    const size_t ldsq = (size_t)R.n_qtiles * 32 + (size_t)RB * PPT * sizeof(uint32_t);
+    const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
     PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
     hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
