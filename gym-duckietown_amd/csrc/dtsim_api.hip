@@ -91,6 +91,7 @@ struct dtsim {
   ScreenTri* d_stris = nullptr;
   ObjEnv* d_objenv = nullptr;
   ObjBox* d_objbox = nullptr;
+  void* d_objmask = nullptr;    // block boxes [tiles*4][4] floats, then object masks [N][tiles*4] u64
   std::vector<uint32_t> h_pool;       // host copy of the RGBA8 pool (quad blocks are built from it at dtsim_set_maps)
   void* d_pixtab = nullptr;           // per-pixel tables of the shared camera (k_pix_setup)
   uint8_t* d_qtex = nullptr;          // quad-layout blocks for k_raster_q
@@ -272,7 +273,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -609,12 +610,15 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
   if (h->d_objenv) { (void)hipFree(h->d_objenv); h->d_objenv = nullptr; }
   if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
+  if (h->d_objmask) { (void)hipFree(h->d_objmask); h->d_objmask = nullptr; }
   h->max_tris = 0;
   for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
   if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
     HIPCHK(hipMalloc(&h->d_stris, sizeof(ScreenTri) * (size_t)h->max_tris * h->N));
     HIPCHK(hipMalloc(&h->d_objenv, sizeof(ObjEnv) * (size_t)h->N));
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
+    const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
+    HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)h->N * n_blk * 8));
   }
   h->n_tilerecs = (int)trecs.size();
   h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
@@ -819,7 +823,10 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.segment = segment ? 1 : 0; R.mesh_seg = h->d_mesh_seg;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
-  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox; R.queue = h->d_queue; R.qcount = h->d_qcount;
+  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox;
+  R.blockbox = reinterpret_cast<float*>(h->d_objmask);
+  R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
+  R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
   R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items;

@@ -160,7 +160,7 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 
 // raster work decomposition: a workgroup owns a DT_TILE_W x DT_TILE_H pixel tile for 32 consecutive envs
 #ifndef DT_WAVE_W
-#define DT_WAVE_W 64                       // pixel columns of a wavefront's block
+#define DT_WAVE_W 128                      // pixel columns of a wavefront's block (128 x 2 pixels; 64 x 4 measured 2.5 % slower)
 #endif
 #ifndef DT_PPT
 #define DT_PPT 4                           // pixels per lane: a wavefront's block is 64 * DT_PPT pixels
@@ -204,6 +204,8 @@ struct RenderParams {
   ScreenTri* stris;             // [N][max_tris]
   ObjEnv* objenv;               // [N]
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
+  float* blockbox;              // [raster tiles * 4][4] source-pixel bounding box of each raster wavefront block (k_blk_setup)
+  unsigned long long* objmask;  // [N][raster tiles * 4] objects whose screen box meets the block (bit o), written by k_obj_setup
   uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
   int32_t* qcount;              // [workgroups][4]
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null

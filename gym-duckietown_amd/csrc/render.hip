@@ -8,8 +8,8 @@
 // Structure
 //   k_cam_setup : one thread per env -> EnvCam (camera centre, yaw, colours, ground-corner
 //                 lighting; with DR also pitch / frustum / light), 128 B per env.
-//   k_raster<DR,OBJ>: workgroup = 4 independent wavefronts owning a 64 x 16 pixel tile of the
-//                 frame (wavefront w: rows 4w..4w+3; lane l: column l of each row), looping over
+//   k_raster<DR,OBJ>: workgroup = 4 independent wavefronts owning a DT_TILE_W x DT_TILE_H = 128 x 8 pixel
+//                 tile of the frame (wavefront w: rows 2w, 2w+1; lane l: columns l and l+64 of each row), looping over
 //                 ENVS_PER_BLOCK envs.  Adjacent lanes are adjacent pixels, so one texel-load
 //                 instruction touches neighbouring texture lines (TA coalescing) and the tile's
 //                 2-D texture footprint stays in L1.  Everything that does not depend on the env
@@ -25,7 +25,7 @@
 //                 border, tile seams, mesh boxes; conservative test) are appended (ballot +
 //                 mbcnt, no atomics) to a per-wavefront global queue region.
 //                 Output: px -> wavefront-private LDS transpose -> 12 B (4 px) per lane, three
-//                 dword stores, 192 contiguous bytes per tile row.
+//                 dword stores, 384 contiguous bytes per tile row.
 //   k_obj_setup (maps with objects): one workgroup per env projects the env's mesh triangles to screen space
 //                 (per-vertex lighting, texture index, traffic-light card by pattern, segmentation colour) and
 //                 reduces per-object screen boxes.
@@ -53,6 +53,7 @@
 #define SLOT_Y(k, l) (((k) * 64 + (l)) / WAVE_W)
 #define WAVE_PIX (64 * PPT)
 #define ENVS_PER_BLOCK DT_ENVS_PER_BLOCK
+#define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
@@ -276,7 +277,34 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
 __device__ inline int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ inline float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams) {
+// Source-pixel bounding box of every raster wavefront block (tile * 4 + wavefront): env-invariant, one workgroup per
+// raster tile.  Empty blocks (no pixel inside the rectilinear image) get an inverted box.
+__global__ __launch_bounds__(RB) void k_blk_setup(RenderParams R, const float4* __restrict__ lut, float4* __restrict__ blockbox) {
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W;
+  const int tile = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile_x0 = (tile % tiles_x) * DT_TILE_W;
+  const int wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
+  float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int x = tile_x0 + SLOT_X(k, lane), y = wave_y0 + SLOT_Y(k, lane);
+    if (x < R.W && y < R.H) {
+      const float4 l = lut[y * R.W + x];
+      if (l.z != 0.f) {
+        const float sx = (l.x + 1.f) * 0.5f * (float)R.W, sy = (1.f - l.y) * 0.5f * (float)R.H;
+        x0 = fminf(x0, sx); x1 = fmaxf(x1, sx); y0 = fminf(y0, sy); y1 = fmaxf(y1, sy);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
+    y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+  }
+  if (lane == 0) blockbox[tile * 4 + wave] = make_float4(x0, x1, y0, y1);
+}
+
+__global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t N = A.N;
@@ -286,6 +314,7 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;
   // per-object screen boxes: LDS min / max through the order-preserving float -> int map
   __shared__ int s_obox[DTSIM_MAX_OBJECTS][4];
+  __shared__ float s_oboxf[DTSIM_MAX_OBJECTS][4];
   if (tid < DTSIM_MAX_OBJECTS) {
     s_obox[tid][0] = s_obox[tid][2] = 0x7fffffff;    // min slots
     s_obox[tid][1] = s_obox[tid][3] = (int)0x80000000;   // max slots
@@ -381,6 +410,21 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     ob.by0 = live ? ord2f(s_obox[tid][2]) : 1e30f; ob.by1 = live ? ord2f(s_obox[tid][3]) : -1e30f;
     ob.count = live ? cnt : 0;
     R.objbox[(size_t)e * DTSIM_MAX_OBJECTS + tid] = ob;
+    s_oboxf[tid][0] = ob.bx0; s_oboxf[tid][1] = ob.bx1; s_oboxf[tid][2] = ob.by0; s_oboxf[tid][3] = ob.by1;   // empty when not live
+  }
+  __syncthreads();
+  if (R.objmask) {
+    // which objects' screen boxes meet each raster wavefront block (source-pixel boxes of the blocks: k_blk_setup): the
+    // raster reads one 8-byte mask per (env, block) instead of walking the env's object boxes
+    const int n_blk = ((R.W + DT_TILE_W - 1) / DT_TILE_W) * ((R.H + DT_TILE_H - 1) / DT_TILE_H) * 4;
+    const float4* bbx = reinterpret_cast<const float4*>(R.blockbox);
+    for (int b = tid; b < n_blk; b += 256) {
+      const float4 bb = bbx[b];                      // x0, x1, y0, y1
+      unsigned long long mk = 0ull;
+      for (int o = 0; o < m.n_obj; ++o)
+        if (!(bb.y < s_oboxf[o][0] || bb.x > s_oboxf[o][1] || bb.w < s_oboxf[o][2] || bb.z > s_oboxf[o][3])) mk |= 1ull << o;
+      R.objmask[(size_t)(pos ? pos[e] : e) * n_blk + b] = mk;   // indexed by position in the render order
+    }
   }
   __shared__ float red[4][256];
   red[0][tid] = bx0; red[1][tid] = bx1; red[2][tid] = by0; red[3][tid] = by1;
@@ -564,8 +608,15 @@ __device__ inline void shade(const EnvCam& c, const MapU& m, const RenderParams&
 
 // z-buffer one mesh triangle against the 4 samples of the pixel centred at (pcx, pcy) px.
 template <typename Tri>
+__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]);
+template <typename Tri>
 __device__ inline void test_tri(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
   if (pcx < st.bx0 || pcx > st.bx1 || pcy < st.by0 || pcy > st.by1) return;
+  test_tri_inside(st, pcx, pcy, zbest, tbest);
+}
+// ... the pixel centre is already known to lie in the triangle's (padded) screen box
+template <typename Tri>
+__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
 #pragma unroll
@@ -597,7 +648,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
   const unsigned long long mm = __ballot(mine);
   const int n_mine = __popcll(mm);
   const int n_chunks = (fill + 63) >> 6;
-  const bool tri_parallel = n_mine * (n_chunks * 110 + 110) < fill * 25;
+  const bool tri_parallel = n_mine * (n_chunks * 110 + 110) < fill * 8 + 400;
   if (dbg && lane == 0) {                            // DTSIM_DEBUG_QUEUE statistics
     atomicAdd(dbg + 2, fill); atomicAdd(dbg + 3, n_mine); atomicAdd(dbg + 4, 1); atomicAdd(dbg + 5, tri_parallel ? 1 : 0);
     atomicAdd(reinterpret_cast<unsigned long long*>(dbg + 6), (unsigned long long)fill * (unsigned long long)n_mine);
@@ -631,8 +682,38 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
         }
       }
     }
-  } else if (mine) {
-    for (int k = 0; k < fill; ++k) test_tri(w_tris[k], pcx, pcy, zbest, tbest);
+  } else {
+    // Pixel-parallel in two steps.  (1) Every lane tests its pixel against the screen boxes of all staged triangles
+    // (one broadcast 16-byte LDS read + four compares each) and keeps the hits as a bit mask.  (2) Each lane walks
+    // its own mask: the wavefront runs max-over-lanes(candidates) passes of the 4-sample test, with a different
+    // triangle per lane, instead of one pass per staged triangle (a 64-pixel batch is a thin strip of the object:
+    // most staged triangles hold only a few of its pixels).
+    static_assert(TRI_CAP == 128, "four 32-bit candidate masks");
+    uint32_t cand[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c * 32 >= fill) break;                     // wave-uniform
+      const int nk = min(32, fill - c * 32);
+      uint32_t mm = 0u;
+      for (int j = 0; j < nk; ++j) {
+        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[c * 32 + j]);   // bx0, bx1, by0, by1
+        const bool in = (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
+        mm |= in ? (1u << j) : 0u;
+      }
+      cand[c] = mine ? mm : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c * 32 >= fill) break;
+      uint32_t mm = cand[c];
+      while (__ballot(mm != 0u)) {                   // wave-uniform trip count
+        if (mm) {
+          const int j = __builtin_ctz(mm);
+          mm &= mm - 1u;
+          test_tri_inside(w_tris[c * 32 + j], pcx, pcy, zbest, tbest);
+        }
+      }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -793,7 +874,6 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 // sized (every pixel of every env of the chunk), so appends need no atomics; entry =
 // (env-in-chunk << 8) | (row-slot k << 6 | lane).  k_resolve drains the regions 64 entries at a time.
 #define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
-#define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
 #define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
 #define GRAB_MAX 16       // work items per cursor atomic, at most
@@ -820,11 +900,12 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   }
   __syncthreads();
 
-  // Pixel ownership: the workgroup owns a 64 x 16 pixel tile, wavefront w its rows 4w..4w+3, lane l
-  // column l of each of those rows (slot k = row).  Adjacent lanes are adjacent pixels, so the texel
+  // Pixel ownership: the workgroup owns a WAVE_W x DT_TILE_H (128 x 8) pixel tile, wavefront w its rows 2w, 2w+1, lane l
+  // pixel (k*64 + l) of the wavefront's row-major block (slot k).  Adjacent lanes are adjacent pixels, so the texel
   // addresses of one load instruction are neighbours in the texture, and the 2D footprint of the tile
   // keeps its texture lines in L1.
   const int wave = tid >> 6, lane = tid & 63;
+  const int blk = tile * 4 + __builtin_amdgcn_readfirstlane(wave);   // raster wavefront block (objmask / blockbox index)
   const int tile_x0 = (tile % tiles_x) * DT_TILE_W;
   const int wave_y0 = (tile / tiles_x) * DT_TILE_H + wave * (WAVE_PIX / WAVE_W);
   const float aspect = (float)R.W / (float)R.H;
@@ -876,6 +957,12 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
   const int tw1 = R.tex_w + 1, xmask = R.tex_w - 1, ymask = R.tex_h - 1;
 
+  // object masks of the chunk's envs for this block: one vector load, lane l <-> env e0 + l (see k_raster_q)
+  uint32_t om_lo = 0u, om_hi = 0u;
+  if (OBJ && lane < e1 - e0) {
+    const unsigned long long v = R.objmask[(size_t)(e0 + lane) * (n_tiles * 4) + blk];
+    om_lo = (uint32_t)v; om_hi = (uint32_t)(v >> 32);
+  }
   for (int e = e0; e < e1; ++e) {
     const EnvFast f = fasts[e];                      // wave-uniform: one 64-byte scalar load
     float base0 = 0.f, base1 = 0.f, base2 = 0.f, dif0 = 0.f, dif1 = 0.f, dif2 = 0.f;
@@ -997,16 +1084,15 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     // ---- mesh objects: every pixel inside the union box of the env's projected triangles
     // takes the exact path (which z-buffers the triangles per sample)
     if (OBJ) {
-      const ObjEnv oe = R.objenv[e];                 // wave-uniform
-      if (oe.n_tris > 0 && wbx1 >= oe.bx0 && wbx0 <= oe.bx1 && wby1 >= oe.by0 && wby0 <= oe.by1) {
-        const ObjBox* boxes = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
-        for (int o = 0; o < oe.n_obj; ++o) {
-          const ObjBox ob = boxes[o];                // wave-uniform
-          if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
+      unsigned long long om = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)om_hi, e - e0) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)om_lo, e - e0);   // objects whose box meets this block
+      const ObjBox* boxes = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
+      while (om) {
+        const ObjBox ob = boxes[__builtin_ctzll(om)];  // wave-uniform
+        om &= om - 1ull;
 #pragma unroll
-          for (int k = 0; k < PPT; ++k)
-            if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
-        }
+        for (int k = 0; k < PPT; ++k)
+          if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
       }
     }
 
@@ -1372,7 +1458,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 //     each axis straddles the seam (half of it belongs to the neighbour tile) and is always an edge;
 //   * all-sky wavefront blocks (env-invariant with the shared camera) take a three-store loop.
 // Anything that is not a fast tile pixel falls into a wave-uniform slow branch that decides ground-fast vs edge and
-// appends edge pixels to the queue exactly as k_raster does; k_resolve is unchanged.
+// appends edge pixels to the wavefront's queue region; the exact path (resolve_region) drains it at the end of the env loop.
+// With mesh objects (OBJ) the pixels inside object screen boxes are appended from the far end of the region instead and
+// left to k_resolve<true>.
 
 #ifndef DT_Q_WAVES
 #define DT_Q_WAVES 5                                 // wavefronts per SIMD the register allocation is held to (96 VGPRs)
@@ -1386,8 +1474,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 #ifndef DT_Q_SCHED_BARRIER
 #define DT_Q_SCHED_BARRIER 1
 #endif
+#ifndef DT_Q_PRIO
+#define DT_Q_PRIO 3                                  // s_setprio level while a wavefront issues its quad loads (0: off)
+#endif
 template <bool OBJ, bool S256>
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, DT_Q_WAVES))) void k_raster_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_WAVES - 1 : DT_Q_WAVES, OBJ ? DT_Q_WAVES - 1 : DT_Q_WAVES))) void k_raster_q(RenderParams R, const EnvCam* __restrict__ cams, const EnvFast* __restrict__ fasts,
                                                  const EnvQ* __restrict__ envq, uint8_t* __restrict__ frames,
                                                  const uint8_t* __restrict__ qtex, const float4* __restrict__ lut, const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
                                                  const uint32_t* __restrict__ qtiles, uint16_t* __restrict__ queue,
@@ -1428,8 +1519,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   float lr[PPT], lf[PPT], lit[PPT];
   uint32_t Mi[PPT];
   bool cand[PPT], gok[PPT], valid[PPT];
-  float spx[PPT], spy[PPT];
-  float wbx0 = 1e30f, wbx1 = -1e30f, wby0 = 1e30f, wby1 = -1e30f;
+  uint32_t spxy[PPT];                                 // OBJ: source-pixel coordinates of the slot as two halves (x | y << 16)
   bool any_cand = false;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
@@ -1440,30 +1530,74 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     lr[k] = t.lr; lf[k] = t.lf; lit[k] = fmaxf(t.lit, 0.f); Mi[k] = t.mi;
     valid[k] = t.lit >= 0.f; cand[k] = t.lit > 0.f; gok[k] = (t.mi & 0xFFFFu) != 0xFFFFu;
     any_cand |= cand[k];
-    spx[k] = spy[k] = 0.f;
+    spxy[k] = 0u;
     if (OBJ && inimg) {
       const float4 l = lut[pix];
-      spx[k] = (l.x + 1.f) * 0.5f * (float)R.W; spy[k] = (1.f - l.y) * 0.5f * (float)R.H;
-      if (valid[k]) { wbx0 = fminf(wbx0, spx[k]); wbx1 = fmaxf(wbx1, spx[k]); wby0 = fminf(wby0, spy[k]); wby1 = fmaxf(wby1, spy[k]); }
-    }
-  }
-  if (OBJ) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      wbx0 = fminf(wbx0, __shfl_xor(wbx0, d)); wbx1 = fmaxf(wbx1, __shfl_xor(wbx1, d));
-      wby0 = fminf(wby0, __shfl_xor(wby0, d)); wby1 = fmaxf(wby1, __shfl_xor(wby1, d));
+      const float sx = (l.x + 1.f) * 0.5f * (float)R.W, sy = (1.f - l.y) * 0.5f * (float)R.H;
+      spxy[k] = (uint32_t)__half_as_ushort(__float2half(sx)) | ((uint32_t)__half_as_ushort(__float2half(sy)) << 16);
     }
   }
 
   uint16_t* w_queue = queue + ((size_t)rwg * (RB / 64) + wave) * QREGION;
-  int qn = 0;
+  int qn = 0, qo = 0;                                  // plane-edge entries (front of the region), object-box entries (back)
   uint32_t* s_px = s_mem + R.n_qtiles * 2 + wave * WAVE_PIX;
   const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
   // frame rows are dword aligned (W % 4 == 0: launch precondition; other widths take the generic k_raster)
   const bool st_ok = lane * 4 < WAVE_PIX && st_x < R.W && st_y < R.H;
   const size_t st_off = ((size_t)st_y * R.W + st_x) * 3;
 
-  const bool wave_sky = !OBJ && !__ballot(any_cand);
+  // object masks (OBJ) are indexed by position in the render order (k_obj_setup)
+  const int n_blk = n_tiles * 4, blk = tile * 4 + __builtin_amdgcn_readfirstlane(wave);
+  // One vector load up front: lane l holds the mask of position e0 + l (a scalar load per env would sit in the same
+  // counter as the LDS reads of the env loop and stall them: measured +0.4 ms); per env two v_readlane.
+  static_assert(ENVS_PER_BLOCK <= 64, "one lane per env of the chunk");
+  uint32_t om_lo = 0u, om_hi = 0u;
+  if (OBJ && lane < e1 - e0) {
+    const unsigned long long v = R.objmask[(size_t)(e0 + lane) * n_blk + blk];
+    om_lo = (uint32_t)v; om_hi = (uint32_t)(v >> 32);
+  }
+  auto objmask_of = [&](int e) -> unsigned long long {
+    if (!OBJ) return 0ull;
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)om_hi, e - e0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)om_lo, e - e0);
+  };
+  // pixels of this block inside the screen boxes of the objects in `om` -> appended from the far end of the region
+  auto push_obj = [&](const int e, const uint32_t env, unsigned long long om, bool oedge[PPT]) __attribute__((always_inline)) {
+    const ObjBox* boxes = R.objbox + (size_t)env * DTSIM_MAX_OBJECTS;
+    // The coordinates are kept as halves (registers); their rounding (<= 0.25 px below 1024) is covered by widening the
+    // box: a pixel just outside a box may take the exact path for nothing, one inside always does.
+    float sx[PPT], sy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      uint32_t t = spxy[k];
+      asm volatile("" : "+v"(t));                    // unpack here, not once ahead of the env loop (8 registers)
+      sx[k] = __half2float(__ushort_as_half((unsigned short)(t & 0xFFFFu)));
+      sy[k] = __half2float(__ushort_as_half((unsigned short)(t >> 16)));
+    }
+    while (om) {                                     // wave-uniform
+      const ObjBox ob = boxes[__builtin_ctzll(om)];
+      om &= om - 1ull;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        if (valid[k] && sx[k] >= ob.bx0 - 0.3f && sx[k] <= ob.bx1 + 0.3f && sy[k] >= ob.by0 - 0.3f && sy[k] <= ob.by1 + 0.3f) oedge[k] = true;
+    }
+    bool any_oedge = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) any_oedge |= oedge[k];
+    if (__ballot(any_oedge)) {                       // wave-uniform (a pixel is in one list or the other: the region never overflows)
+      const uint32_t etag = (uint32_t)(e - e0) << 8;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const bool ek = oedge[k];
+        const unsigned long long mk = __ballot(ek);
+        if (ek) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
+        }
+        qo += __popcll(mk);
+      }
+    }
+  };
+  const bool wave_sky = !__ballot(any_cand);
   if (wave_sky) {
     // ---- all sky / border for every env: the lane's 12 bytes are the horizon colour pattern, masked where the
     // source pixel lies outside the rectilinear image.
@@ -1473,12 +1607,19 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     const uint32_t m0 = (vm.x & 0x00FFFFFFu) | (vm.y << 24), m1 = ((vm.y >> 8) & 0xFFFFu) | (vm.z << 16), m2 = ((vm.z >> 16) & 0xFFu) | (vm.w << 8);
     for (int e = e0; e < e1; ++e) {
       const EnvQ f = envq[e];
+      const unsigned long long om = objmask_of(e);
       if (st_ok) {
         uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)f.env * npix * 3 + st_off);
         d32[0] = f.sky[0] & m0; d32[1] = f.sky[1] & m1; d32[2] = f.sky[2] & m2;
       }
+      if (OBJ && om) {                               // mesh objects in front of the sky
+        bool oedge[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) oedge[k] = false;
+        push_obj(e, f.env, om, oedge);
+      }
     }
-    if (lane == 0) qcount[rwg * (RB / 64) + wave] = 0;
+    if (lane == 0) qcount[rwg * (RB / 64) + wave] = OBJ ? qo : 0;
   } else {
   typedef float f2 __attribute__((ext_vector_type(2)));
   static_assert(PPT % 2 == 0, "pixel slots are processed in pairs (packed fp32)");
@@ -1568,14 +1709,22 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
   // Clamping the coordinates into the padded grid (two v_med3 per pixel) is only needed when a hit of this block can
   // leave it: the block's farthest hit (cells, env-invariant) against the camera's distance to the border (per env).
   auto issue = [&](const EnvQ& f, QStage& st) __attribute__((always_inline)) {
+#if DT_Q_PRIO
+    __builtin_amdgcn_s_setprio(DT_Q_PRIO);           // a wavefront about to issue its quad loads goes first
+#endif
     if (f.reach > blk_reach) issue_t(f, st, std::false_type{});       // wave-uniform, scalar compare
     else issue_t(f, st, std::true_type{});
+#if DT_Q_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
-  auto finish = [&](const int e, const uint32_t env, const uint32_t hor_rgb, const QStage& st) __attribute__((always_inline)) -> U3 {   // e: position, env: frame
+  auto finish = [&](const int e, const uint32_t env, const uint32_t hor_rgb, const QStage& st, unsigned long long om) __attribute__((always_inline)) -> U3 {   // e: position, env: frame, om: object mask of the block (OBJ)
     U3 out{0u, 0u, 0u};
     uint32_t px[PPT];
-    bool edge[PPT];
+    bool edge[PPT], oedge[PPT];                      // oedge: inside a mesh object's screen box (OBJ)
     unsigned long long fastm[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) oedge[k] = false;
     const uint4* q = st.q;
     const f2* ax2 = st.ax2; const f2* az2 = st.az2;
     unsigned long long slow = 0ull;                  // lane masks live in SGPR pairs: predicate logic on the scalar unit
@@ -1649,19 +1798,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
       }
     }
 
-    if (OBJ) {
-      const ObjEnv oe = R.objenv[env];               // wave-uniform
-      if (oe.n_tris > 0 && wbx1 >= oe.bx0 && wbx0 <= oe.bx1 && wby1 >= oe.by0 && wby0 <= oe.by1) {
-        const ObjBox* boxes = R.objbox + (size_t)env * DTSIM_MAX_OBJECTS;
-        for (int o = 0; o < oe.n_obj; ++o) {
-          const ObjBox ob = boxes[o];                // wave-uniform
-          if (ob.count == 0 || wbx1 < ob.bx0 || wbx0 > ob.bx1 || wby1 < ob.by0 || wby0 > ob.by1) continue;
-#pragma unroll
-          for (int k = 0; k < PPT; ++k)
-            if (valid[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
-        }
-      }
-    }
+    if (OBJ && om) push_obj(e, env, om, oedge);   // wave-uniform: some object's screen box meets this block
 
     if (any_invalid) {                               // wave-uniform, rare: source pixels outside the rectilinear image are 0
 #pragma unroll
@@ -1675,9 +1812,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
 
     bool any_edge = false;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) any_edge |= edge[k];
+    for (int k = 0; k < PPT; ++k) { edge[k] &= !oedge[k]; any_edge |= edge[k]; }
+    const uint32_t etag = (uint32_t)(e - e0) << 8;
     if (__ballot(any_edge)) {                          // wave-uniform
-      const uint32_t etag = (uint32_t)(e - e0) << 8;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const bool ek = edge[k];
@@ -1700,12 +1837,12 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
       const uint32_t hor_a = fa.hor_rgb, hor_b = fb.hor_rgb, env_a = fa.env, env_b = fb.env;
       issue(fb, sb);                                 // env e+1 (a harmless repeat of the last env past the end)
       fa = envq[min(e + 2, e1 - 1)];
-      const U3 oa = finish(e, env_a, hor_a, sa);
+      const U3 oa = finish(e, env_a, hor_a, sa, objmask_of(e));
       store(env_a, oa);
       if (e + 1 < e1) {
         issue(fa, sa);                               // env e+2
         fb = envq[min(e + 3, e1 - 1)];
-        const U3 ob = finish(e + 1, env_b, hor_b, sb);
+        const U3 ob = finish(e + 1, env_b, hor_b, sb, objmask_of(e + 1));
         store(env_b, ob);
       }
     }
@@ -1723,7 +1860,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
     issue(f, sa);
     uint32_t hor = f.hor_rgb, env = f.env, env_prev;
     f = envq[min(e0 + 1, e1 - 1)];
-    U3 held = finish(e0, env, hor, sa);
+    U3 held = finish(e0, env, hor, sa, objmask_of(e0));
     for (int e = e0 + 1; e < e1; ++e) {
       env_prev = env; hor = f.hor_rgb; env = f.env;
 #ifdef DT_Q_TIMING
@@ -1737,7 +1874,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
       __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): all four quad records (and the store) have landed
       const unsigned long long t2 = TSTAMP();
 #endif
-      held = finish(e, env, hor, sa);
+      held = finish(e, env, hor, sa, objmask_of(e));
 #ifdef DT_Q_TIMING
       const unsigned long long t3 = TSTAMP();
       t_issue += t1 - t0; t_mem += t2 - t1; t_filt += t3 - t2; t_n += 1;
@@ -1752,17 +1889,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
 #endif
   }
 #endif
-  if (lane == 0) qcount[rwg * (RB / 64) + wave] = qn;
-  if (!OBJ && qn > 0) {
+  if (lane == 0) qcount[rwg * (RB / 64) + wave] = OBJ ? qo : qn;
+  if (qn > 0) {
     // exact path for this wavefront's own edge pixels, right here (the frame stores of the env loop are ordered
     // before the byte patches: same wavefront, same addresses)
     __builtin_amdgcn_s_waitcnt(0);                 // queue stores have left the wavefront
     resolve_region<S256>(R, cams, envq, pixtab, samptab, qtex, s_qt, s_px, w_queue, qn, e0, tile_x0, wave_y0, lane);
   }
   }
-  if (OBJ) {   // mesh objects: k_resolve<true> drains the regions -- work items for it
+  if (OBJ) {   // mesh objects: k_resolve<true> drains the object-box entries (back of the regions) -- work items for it
     __shared__ int s_nb[RB / 64];
-    if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
+    if (lane == 0) s_nb[wave] = (qo + 63) >> 6;
     __syncthreads();
     if (tid == 0) {
       int nb = 0;
@@ -1782,7 +1919,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_Q_WAVES, 
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
 template <bool OBJ>
 __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
-                                                const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount) {
+                                                const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount, const int back,
+                                                const EnvQ* __restrict__ envq) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
   const int tid = threadIdx.x;
@@ -1813,12 +1951,17 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
       const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
+      // queue entries carry positions in the render order (e0 + el); with k_env_sort active (envq given) the env behind
+      // a position is EnvQ.env, otherwise the position itself
+      auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };
       {  // the chunk's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
         static_assert(ENVS_PER_BLOCK * sizeof(EnvCam) == 64 * 64, "one 64-byte slice per lane");
         const int ne = min(ENVS_PER_BLOCK, R.N - e0);
-        const uint4* src = reinterpret_cast<const uint4*>(cams + e0) + lane * 4;
         uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
-        if (lane * 64 < ne * (int)sizeof(EnvCam)) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
+        if (lane * 64 < ne * (int)sizeof(EnvCam)) {
+          const uint4* src = reinterpret_cast<const uint4*>(cams + env_at(e0 + (lane >> 1))) + (lane & 1) * 4;
+          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
       }
       const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
       static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
@@ -1834,7 +1977,8 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
         const uint16_t* w_queue = queue + ((size_t)rwg * 4 + reg) * QREGION;
         const int wave_y0 = tile_y0 + reg * (WAVE_PIX / WAVE_W);
         const bool have = q0 + lane < n;
-        const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
+        // back: the entries were appended from the far end of the region (k_raster_q<OBJ>: object-box pixels)
+        const uint32_t ent = have ? w_queue[back ? QREGION - 1 - (q0 + lane) : q0 + lane] : 0u;
         const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
         const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;      // entries only exist for in-image pixels
         const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
@@ -1853,7 +1997,8 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
           for (int ee = el_lo; ee <= el_hi; ++ee) {  // wave-uniform
             const bool mine = el == ee;
             if (!__ballot(mine)) continue;
-            const ObjEnv oe = R.objenv[e0 + ee];
+            const int env_ee = __builtin_amdgcn_readfirstlane(env_at(e0 + ee));
+            const ObjEnv oe = R.objenv[env_ee];
             if (oe.n_tris == 0) continue;
             float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
 #pragma unroll
@@ -1863,13 +2008,13 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
             }
             if (oe.bx0 > x1 || oe.bx1 < x0 || oe.by0 > y1 || oe.by1 < y0) continue;
             if (R.dbg && lane == 0) atomicAdd(R.dbg + 0, 1);                   // (batch, env) pairs that look at objects
-            const ScreenTri* base = R.stris + (size_t)(e0 + ee) * R.max_tris;
+            const ScreenTri* base = R.stris + (size_t)env_ee * R.max_tris;
             // object screen boxes: one vector load (lane o <-> object o)
             static_assert(DTSIM_MAX_OBJECTS <= 64, "one lane per object");
             int ob_first = 0, ob_count = 0;
             bool ob_hit = false;
             if (lane < oe.n_obj) {
-              const ObjBox ob = R.objbox[(size_t)(e0 + ee) * DTSIM_MAX_OBJECTS + lane];
+              const ObjBox ob = R.objbox[(size_t)env_ee * DTSIM_MAX_OBJECTS + lane];
               ob_first = ob.first; ob_count = ob.count;
               ob_hit = ob.count > 0 && !(ob.bx0 > x1 || ob.bx1 < x0 || ob.by0 > y1 || ob.by1 < y0);
             }
@@ -1915,9 +2060,10 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
         if (have) {
           const EnvCam c = w_cams[el];
           const MapU m = map_u(R.maps[c.map_id]);
-          const ScreenTri* tris = OBJ ? R.stris + (size_t)(e0 + el) * R.max_tris : nullptr;
+          const int env_l = env_at(e0 + el);
+          const ScreenTri* tris = OBJ ? R.stris + (size_t)env_l * R.max_tris : nullptr;
           const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
-          uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + pix) * 3;
+          uint8_t* dst = R.frames + ((size_t)env_l * npix + pix) * 3;
           dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
       }
@@ -1934,13 +2080,16 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0;
   const bool obj = R.max_tris > 0;
-  // render order (k_env_sort): only the quad pipeline without mesh objects indexes by position (k_resolve<true> and
-  // k_obj_setup address envs directly)
-  int32_t* pos = (quad && !obj && R.envpos) ? R.envpos : nullptr;
+  // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
+  // from EnvQ.env
+  int32_t* pos = (quad && R.envpos) ? R.envpos : nullptr;
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos);
-  if (R.max_tris > 0) hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams);
+  if (R.max_tris > 0) {
+    hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
+    hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams, pos);
+  }
   (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
@@ -1970,9 +2119,11 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   if (quad && !obj) {
     // the exact path ran inside k_raster_q (resolve_region)
   } else if (!R.no_msaa) {
+    // generic raster: every queued pixel; k_raster_q<OBJ>: the pixels inside mesh-object screen boxes (the plane-only
+    // edge pixels were resolved inside the raster wavefronts)
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
-    if (obj) hipLaunchKernelGGL(k_resolve<true>, rgrid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount);
-    else hipLaunchKernelGGL(k_resolve<false>, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    if (obj) hipLaunchKernelGGL(k_resolve<true>, rgrid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount, quad ? 1 : 0, pos ? envq : (const EnvQ*)nullptr);
+    else hipLaunchKernelGGL(k_resolve<false>, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount, 0, (const EnvQ*)nullptr);
   }
 }

@@ -185,6 +185,32 @@ def test_real_assets_match_oracle(W, H, distortion, dr, steps):
     sim.close()
 
 
+@pytest.mark.parametrize("distortion", [False, True])
+def test_file_textures_without_objects_match_oracle(distortion):
+    """The asset tree's 128 x 128 tile images on a map without mesh objects: the quad-layout raster with the generic
+    texture size (not the S = 256 specialisation) and the exact path inside the raster wavefronts."""
+    import copy
+    lib = assets.AssetLibrary(ASSETS)
+    md = copy.deepcopy(lib.map_data("test_town"))
+    md["objects"] = []
+    W, H, N = 640, 480, 6
+    sim = BatchedSimulator("test_town_bare", N, map_data=md, asset_root=ASSETS, camera_width=W, camera_height=H,
+                           distortion=distortion, domain_rand=False, seed=11, max_steps=100000)
+    sim.step(np.random.default_rng(5).uniform(0.2, 0.8, (6, N, 2)).astype(np.float32), n_steps=6)
+    sim.render()
+    frames = sim.frames_host()
+    om = osim.OracleMap(md, {"*": (assets.get_mesh("*").min_coords, assets.get_mesh("*").max_coords)})
+    kinds = {t["kind"] for t in om.grid if t is not None}
+    assert {lib.tile_texture(k).shape[0] for k in kinds} == {128}
+    scene = raster.Scene(om, {k: lib.tile_texture(k) for k in kinds}, {"*": assets.get_mesh("*")})
+    rmap = pdist.distortion_maps(W, H) if distortion else None
+    for e in range(N):
+        cam = _camera(sim, e, W, H, False)
+        s = _stats(frames[e], raster.render_obs(cam, scene, "pixel", rmap))
+        assert s["frac_gt1"] <= 1e-3 and s["frac_gt2"] <= 5e-4 and s["mean"] <= 0.02, (e, s)
+    sim.close()
+
+
 def test_traffic_light_pattern_follows_the_reference_clock():
     """TrafficLightObj.step on the device vs the pattern sequence recorded from the reference's own code
     (tests/golden/ref_trafficlight.npz), including frame_skip sub-steps; the clock survives env resets."""
