@@ -618,7 +618,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     HIPCHK(hipMalloc(&h->d_objenv, sizeof(ObjEnv) * (size_t)h->N));
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
-    HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)h->N * n_blk * 8));
+    HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
   }
   h->n_tilerecs = (int)trecs.size();
   h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
@@ -825,7 +825,8 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox;
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
-  R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
+  R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
+  R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
@@ -846,7 +847,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     dt_launch_render(h->stream, h->A, R);
   }
   HIPCHK(hipGetLastError());
-  if (getenv("DTSIM_DEBUG_QUEUE")) {   // profiling aid: how many pixels took the exact MSAA path
+  if (getenv("DTSIM_DEBUG_QUEUE") || getenv("DTSIM_DEBUG_TIMERS")) {   // profiling aid: how many pixels took the exact MSAA path (DEBUG_TIMERS: without the in-kernel counters)
     HIPCHK(hipStreamSynchronize(h->stream));
     {  // phase timers of the DT_Q_TIMING build variant (zero otherwise)
       unsigned long long tc[4];
@@ -855,6 +856,12 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
       if (tc[3]) fprintf(stderr, "[dtsim] k_raster_q phase cycles per wavefront iteration: issue %.0f, wait for quads %.0f, filter+slow+transpose %.0f  (%llu iterations)\n",
                          (double)tc[0] / tc[3], (double)tc[1] / tc[3], (double)tc[2] / tc[3], tc[3]);
       HIPCHK(hipMemset(dbgp, 0, sizeof tc));
+      unsigned long long tr[9];                      // DT_RES_TIMING build variant: k_resolve phase cycles
+      HIPCHK(hipMemcpy(tr, dbgp + 64, sizeof tr, hipMemcpyDeviceToHost));
+      if (tr[8]) fprintf(stderr, "[dtsim] k_resolve cycles per wavefront: total %.0f = item setup %.0f + entry load %.0f + mesh stream %.0f + z-buffer %.0f + shade %.0f; "
+                         "%.1f items, %.1f batches per wavefront (%llu wavefronts)\n", (double)tr[7] / tr[8], (double)tr[0] / tr[8], (double)tr[1] / tr[8], (double)tr[2] / tr[8],
+                         (double)tr[3] / tr[8], (double)tr[4] / tr[8], (double)tr[6] / tr[8], (double)tr[5] / tr[8], tr[8]);
+      HIPCHK(hipMemset(dbgp + 64, 0, sizeof tr));
     }
     const size_t npix = (size_t)R.W * R.H;
     const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);

@@ -170,7 +170,9 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 #ifndef DT_ENVS_PER_BLOCK
 #define DT_ENVS_PER_BLOCK 32                 // envs a raster workgroup loops over
 #endif
+#ifndef DT_ITEM_B
 #define DT_ITEM_B 8                          // 64-entry edge batches per k_resolve work item
+#endif
 #define DT_ITEMS_PER_WG (4 * (DT_PPT * DT_ENVS_PER_BLOCK) / DT_ITEM_B) // worst case: 4 regions x (64*PPT px x envs / 64) batches
 // Quad-layout tile textures for the one-ray fast path (render.hip k_raster_q): per (texture, tile angle) pair one
 // block of S x S records of 16 bytes, record (x0, z0) = the four GL_LINEAR taps of the pre-rotated tile texture around
@@ -206,6 +208,7 @@ struct RenderParams {
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
   float* blockbox;              // [raster tiles * 4][4] source-pixel bounding box of each raster wavefront block (k_blk_setup)
   unsigned long long* objmask;  // [N][raster tiles * 4] objects whose screen box meets the block (bit o), written by k_obj_setup
+  uint2* objrange;              // [DTSIM_MAX_MAPS][DTSIM_MAX_OBJECTS] (first, count) of each object's triangles in its map's order (k_blk_setup)
   uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
   int32_t* qcount;              // [workgroups][4]
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null

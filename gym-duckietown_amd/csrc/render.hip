@@ -53,7 +53,10 @@
 #define SLOT_Y(k, l) (((k) * 64 + (l)) / WAVE_W)
 #define WAVE_PIX (64 * PPT)
 #define ENVS_PER_BLOCK DT_ENVS_PER_BLOCK
-#define TRI_CAP 128       // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
+#ifndef DT_TRI_CAP
+#define DT_TRI_CAP 128
+#endif
+#define TRI_CAP DT_TRI_CAP  // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
@@ -302,6 +305,19 @@ __global__ __launch_bounds__(RB) void k_blk_setup(RenderParams R, const float4* 
     y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
   }
   if (lane == 0) blockbox[tile * 4 + wave] = make_float4(x0, x1, y0, y1);
+  if (blockIdx.x == 0) {   // triangle range of every object in its map's triangle order (static; k_resolve<true> streams by it)
+    for (int i = threadIdx.x; i < R.n_maps * DTSIM_MAX_OBJECTS; i += RB) {
+      const int mi = i / DTSIM_MAX_OBJECTS, o = i % DTSIM_MAX_OBJECTS;
+      const RenderMapDev m = R.maps[mi];
+      uint2 fc = make_uint2(0u, 0u);
+      if (o < m.n_obj) {
+        for (int k = 0; k < o; ++k) { const int mid = R.objs[m.obj_off + k].mesh_id; fc.x += mid >= 0 ? (uint32_t)R.meshes[mid].n_tris : 0u; }
+        const int mid = R.objs[m.obj_off + o].mesh_id;
+        fc.y = mid >= 0 ? (uint32_t)R.meshes[mid].n_tris : 0u;
+      }
+      R.objrange[i] = fc;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
@@ -619,13 +635,18 @@ template <typename Tri>
 __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  // The barycentrics are affine in the sample position: value at the pixel centre + gradient * sample offset
+  // (b0(q) = ((x1-qx)(y2-qy) - (x2-qx)(y1-qy)) / area: d/dqx = (y1-y2)/area, d/dqy = (x2-x1)/area; b1 likewise).
+  const float ia = st.inv_area;
+  const float e0x = st.sx[0] - pcx, e0y = st.sy[0] - pcy, e1x = st.sx[1] - pcx, e1y = st.sy[1] - pcy, e2x = st.sx[2] - pcx, e2y = st.sy[2] - pcy;
+  const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
+  const float g0x = (e1y - e2y) * ia, g0y = (e2x - e1x) * ia, g1x = (e2y - e0y) * ia, g1y = (e0x - e2x) * ia;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const float qx = pcx + ox[s], qy = pcy + oy[s];
-    const float b0 = ((st.sx[1] - qx) * (st.sy[2] - qy) - (st.sx[2] - qx) * (st.sy[1] - qy)) * st.inv_area;
-    const float b1 = ((st.sx[2] - qx) * (st.sy[0] - qy) - (st.sx[0] - qx) * (st.sy[2] - qy)) * st.inv_area;
+    const float b0 = fmaf(g0y, oy[s], fmaf(g0x, ox[s], b0c));
+    const float b1 = fmaf(g1y, oy[s], fmaf(g1x, ox[s], b1c));
     const float b2 = 1.f - b0 - b1;
-    if (b0 >= 0.f && b1 >= 0.f && b2 >= 0.f) {
+    if (fminf(fminf(b0, b1), b2) >= 0.f) {
       const float d = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
       // depth func LESS; equal depth: the earlier triangle in draw order keeps the sample
       if (d >= NEAR_Z && d <= FAR_Z && (d < zbest[s] || (d == zbest[s] && st.index < tbest[s]))) { zbest[s] = d; tbest[s] = st.index; }
@@ -688,7 +709,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
     // its own mask: the wavefront runs max-over-lanes(candidates) passes of the 4-sample test, with a different
     // triangle per lane, instead of one pass per staged triangle (a 64-pixel batch is a thin strip of the object:
     // most staged triangles hold only a few of its pixels).
-    static_assert(TRI_CAP == 128, "four 32-bit candidate masks");
+    static_assert(TRI_CAP <= 128 && TRI_CAP % 32 == 0, "up to four 32-bit candidate masks");
     uint32_t cand[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1917,8 +1938,13 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
+#ifdef DT_RES_WAVES
+#define RES_ATTR __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES, DT_RES_WAVES)))
+#else
+#define RES_ATTR
+#endif
 template <bool OBJ>
-__global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
+__global__ __launch_bounds__(RB) RES_ATTR void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
                                                 const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount, const int back,
                                                 const EnvQ* __restrict__ envq) {
   extern __shared__ uint32_t s_mem[];
@@ -1936,6 +1962,15 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
   EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * ENVS_PER_BLOCK;                    // wavefront-local
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * ENVS_PER_BLOCK * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
   const int n_items = R.work[0];                     // written by the raster launch
+#ifdef DT_RES_TIMING
+  unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // item setup, entry load, mesh stream, z-buffer, shade, batches, items, total
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#define RT(i, a, b) tm[i] += (b) - (a)
+#define RNOW() __builtin_readcyclecounter()
+#else
+#define RT(i, a, b)
+#define RNOW() 0ull
+#endif
   // One atomic buys `grab` items, taken with stride n_grabs through the list: same-address atomics are
   // serialised by the L2 (~0.2 ms per 100 k of them), and the stride keeps the consecutive items of one hot
   // raster workgroup on different wavefronts.  Granularity: ~4 grabs per resident wavefront, <= GRAB_MAX items.
@@ -1947,6 +1982,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= n_grabs) break;
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
+      const unsigned long long t_i0 = RNOW();
       const uint32_t item = R.items[it];
       const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
@@ -1965,12 +2001,24 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
       }
       const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
       static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
+      // object masks of the chunk's envs for the four blocks of this raster tile: lane l <-> position e0 + l
+      uint32_t mk_lo[4] = {0u, 0u, 0u, 0u}, mk_hi[4] = {0u, 0u, 0u, 0u};
+      if (OBJ && lane < min(ENVS_PER_BLOCK, R.N - e0)) {
+        const unsigned long long* mp = R.objmask + ((size_t)(e0 + lane) * n_tiles + tile) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const unsigned long long v = mp[r]; mk_lo[r] = (uint32_t)v; mk_hi[r] = (uint32_t)(v >> 32); }
+      }
       int rn[4], rb[5];
       rb[0] = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { rn[r] = qcount[rwg * 4 + r]; rb[r + 1] = rb[r] + ((rn[r] + 63) >> 6); }
       const int b_end = min(rb[4], (part + 1) * ITEM_B);
+#ifdef DT_RES_TIMING
+      __builtin_amdgcn_s_waitcnt(0);
+      RT(0, t_i0, RNOW()); tm[6] += 1;
+#endif
       for (int b = part * ITEM_B; b < b_end; ++b) {  // wave-uniform
+        const unsigned long long t_b0 = RNOW();
         const int reg = (b >= rb[1]) + (b >= rb[2]) + (b >= rb[3]);
         const int q0 = (b - (reg == 0 ? rb[0] : reg == 1 ? rb[1] : reg == 2 ? rb[2] : rb[3])) * 64;
         const int n = reg == 0 ? rn[0] : reg == 1 ? rn[1] : reg == 2 ? rn[2] : rn[3];
@@ -1985,6 +2033,12 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
         const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
         float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
         int tbest[4] = {-1, -1, -1, -1};
+#ifdef DT_RES_TIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t_b1 = RNOW();
+        RT(1, t_b0, t_b1); tm[5] += 1;
+        unsigned long long t_z = 0;
+#endif
         if (OBJ) {
           // ---- mesh pass.  Queue entries are in env order, so these 64 pixels belong to a few
           // consecutive envs.  Per env, and per object whose screen box meets the env's pixels here:
@@ -1997,29 +2051,22 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
           for (int ee = el_lo; ee <= el_hi; ++ee) {  // wave-uniform
             const bool mine = el == ee;
             if (!__ballot(mine)) continue;
+            // the objects whose screen box meets this raster block in this env (k_obj_setup's mask: no per-pair box loads)
+            const uint32_t sel_lo = reg == 0 ? mk_lo[0] : reg == 1 ? mk_lo[1] : reg == 2 ? mk_lo[2] : mk_lo[3];
+            const uint32_t sel_hi = reg == 0 ? mk_hi[0] : reg == 1 ? mk_hi[1] : reg == 2 ? mk_hi[2] : mk_hi[3];
+            unsigned long long hm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sel_hi, ee) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)sel_lo, ee);   // wave-uniform
+            if (!hm) continue;
             const int env_ee = __builtin_amdgcn_readfirstlane(env_at(e0 + ee));
-            const ObjEnv oe = R.objenv[env_ee];
-            if (oe.n_tris == 0) continue;
             float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
               x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
               y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
             }
-            if (oe.bx0 > x1 || oe.bx1 < x0 || oe.by0 > y1 || oe.by1 < y0) continue;
-            if (R.dbg && lane == 0) atomicAdd(R.dbg + 0, 1);                   // (batch, env) pairs that look at objects
+            if (R.dbg && lane == 0) { atomicAdd(R.dbg + 0, 1); atomicAdd(R.dbg + 1, __popcll(hm)); }   // (batch, env) pairs that look at objects, objects streamed
             const ScreenTri* base = R.stris + (size_t)env_ee * R.max_tris;
-            // object screen boxes: one vector load (lane o <-> object o)
-            static_assert(DTSIM_MAX_OBJECTS <= 64, "one lane per object");
-            int ob_first = 0, ob_count = 0;
-            bool ob_hit = false;
-            if (lane < oe.n_obj) {
-              const ObjBox ob = R.objbox[(size_t)env_ee * DTSIM_MAX_OBJECTS + lane];
-              ob_first = ob.first; ob_count = ob.count;
-              ob_hit = ob.count > 0 && !(ob.bx0 > x1 || ob.bx1 < x0 || ob.by0 > y1 || ob.by1 < y0);
-            }
-            unsigned long long hm = __ballot(ob_hit);  // wave-uniform
-            if (R.dbg && lane == 0) atomicAdd(R.dbg + 1, __popcll(hm));
+            const uint2* rng = R.objrange + (size_t)__builtin_amdgcn_readfirstlane(w_cams[ee].map_id) * DTSIM_MAX_OBJECTS;
             // flat sequence of 64-triangle chunks over the hit objects; the coverage half (64 B) of the
             // next chunk's ScreenTri is loaded while the current one is filtered and staged
             int first = 0, count = 0, t0 = 0;
@@ -2027,9 +2074,9 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
               t0 += 64;
               while (t0 >= count) {
                 if (!hm) return false;
-                const int o = __builtin_ctzll(hm);
+                const uint2 fc = rng[__builtin_ctzll(hm)];   // wave-uniform
                 hm &= hm - 1ull;
-                first = __shfl(ob_first, o); count = __shfl(ob_count, o); t0 = 0;
+                first = (int)fc.x; count = (int)fc.y; t0 = 0;
               }
               return true;
             };
@@ -2050,13 +2097,23 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
               if (pass) w_tris[fill + __popcll(pm & ((1ull << lane) - 1ull))] = cur;
               fill += __popcll(pm);
               if (fill > TRI_CAP - 64 || (!has_next && fill > 0)) {   // chunk full, or the last one: z-buffer it
+#ifdef DT_RES_TIMING
+                const unsigned long long t_z0 = RNOW();
+#endif
                 zbuffer_chunk(w_tris, fill, mine, lane, pcx, pcy, zbest, tbest, R.dbg);
+#ifdef DT_RES_TIMING
+                t_z += RNOW() - t_z0;
+#endif
                 fill = 0;
               }
               cur = nxt; cur_in = nxt_in; more = has_next;
             }
           }
         }
+#ifdef DT_RES_TIMING
+        const unsigned long long t_b2 = RNOW();
+        tm[2] += (t_b2 - t_b1) - t_z; tm[3] += t_z;
+#endif
         if (have) {
           const EnvCam c = w_cams[el];
           const MapU m = map_u(R.maps[c.map_id]);
@@ -2064,11 +2121,29 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
           const ScreenTri* tris = OBJ ? R.stris + (size_t)env_l * R.max_tris : nullptr;
           const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
           uint8_t* dst = R.frames + ((size_t)env_l * npix + pix) * 3;
+#if defined(DT_RES_ABL_NOSTORE)
+          if (v == 0x12345678u) dst[0] = 1;
+#elif defined(DT_RES_ABL_ONESTORE)
+          *reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)3) = v;
+#else
           dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+#endif
         }
+#ifdef DT_RES_TIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        RT(4, t_b2, RNOW());
+#endif
       }
     }
   }
+#ifdef DT_RES_TIMING
+  tm[7] = __builtin_readcyclecounter() - t_begin;
+  if (lane == 0) {
+    unsigned long long* tc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.dump) + 1024 + 64);
+    for (int i = 0; i < 8; ++i) atomicAdd(tc + i, tm[i]);
+    atomicAdd(tc + 8, 1ull);
+  }
+#endif
 }
 
 }  // namespace

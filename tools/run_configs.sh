@@ -21,3 +21,14 @@ for l in open(f"gpurun_out/{tag}_configs.json"):
     except Exception as e:
         print("bad line:", l[:120], e)
 PY
+# per-kernel durations of the two object configs (rocprofv3 kernel trace of the same bench commands)
+export TMPDIR=/tmp
+KOUT=$PWD/gpurun_out/${TAG}_configs_kernels.txt
+: > $KOUT
+for c in c4 c5; do
+  D=/tmp/cfgtrace_$c; rm -rf $D; mkdir -p $D
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $D -o t -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 10 --warmup 3 --cpu-steps 0 > $D/log 2>&1)
+  echo "== bench.py --config $c --steps 10 --warmup 3 (N = 4096, 640x480 + fisheye): kernels of the timed loop" >> $KOUT
+  python tools/rocpd_summary.py "$D/*.db" | grep calls | head -8 | sed 's/^ *//' | cut -c1-150 >> $KOUT
+done
+cat $KOUT
