@@ -101,6 +101,7 @@ struct dtsim {
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
   uint32_t* d_items = nullptr;
+  uint16_t* d_qend = nullptr;
   dtsim_reset_sampler* d_sampler = nullptr;   // device copy when a reset sampler is installed
   int map_w[DTSIM_MAX_MAPS] = {0}, map_h[DTSIM_MAX_MAPS] = {0};
   int32_t* d_obs_tab = nullptr;   // dtsim_observe resampling tables (cached per output size)
@@ -250,6 +251,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
       if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * DT_ITEMS_PER_WG * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_qend, n_wg * 4 * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
     (void)hipMemset((char*)h->d_pixtab + (size_t)cfg->cam_height * cfg->cam_width * 64, 0, 2048);
@@ -273,7 +275,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -830,7 +832,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
-  R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items;
+  R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items; R.qend = h->d_qend;
   if (getenv("DTSIM_DEBUG_QUEUE")) {
     R.dbg = h->d_qcount + n_wg_ * 4;
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
@@ -856,11 +858,13 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
       if (tc[3]) fprintf(stderr, "[dtsim] k_raster_q phase cycles per wavefront iteration: issue %.0f, wait for quads %.0f, filter+slow+transpose %.0f  (%llu iterations)\n",
                          (double)tc[0] / tc[3], (double)tc[1] / tc[3], (double)tc[2] / tc[3], tc[3]);
       HIPCHK(hipMemset(dbgp, 0, sizeof tc));
-      unsigned long long tr[9];                      // DT_RES_TIMING build variant: k_resolve phase cycles
+      unsigned long long tr[13];                     // DT_RES_TIMING build variant: k_resolve phase cycles
       HIPCHK(hipMemcpy(tr, dbgp + 64, sizeof tr, hipMemcpyDeviceToHost));
       if (tr[8]) fprintf(stderr, "[dtsim] k_resolve cycles per wavefront: total %.0f = item setup %.0f + entry load %.0f + mesh stream %.0f + z-buffer %.0f + shade %.0f; "
                          "%.1f items, %.1f batches per wavefront (%llu wavefronts)\n", (double)tr[7] / tr[8], (double)tr[0] / tr[8], (double)tr[1] / tr[8], (double)tr[2] / tr[8],
                          (double)tr[3] / tr[8], (double)tr[4] / tr[8], (double)tr[6] / tr[8], (double)tr[5] / tr[8], tr[8]);
+      if (tr[8]) fprintf(stderr, "[dtsim] k_resolve: longest wavefront %llu, longest batch %llu cycles; %llu (batch, env) pairs with objects in %llu batches, at most %llu in one batch\n",
+                         tr[9], tr[10], tr[11], tr[5], tr[12]);
       HIPCHK(hipMemset(dbgp + 64, 0, sizeof tr));
     }
     const size_t npix = (size_t)R.W * R.H;

@@ -211,6 +211,7 @@ struct RenderParams {
   uint2* objrange;              // [DTSIM_MAX_MAPS][DTSIM_MAX_OBJECTS] (first, count) of each object's triangles in its map's order (k_blk_setup)
   uint16_t* queue;              // MSAA edge-pixel queue regions, [workgroups][4][256*16]
   int32_t* qcount;              // [workgroups][4]
+  uint16_t* qend;               // [workgroups][4][DT_ENVS_PER_BLOCK] queue fill of each region after each env of the chunk (mesh-object renders)
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
   int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor; zeroed per render
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part

@@ -622,47 +622,52 @@ __device__ inline void shade(const EnvCam& c, const MapU& m, const RenderParams&
 }
 
 
-// z-buffer one mesh triangle against the 4 samples of the pixel centred at (pcx, pcy) px.
+// z-buffer one mesh triangle against the 4 samples of the pixel centred at (pcx, pcy) px.  Depth is kept as
+// w = 1 / depth (larger = nearer; 0 = nothing yet): barycentrics and w are affine in the sample position, so a triangle
+// costs one set-up at the pixel centre + two fused multiply-adds per quantity and sample, and no division.
 template <typename Tri>
-__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]);
+__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float wbest[4], int tbest[4]);
 template <typename Tri>
-__device__ inline void test_tri(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
+__device__ inline void test_tri(const Tri& st, float pcx, float pcy, float wbest[4], int tbest[4]) {
   if (pcx < st.bx0 || pcx > st.bx1 || pcy < st.by0 || pcy > st.by1) return;
-  test_tri_inside(st, pcx, pcy, zbest, tbest);
+  test_tri_inside(st, pcx, pcy, wbest, tbest);
 }
 // ... the pixel centre is already known to lie in the triangle's (padded) screen box
 template <typename Tri>
-__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float zbest[4], int tbest[4]) {
+__device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float wbest[4], int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
   const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
-  // The barycentrics are affine in the sample position: value at the pixel centre + gradient * sample offset
-  // (b0(q) = ((x1-qx)(y2-qy) - (x2-qx)(y1-qy)) / area: d/dqx = (y1-y2)/area, d/dqy = (x2-x1)/area; b1 likewise).
+  // b0(q) = ((x1-qx)(y2-qy) - (x2-qx)(y1-qy)) / area: d/dqx = (y1-y2)/area, d/dqy = (x2-x1)/area; b1 likewise;
+  // w(q) = iw2 + b0 (iw0 - iw2) + b1 (iw1 - iw2)
   const float ia = st.inv_area;
   const float e0x = st.sx[0] - pcx, e0y = st.sy[0] - pcy, e1x = st.sx[1] - pcx, e1y = st.sy[1] - pcy, e2x = st.sx[2] - pcx, e2y = st.sy[2] - pcy;
   const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
   const float g0x = (e1y - e2y) * ia, g0y = (e2x - e1x) * ia, g1x = (e2y - e0y) * ia, g1y = (e0x - e2x) * ia;
+  const float d0 = st.iw[0] - st.iw[2], d1 = st.iw[1] - st.iw[2];
+  const float wc = fmaf(b1c, d1, fmaf(b0c, d0, st.iw[2]));
+  const float gwx = fmaf(g1x, d1, g0x * d0), gwy = fmaf(g1y, d1, g0y * d0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const float b0 = fmaf(g0y, oy[s], fmaf(g0x, ox[s], b0c));
     const float b1 = fmaf(g1y, oy[s], fmaf(g1x, ox[s], b1c));
     const float b2 = 1.f - b0 - b1;
-    if (fminf(fminf(b0, b1), b2) >= 0.f) {
-      const float d = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
-      // depth func LESS; equal depth: the earlier triangle in draw order keeps the sample
-      if (d >= NEAR_Z && d <= FAR_Z && (d < zbest[s] || (d == zbest[s] && st.index < tbest[s]))) { zbest[s] = d; tbest[s] = st.index; }
-    }
+    const float w = fmaf(gwy, oy[s], fmaf(gwx, ox[s], wc));
+    // depth func LESS within [near, far]; equal depth: the earlier triangle in draw order keeps the sample
+    const bool in = fminf(fminf(b0, b1), b2) >= 0.f && w <= 1.f / NEAR_Z && w >= 1.f / FAR_Z;
+    if (in && (w > wbest[s] || (w == wbest[s] && st.index < tbest[s]))) { wbest[s] = w; tbest[s] = st.index; }
   }
 }
 
 // z-buffer the `fill` staged triangles of the wavefront-local LDS chunk against the pixels of the
 // lanes with `mine` set.  Two schedules, picked per call from a cost estimate (wave-uniform):
-//   pixel-parallel    every `mine` lane walks all staged triangles (dense blocks: many pixels, few tris);
+//   pixel-parallel    every `mine` lane collects the staged triangles whose box holds its pixel, then walks its own
+//                     list (dense blocks: many pixels);
 //   triangle-parallel for each `mine` pixel in turn, the 64 lanes test 64 staged triangles at once and
 //                     the per-sample winners are reduced across the wavefront (a handful of pixels of a
 //                     small / distant object, where the pixel-parallel loop would idle most lanes).
 // Depth func LESS with the draw-order tie break, identical in both schedules.
 __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, int lane, float pcx, float pcy,
-                                     float zbest[4], int tbest[4], int32_t* dbg) {
+                                     float wbest[4], int tbest[4], int32_t* dbg) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -680,26 +685,19 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
       const int src = __builtin_ctzll(todo);
       todo &= todo - 1ull;
       const float qx = __shfl(pcx, src), qy = __shfl(pcy, src);
-      float zb[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+      float wb[4] = {0.f, 0.f, 0.f, 0.f};
       int tb[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-      for (int k = lane; k < fill; k += 64) {
-        int tl[4] = {-1, -1, -1, -1};
-        float zl[4] = {zb[0], zb[1], zb[2], zb[3]};
-        test_tri(w_tris[k], qx, qy, zl, tl);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (tl[s] >= 0 && (zl[s] < zb[s] || (zl[s] == zb[s] && tl[s] < tb[s]))) { zb[s] = zl[s]; tb[s] = tl[s]; }
-      }
+      for (int k = lane; k < fill; k += 64) test_tri(w_tris[k], qx, qy, wb, tb);   // tb starts at "no triangle" = +inf: ties keep the lower index
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        float zmin = zb[s];
+        float wmax = wb[s];
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, d));
-        int tmin = zb[s] == zmin ? tb[s] : 0x7fffffff;
+        for (int d = 32; d > 0; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d));
+        int tmin = (wb[s] == wmax && wmax > 0.f) ? tb[s] : 0x7fffffff;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) tmin = min(tmin, __shfl_xor(tmin, d));
-        if (lane == src && tmin != 0x7fffffff && (zmin < zbest[s] || (zmin == zbest[s] && tmin < tbest[s]))) {
-          zbest[s] = zmin; tbest[s] = tmin;
+        if (lane == src && tmin != 0x7fffffff && (wmax > wbest[s] || (wmax == wbest[s] && tmin < tbest[s]))) {
+          wbest[s] = wmax; tbest[s] = tmin;
         }
       }
     }
@@ -707,31 +705,30 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
     // Pixel-parallel in two steps.  (1) Every lane tests its pixel against the screen boxes of all staged triangles
     // (one broadcast 16-byte LDS read + four compares each) and keeps the hits as a bit mask.  (2) Each lane walks
     // its own mask: the wavefront runs max-over-lanes(candidates) passes of the 4-sample test, with a different
-    // triangle per lane, instead of one pass per staged triangle (a 64-pixel batch is a thin strip of the object:
-    // most staged triangles hold only a few of its pixels).
+    // triangle per lane.
     static_assert(TRI_CAP <= 128 && TRI_CAP % 32 == 0, "up to four 32-bit candidate masks");
     uint32_t cand[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c * 32 >= fill) break;                     // wave-uniform
       const int nk = min(32, fill - c * 32);
-      uint32_t mm = 0u;
+      uint32_t mk = 0u;
       for (int j = 0; j < nk; ++j) {
         const float4 bb = *reinterpret_cast<const float4*>(&w_tris[c * 32 + j]);   // bx0, bx1, by0, by1
         const bool in = (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
-        mm |= in ? (1u << j) : 0u;
+        mk |= in ? (1u << j) : 0u;
       }
-      cand[c] = mine ? mm : 0u;
+      cand[c] = mine ? mk : 0u;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c * 32 >= fill) break;
-      uint32_t mm = cand[c];
-      while (__ballot(mm != 0u)) {                   // wave-uniform trip count
-        if (mm) {
-          const int j = __builtin_ctz(mm);
-          mm &= mm - 1u;
-          test_tri_inside(w_tris[c * 32 + j], pcx, pcy, zbest, tbest);
+      uint32_t mk = cand[c];
+      while (__ballot(mk != 0u)) {                   // wave-uniform trip count
+        if (mk) {
+          const int j = __builtin_ctz(mk);
+          mk &= mk - 1u;
+          test_tri_inside(w_tris[c * 32 + j], pcx, pcy, wbest, tbest);
         }
       }
     }
@@ -741,8 +738,8 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
 }
 
 // exact 4-sample resolve of one pixel (centre NDC nx, ny): coverage and depth per sample,
-// shading once per primitive at the pixel centre; zbest/tbest = nearest mesh triangle per sample
-// (from the mesh pass), z-buffered against the planes here.
+// shading once per primitive at the pixel centre; zbest/tbest = 1 / depth and index of the nearest mesh triangle per
+// sample (from the mesh pass; tbest < 0: none), z-buffered against the planes here.
 template <bool OBJ>
 __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const RenderParams& R,
                                       const TileLds* tiles, float nx, float ny, const ScreenTri* tris,
@@ -760,7 +757,7 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
     const Ray rs = make_ray(nx + ox[s] * sxn, ny - oy[s] * syn, c.tx, c.ty, c.sth, c.cth);
     const Hit hs = classify(c, m, tiles, rs);
     const float zplane = hs.cls == CLS_SKY ? 3.0e38f : hs.t;
-    if (OBJ && tbest[s] >= 0 && zbest[s] < zplane) key[s] = 3u | ((uint32_t)tbest[s] << 2);
+    if (OBJ && tbest[s] >= 0 && 1.f / zbest[s] < zplane) key[s] = 3u | ((uint32_t)tbest[s] << 2);   // zbest holds w = 1 / depth
     else if (hs.cls == CLS_TILE) key[s] = 2u | ((uint32_t)hs.tj << 2) | ((uint32_t)hs.ti << 14);
     else { key[s] = (uint32_t)hs.cls; n_sky += hs.cls == CLS_SKY; n_gnd += hs.cls == CLS_GROUND; }
   }
@@ -898,6 +895,8 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 #define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
 #define GRAB_MAX 16       // work items per cursor atomic, at most
+#define RES_ENVS 8        // env positions of a chunk per k_resolve_obj work item
+static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITEMS_PER_WG, "octet items");
 
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
@@ -968,6 +967,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
   uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
   int qn = 0;                                           // wave-uniform queue fill
+  int qend_v = 0;
   // Frame stores go through a wavefront-private LDS transpose: lane l then owns the 12 bytes of the
   // 4 consecutive pixels 4l..4l+3 (row-major in the wavefront's block) -> three dword stores per lane,
   // 3*WAVE_W contiguous bytes per block row.
@@ -1154,8 +1154,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         qn += __popcll(mk);
       }
     }
+    if (OBJ) qend_v = lane >= e - e0 ? qn : qend_v;   // lane l: queue fill after env e0 + l (k_resolve_obj's per-env ranges)
   }
   if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
+  if (OBJ && lane < ENVS_PER_BLOCK) R.qend[((size_t)blockIdx.x * (RB / 64) + wave) * ENVS_PER_BLOCK + lane] = (uint16_t)qend_v;
   // Work items for k_resolve: the workgroup's 64-entry batches (four regions, flattened), ITEM_B at a
   // time, appended to a global list so that the resolve launch can spread hot tiles (close-up meshes,
   // horizon band) over the whole chip.  The append order is arbitrary; items touch disjoint pixels.
@@ -1167,7 +1169,8 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 #pragma unroll
     for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
     if (nb > 0) {
-      const int ni = (nb + ITEM_B - 1) / ITEM_B;
+      // without objects: ITEM_B batches per item (k_resolve<false>); with objects: one item per 8 envs of the chunk (k_resolve_obj)
+      const int ni = OBJ ? ENVS_PER_BLOCK / RES_ENVS : (nb + ITEM_B - 1) / ITEM_B;
       const int pos = atomicAdd(R.work, ni);
       for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)blockIdx.x * ITEMS_PER_WG + (uint32_t)i;
     }
@@ -1314,6 +1317,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   };
   auto store_rgb = [&](int e, int pix, uint32_t rgb) {
     uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
+#ifdef DT_Q_ABL_NOPATCH
+    if (rgb != 0x12345678u) return;                  // ablation: what the byte patches cost (traffic, time)
+#endif
     // two stores: a 2-byte aligned half + one byte, whichever way the pixel's 3 bytes fall
     const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;
     uint8_t* p8 = odd ? dst : dst + 2;
@@ -1561,6 +1567,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 
   uint16_t* w_queue = queue + ((size_t)rwg * (RB / 64) + wave) * QREGION;
   int qn = 0, qo = 0;                                  // plane-edge entries (front of the region), object-box entries (back)
+  int qend_v = 0;                                      // lane l: object-entry fill after the env at position e0 + l
   uint32_t* s_px = s_mem + R.n_qtiles * 2 + wave * WAVE_PIX;
   const int st_x = tile_x0 + (lane * 4) % WAVE_W, st_y = wave_y0 + (lane * 4) / WAVE_W;
   // frame rows are dword aligned (W % 4 == 0: launch precondition; other widths take the generic k_raster)
@@ -1639,6 +1646,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         for (int k = 0; k < PPT; ++k) oedge[k] = false;
         push_obj(e, f.env, om, oedge);
       }
+      if (OBJ) qend_v = lane >= e - e0 ? qo : qend_v;
     }
     if (lane == 0) qcount[rwg * (RB / 64) + wave] = OBJ ? qo : 0;
   } else {
@@ -1882,6 +1890,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     uint32_t hor = f.hor_rgb, env = f.env, env_prev;
     f = envq[min(e0 + 1, e1 - 1)];
     U3 held = finish(e0, env, hor, sa, objmask_of(e0));
+    if (OBJ) qend_v = qo;
     for (int e = e0 + 1; e < e1; ++e) {
       env_prev = env; hor = f.hor_rgb; env = f.env;
 #ifdef DT_Q_TIMING
@@ -1896,6 +1905,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
       const unsigned long long t2 = TSTAMP();
 #endif
       held = finish(e, env, hor, sa, objmask_of(e));
+      if (OBJ) qend_v = lane >= e - e0 ? qo : qend_v;
 #ifdef DT_Q_TIMING
       const unsigned long long t3 = TSTAMP();
       t_issue += t1 - t0; t_mem += t2 - t1; t_filt += t3 - t2; t_n += 1;
@@ -1918,16 +1928,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     resolve_region<S256>(R, cams, envq, pixtab, samptab, qtex, s_qt, s_px, w_queue, qn, e0, tile_x0, wave_y0, lane);
   }
   }
-  if (OBJ) {   // mesh objects: k_resolve<true> drains the object-box entries (back of the regions) -- work items for it
+  if (OBJ) {   // mesh objects: k_resolve_obj drains the object-box entries (back of the regions) -- work items for it
+    if (lane < ENVS_PER_BLOCK) R.qend[((size_t)rwg * (RB / 64) + wave) * ENVS_PER_BLOCK + lane] = (uint16_t)qend_v;
     __shared__ int s_nb[RB / 64];
-    if (lane == 0) s_nb[wave] = (qo + 63) >> 6;
+    if (lane == 0) s_nb[wave] = qo;
     __syncthreads();
     if (tid == 0) {
       int nb = 0;
 #pragma unroll
       for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
-      if (nb > 0) {
-        const int ni = (nb + ITEM_B - 1) / ITEM_B;
+      if (nb > 0) {                                  // one item per RES_ENVS env positions of the chunk
+        const int ni = ENVS_PER_BLOCK / RES_ENVS;
         const int pos = atomicAdd(R.work, ni);
         for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)rwg * ITEMS_PER_WG + (uint32_t)i;
       }
@@ -1938,15 +1949,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
-#ifdef DT_RES_WAVES
-#define RES_ATTR __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES, DT_RES_WAVES)))
-#else
-#define RES_ATTR
-#endif
-template <bool OBJ>
-__global__ __launch_bounds__(RB) RES_ATTR void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
-                                                const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount, const int back,
-                                                const EnvQ* __restrict__ envq) {
+__global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
+                                                const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
   const int tid = threadIdx.x;
@@ -1960,17 +1964,7 @@ __global__ __launch_bounds__(RB) RES_ATTR void k_resolve(RenderParams R, const E
   __syncthreads();
   uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
   EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * ENVS_PER_BLOCK;                    // wavefront-local
-  TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * ENVS_PER_BLOCK * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
   const int n_items = R.work[0];                     // written by the raster launch
-#ifdef DT_RES_TIMING
-  unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // item setup, entry load, mesh stream, z-buffer, shade, batches, items, total
-  const unsigned long long t_begin = __builtin_readcyclecounter();
-#define RT(i, a, b) tm[i] += (b) - (a)
-#define RNOW() __builtin_readcyclecounter()
-#else
-#define RT(i, a, b)
-#define RNOW() 0ull
-#endif
   // One atomic buys `grab` items, taken with stride n_grabs through the list: same-address atomics are
   // serialised by the L2 (~0.2 ms per 100 k of them), and the stride keeps the consecutive items of one hot
   // raster workgroup on different wavefronts.  Granularity: ~4 grabs per resident wavefront, <= GRAB_MAX items.
@@ -1982,99 +1976,181 @@ __global__ __launch_bounds__(RB) RES_ATTR void k_resolve(RenderParams R, const E
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= n_grabs) break;
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
-      const unsigned long long t_i0 = RNOW();
       const uint32_t item = R.items[it];
       const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
-      // queue entries carry positions in the render order (e0 + el); with k_env_sort active (envq given) the env behind
-      // a position is EnvQ.env, otherwise the position itself
-      auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };
       {  // the chunk's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
         static_assert(ENVS_PER_BLOCK * sizeof(EnvCam) == 64 * 64, "one 64-byte slice per lane");
         const int ne = min(ENVS_PER_BLOCK, R.N - e0);
+        const uint4* src = reinterpret_cast<const uint4*>(cams + e0) + lane * 4;
         uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
-        if (lane * 64 < ne * (int)sizeof(EnvCam)) {
-          const uint4* src = reinterpret_cast<const uint4*>(cams + env_at(e0 + (lane >> 1))) + (lane & 1) * 4;
-          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-        }
+        if (lane * 64 < ne * (int)sizeof(EnvCam)) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
       }
       const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
       static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
-      // object masks of the chunk's envs for the four blocks of this raster tile: lane l <-> position e0 + l
-      uint32_t mk_lo[4] = {0u, 0u, 0u, 0u}, mk_hi[4] = {0u, 0u, 0u, 0u};
-      if (OBJ && lane < min(ENVS_PER_BLOCK, R.N - e0)) {
-        const unsigned long long* mp = R.objmask + ((size_t)(e0 + lane) * n_tiles + tile) * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const unsigned long long v = mp[r]; mk_lo[r] = (uint32_t)v; mk_hi[r] = (uint32_t)(v >> 32); }
-      }
       int rn[4], rb[5];
       rb[0] = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { rn[r] = qcount[rwg * 4 + r]; rb[r + 1] = rb[r] + ((rn[r] + 63) >> 6); }
       const int b_end = min(rb[4], (part + 1) * ITEM_B);
-#ifdef DT_RES_TIMING
-      __builtin_amdgcn_s_waitcnt(0);
-      RT(0, t_i0, RNOW()); tm[6] += 1;
-#endif
       for (int b = part * ITEM_B; b < b_end; ++b) {  // wave-uniform
-        const unsigned long long t_b0 = RNOW();
         const int reg = (b >= rb[1]) + (b >= rb[2]) + (b >= rb[3]);
         const int q0 = (b - (reg == 0 ? rb[0] : reg == 1 ? rb[1] : reg == 2 ? rb[2] : rb[3])) * 64;
         const int n = reg == 0 ? rn[0] : reg == 1 ? rn[1] : reg == 2 ? rn[2] : rn[3];
         const uint16_t* w_queue = queue + ((size_t)rwg * 4 + reg) * QREGION;
         const int wave_y0 = tile_y0 + reg * (WAVE_PIX / WAVE_W);
         const bool have = q0 + lane < n;
-        // back: the entries were appended from the far end of the region (k_raster_q<OBJ>: object-box pixels)
-        const uint32_t ent = have ? w_queue[back ? QREGION - 1 - (q0 + lane) : q0 + lane] : 0u;
+        const uint32_t ent = have ? w_queue[q0 + lane] : 0u;
         const int el = have ? (int)(ent >> 8) : -1, lp = ent & 255;
         const int pix = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;      // entries only exist for in-image pixels
         const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
-        const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
-        float zbest[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-        int tbest[4] = {-1, -1, -1, -1};
-#ifdef DT_RES_TIMING
-        __builtin_amdgcn_s_waitcnt(0);
-        const unsigned long long t_b1 = RNOW();
-        RT(1, t_b0, t_b1); tm[5] += 1;
-        unsigned long long t_z = 0;
+        if (have) {
+          const float wb[4] = {0.f, 0.f, 0.f, 0.f};
+          const int tb[4] = {-1, -1, -1, -1};
+          const EnvCam c = w_cams[el];
+          const MapU m = map_u(R.maps[c.map_id]);
+          const uint32_t v = shade_msaa<false>(c, m, R, s_tiles, l.x, l.y, nullptr, wb, tb);
+          uint8_t* dst = R.frames + ((size_t)(e0 + el) * npix + pix) * 3;
+          dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+        }
+      }
+    }
+  }
+}
+
+// Exact path of the pixels inside mesh-object screen boxes (and, after the generic raster, of every queued pixel).
+// Work unit = (raster tile, env): the entries one env left in the four wavefront regions of a raster workgroup are taken
+// together, up to NB 64-entry batches at a time, so that the env's triangles are streamed, culled and staged ONCE for
+// the 128 x 8 pixels of the tile instead of once per 128 x 2 block (k_resolve<true> of round 1: one pass per
+// (batch, env) pair, ~45 pairs per env and frame).  The raster records the queue fill of every region after every env
+// (qend), so a unit's entries are four contiguous ranges; a work item covers RES_ENVS consecutive env positions of a chunk.
+#ifndef DT_RES_NB
+#define DT_RES_NB 2
 #endif
-        if (OBJ) {
-          // ---- mesh pass.  Queue entries are in env order, so these 64 pixels belong to a few
-          // consecutive envs.  Per env, and per object whose screen box meets the env's pixels here:
-          // stream the object's triangles 64 at a time (one per lane), keep those whose screen box meets
-          // the bounding box of these pixels, compact them into a wavefront-local LDS chunk and z-buffer
-          // the chunk.  No cap, no barrier: DS operations of one wavefront execute in program order.
-          int el_lo = have ? el : 0x7fffffff, el_hi = el;
+template <int NB>
+__global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue,
+                                                    const int back, const EnvQ* __restrict__ envq) {
+  extern __shared__ uint32_t s_mem[];
+  TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
+  const int tid = threadIdx.x;
+  const int npix = R.W * R.H;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  const int wave = tid >> 6, lane = tid & 63;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.tile_recs);
+    for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
+  }
+  __syncthreads();
+  uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
+  EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * RES_ENVS;                            // wavefront-local
+  TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
+  const int n_items = R.work[0];                     // written by the raster launch
+  const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
+  const int n_grabs = (n_items + grab - 1) / grab;
+  auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };   // position in the render order -> env
+  while (true) {
+    int g = 0;
+    if (lane == 0) g = atomicAdd(R.work + 1, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= n_grabs) break;
+    for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
+      const uint32_t item = R.items[it];
+      const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG) * RES_ENVS;
+      const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
+      const int e0 = chunk * ENVS_PER_BLOCK;
+      const int ne = min(ENVS_PER_BLOCK, R.N - e0);
+      if (p0 >= ne) continue;
+      // per-region entry ranges of the chunk's envs: lane l <-> position e0 + l
+      static_assert(RB / 64 == 4, "four regions per raster workgroup");
+      int endv[4], startv[4];
 #pragma unroll
-          for (int d = 32; d > 0; d >>= 1) { el_lo = min(el_lo, __shfl_xor(el_lo, d)); el_hi = max(el_hi, __shfl_xor(el_hi, d)); }
-          for (int ee = el_lo; ee <= el_hi; ++ee) {  // wave-uniform
-            const bool mine = el == ee;
-            if (!__ballot(mine)) continue;
-            // the objects whose screen box meets this raster block in this env (k_obj_setup's mask: no per-pair box loads)
-            const uint32_t sel_lo = reg == 0 ? mk_lo[0] : reg == 1 ? mk_lo[1] : reg == 2 ? mk_lo[2] : mk_lo[3];
-            const uint32_t sel_hi = reg == 0 ? mk_hi[0] : reg == 1 ? mk_hi[1] : reg == 2 ? mk_hi[2] : mk_hi[3];
-            unsigned long long hm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sel_hi, ee) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)sel_lo, ee);   // wave-uniform
-            if (!hm) continue;
-            const int env_ee = __builtin_amdgcn_readfirstlane(env_at(e0 + ee));
-            float x0 = mine ? pcx : 1e30f, x1 = mine ? pcx : -1e30f, y0 = mine ? pcy : 1e30f, y1 = mine ? pcy : -1e30f;
+      for (int r = 0; r < 4; ++r) endv[r] = lane < ENVS_PER_BLOCK ? (int)R.qend[((size_t)rwg * 4 + r) * ENVS_PER_BLOCK + lane] : 0;
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int up = __shfl_up(endv[r], 1);
+        startv[r] = lane == 0 ? 0 : up;
+        any |= endv[r] != startv[r];
+      }
+      if (!__ballot(any && lane >= p0 && lane < p0 + RES_ENVS)) continue;   // nothing queued for these envs
+      {  // the item's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
+        static_assert(sizeof(EnvCam) == 128, "two 64-byte slices per EnvCam");
+        if (lane < 2 * RES_ENVS && p0 + (lane >> 1) < ne) {
+          const uint4* src = reinterpret_cast<const uint4*>(cams + env_at(e0 + p0 + (lane >> 1))) + (lane & 1) * 4;
+          uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
+          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+      }
+      // object masks of the chunk's envs for the four blocks of this raster tile (OR: the unit spans all four)
+      uint32_t mk_lo = 0u, mk_hi = 0u;
+      if (lane < ne) {
+        const unsigned long long* mp = R.objmask + ((size_t)(e0 + lane) * n_tiles + tile) * 4;
+        const unsigned long long v = mp[0] | mp[1] | mp[2] | mp[3];
+        mk_lo = (uint32_t)v; mk_hi = (uint32_t)(v >> 32);
+      }
+      const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int p = p0; p < min(p0 + RES_ENVS, ne); ++p) {   // wave-uniform: one (tile, env) unit
+        int c_[4], s_[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s_[r] = __builtin_amdgcn_readlane(startv[r], p); c_[r] = __builtin_amdgcn_readlane(endv[r], p) - s_[r]; }
+        const int t1 = c_[0], t2 = t1 + c_[1], t3 = t2 + c_[2], n_p = t3 + c_[3];
+        if (n_p == 0) continue;
+        const unsigned long long hm0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk_hi, p) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)mk_lo, p);
+        const int env_p = __builtin_amdgcn_readfirstlane(env_at(e0 + p));
+        const EnvCam& c = w_cams[p - p0];
+        const MapU m = map_u(R.maps[c.map_id]);
+        const ScreenTri* base = R.stris + (size_t)env_p * R.max_tris;
+        const uint2* rng = R.objrange + (size_t)__builtin_amdgcn_readfirstlane(c.map_id) * DTSIM_MAX_OBJECTS;
+        for (int g0 = 0; g0 < n_p; g0 += 64 * NB) {   // wave-uniform: up to NB batches of the unit at a time
+          bool have[NB];
+          int pix[NB];
+          float nxv[NB], nyv[NB];
+          float zbest[NB][4];
+          int tbest[NB][4];
+          float x0 = 1e30f, x1 = -1e30f, y0 = 1e30f, y1 = -1e30f;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int idx = g0 + j * 64 + lane;
+            have[j] = idx < n_p;
+            const int r = (idx >= t1) + (idx >= t2) + (idx >= t3);
+            const int li = idx - (r == 0 ? 0 : r == 1 ? t1 : r == 2 ? t2 : t3) + (r == 0 ? s_[0] : r == 1 ? s_[1] : r == 2 ? s_[2] : s_[3]);
+            const uint16_t* w_queue = queue + ((size_t)rwg * 4 + r) * QREGION;
+            // back: the entries were appended from the far end of the region (k_raster_q<OBJ>: object-box pixels)
+            const uint32_t ent = have[j] ? w_queue[back ? QREGION - 1 - li : li] : 0u;
+            const int lp = ent & 255;
+            pix[j] = (tile_y0 + r * (WAVE_PIX / WAVE_W) + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;   // entries only exist for in-image pixels
+            if (!have[j]) pix[j] = 0;
+            const float4 l = reinterpret_cast<const float4*>(R.lut)[pix[j]];
+            nxv[j] = l.x; nyv[j] = l.y;
+            const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
+            if (have[j]) { x0 = fminf(x0, pcx); x1 = fmaxf(x1, pcx); y0 = fminf(y0, pcy); y1 = fmaxf(y1, pcy); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zbest[j][q] = 0.f; tbest[j][q] = -1; }   // w = 1 / depth: 0 = nothing yet
+          }
+          unsigned long long hm = hm0;
+#ifdef DT_RO_NOSTREAM
+          hm = 0ull;
+#endif
+          if (hm) {
+            // ---- mesh pass: stream the triangles of the objects whose screen box meets the tile, 64 at a time (one per
+            // lane, coverage half only), keep those whose box meets the bounding box of the unit's pixels, compact them
+            // into the wavefront-local LDS chunk and z-buffer the chunk against every batch of the group.
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) {
               x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
               y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
             }
-            if (R.dbg && lane == 0) { atomicAdd(R.dbg + 0, 1); atomicAdd(R.dbg + 1, __popcll(hm)); }   // (batch, env) pairs that look at objects, objects streamed
-            const ScreenTri* base = R.stris + (size_t)env_ee * R.max_tris;
-            const uint2* rng = R.objrange + (size_t)__builtin_amdgcn_readfirstlane(w_cams[ee].map_id) * DTSIM_MAX_OBJECTS;
-            // flat sequence of 64-triangle chunks over the hit objects; the coverage half (64 B) of the
-            // next chunk's ScreenTri is loaded while the current one is filtered and staged
             int first = 0, count = 0, t0 = 0;
             auto advance = [&]() -> bool {             // wave-uniform: next (object, t0); false when exhausted
               t0 += 64;
               while (t0 >= count) {
                 if (!hm) return false;
-                const uint2 fc = rng[__builtin_ctzll(hm)];   // wave-uniform
+                const uint2 fc = rng[__builtin_ctzll(hm)];
                 hm &= hm - 1ull;
                 first = (int)fc.x; count = (int)fc.y; t0 = 0;
               }
@@ -2097,53 +2173,40 @@ __global__ __launch_bounds__(RB) RES_ATTR void k_resolve(RenderParams R, const E
               if (pass) w_tris[fill + __popcll(pm & ((1ull << lane) - 1ull))] = cur;
               fill += __popcll(pm);
               if (fill > TRI_CAP - 64 || (!has_next && fill > 0)) {   // chunk full, or the last one: z-buffer it
-#ifdef DT_RES_TIMING
-                const unsigned long long t_z0 = RNOW();
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                  if (j > 0 && g0 + j * 64 >= n_p) break;            // wave-uniform
+#ifdef DT_RO_NOZ
+                  if (fill == 12345) zbest[j][0] = 0.f;
+#else
+                  zbuffer_chunk(w_tris, fill, have[j], lane, (nxv[j] + 1.f) * 0.5f * (float)R.W, (1.f - nyv[j]) * 0.5f * (float)R.H,
+                                zbest[j], tbest[j], nullptr);
 #endif
-                zbuffer_chunk(w_tris, fill, mine, lane, pcx, pcy, zbest, tbest, R.dbg);
-#ifdef DT_RES_TIMING
-                t_z += RNOW() - t_z0;
-#endif
+                }
                 fill = 0;
               }
               cur = nxt; cur_in = nxt_in; more = has_next;
             }
           }
-        }
-#ifdef DT_RES_TIMING
-        const unsigned long long t_b2 = RNOW();
-        tm[2] += (t_b2 - t_b1) - t_z; tm[3] += t_z;
-#endif
-        if (have) {
-          const EnvCam c = w_cams[el];
-          const MapU m = map_u(R.maps[c.map_id]);
-          const int env_l = env_at(e0 + el);
-          const ScreenTri* tris = OBJ ? R.stris + (size_t)env_l * R.max_tris : nullptr;
-          const uint32_t v = shade_msaa<OBJ>(c, m, R, s_tiles, l.x, l.y, tris, zbest, tbest);
-          uint8_t* dst = R.frames + ((size_t)env_l * npix + pix) * 3;
-#if defined(DT_RES_ABL_NOSTORE)
-          if (v == 0x12345678u) dst[0] = 1;
-#elif defined(DT_RES_ABL_ONESTORE)
-          *reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)3) = v;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            if (j > 0 && g0 + j * 64 >= n_p) break;                  // wave-uniform
+            if (have[j]) {
+#ifdef DT_RO_NOSHADE
+              const uint32_t v = (uint32_t)tbest[j][0] ^ (uint32_t)tbest[j][1] ^ (uint32_t)tbest[j][2] ^ (uint32_t)tbest[j][3];
 #else
-          dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+              const uint32_t v = shade_msaa<true>(c, m, R, s_tiles, nxv[j], nyv[j], base, zbest[j], tbest[j]);
 #endif
+              uint8_t* dst = R.frames + ((size_t)env_p * npix + pix[j]) * 3;
+              dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
+            }
+          }
         }
-#ifdef DT_RES_TIMING
-        __builtin_amdgcn_s_waitcnt(0);
-        RT(4, t_b2, RNOW());
-#endif
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next item overwrites w_cams
+      __builtin_amdgcn_wave_barrier();
     }
   }
-#ifdef DT_RES_TIMING
-  tm[7] = __builtin_readcyclecounter() - t_begin;
-  if (lane == 0) {
-    unsigned long long* tc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.dump) + 1024 + 64);
-    for (int i = 0; i < 8; ++i) atomicAdd(tc + i, tm[i]);
-    atomicAdd(tc + 8, 1ull);
-  }
-#endif
 }
 
 }  // namespace
@@ -2198,7 +2261,8 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
     // edge pixels were resolved inside the raster wavefronts)
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
-    if (obj) hipLaunchKernelGGL(k_resolve<true>, rgrid, dim3(RB), lds3, s, R, cams, R.queue, R.qcount, quad ? 1 : 0, pos ? envq : (const EnvQ*)nullptr);
-    else hipLaunchKernelGGL(k_resolve<false>, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount, 0, (const EnvQ*)nullptr);
+    const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
+    if (obj) hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, quad ? 1 : 0, pos ? envq : (const EnvQ*)nullptr);
+    else hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
   }
 }
