@@ -250,7 +250,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
-      if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * DT_ITEMS_PER_WG * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * (DT_ITEMS_PER_WG + 4) * sizeof(uint32_t));   // k_resolve's list + k_resolve_obj's (4 per workgroup)
       if (e == hipSuccess) e = hipMalloc(&h->d_qend, n_wg * 4 * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
@@ -832,7 +832,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
-  R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items; R.qend = h->d_qend;
+  R.work = h->d_qcount + n_wg_ * 4 + 8; R.items = h->d_items; R.items2 = h->d_items + n_wg_ * DT_ITEMS_PER_WG; R.qend = h->d_qend;
   if (getenv("DTSIM_DEBUG_QUEUE")) {
     R.dbg = h->d_qcount + n_wg_ * 4;
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));

@@ -898,6 +898,14 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
 #define RES_ENVS 8        // env positions of a chunk per k_resolve_obj work item
 static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITEMS_PER_WG, "octet items");
 
+// Work items of k_resolve_obj (its own list: R.work[2] = count, [3] = cursor; second part of R.items): one per RES_ENVS
+// env positions of a raster workgroup that queued object-box pixels.
+__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg) {
+  const int ni = ENVS_PER_BLOCK / RES_ENVS;
+  const int pos = atomicAdd(R.work + 2, ni);
+  for (int i = 0; i < ni; ++i) R.items2[pos + i] = rwg * ITEMS_PER_WG + (uint32_t)i;
+}
+
 template <bool DR, bool OBJ>
 __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __restrict__ cams,
                                                const EnvFast* __restrict__ fasts, uint8_t* __restrict__ frames, const uint32_t* __restrict__ texels,
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
   }
 
   uint16_t* w_queue = queue + ((size_t)blockIdx.x * (RB / 64) + wave) * QREGION;
-  int qn = 0;                                           // wave-uniform queue fill
+  int qn = 0, qo = 0;                                   // wave-uniform queue fill: plane edges (front), object-box pixels (back)
   int qend_v = 0;
   // Frame stores go through a wavefront-private LDS transpose: lane l then owns the 12 bytes of the
   // 4 consecutive pixels 4l..4l+3 (row-major in the wavefront's block) -> three dword stores per lane,
@@ -1001,7 +1009,9 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     // tile-record reads and the 8 texel loads of the 4 pixels are all in flight together.
     // Per-pixel predicates are kept as bools (lane masks in SGPR pairs), not as VGPR bit fields.
     uint32_t px[PPT];
-    bool edge[PPT];
+    bool edge[PPT], oedge[PPT];                        // oedge: inside a mesh object's screen box (k_resolve_obj's pixels)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) oedge[k] = false;
     bool any_work = false;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) any_work |= (pv[k].flags & (PF_VALID | PF_SKY)) == PF_VALID;
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         om &= om - 1ull;
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-          if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) edge[k] = true;
+          if (ok[k] && spx[k] >= ob.bx0 && spx[k] <= ob.bx1 && spy[k] >= ob.by0 && spy[k] <= ob.by1) oedge[k] = true;
       }
     }
 
@@ -1138,11 +1148,23 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 
     // ---- edge pixels: exact 4-sample resolve, deferred to k_resolve (own launch, own
     // register budget): append them to this wavefront's queue region.
-    bool any_edge = false;
+    bool any_edge = false, any_oedge = false;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) any_edge |= edge[k];
+    for (int k = 0; k < PPT; ++k) { any_oedge |= oedge[k]; edge[k] &= !oedge[k]; any_edge |= edge[k]; }
+    const uint32_t etag = (uint32_t)(e - e0) << 8;
+    if (OBJ && !R.no_msaa && __ballot(any_oedge)) {    // wave-uniform: object-box pixels fill the region from its far end
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const bool ek = oedge[k];
+        const unsigned long long mk = __ballot(ek);
+        if (ek) {
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
+        }
+        qo += __popcll(mk);
+      }
+    }
     if (!R.no_msaa && __ballot(any_edge)) {    // wave-uniform
-      const uint32_t etag = (uint32_t)(e - e0) << 8;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {                // per pixel slot: ballot -> rank -> masked store
         const bool ek = edge[k];
@@ -1154,26 +1176,26 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         qn += __popcll(mk);
       }
     }
-    if (OBJ) qend_v = lane >= e - e0 ? qn : qend_v;   // lane l: queue fill after env e0 + l (k_resolve_obj's per-env ranges)
+    if (OBJ) qend_v = lane >= e - e0 ? qo : qend_v;   // lane l: object-entry fill after env e0 + l (k_resolve_obj's per-env ranges)
   }
   if (lane == 0) qcount[blockIdx.x * (RB / 64) + wave] = qn;
   if (OBJ && lane < ENVS_PER_BLOCK) R.qend[((size_t)blockIdx.x * (RB / 64) + wave) * ENVS_PER_BLOCK + lane] = (uint16_t)qend_v;
   // Work items for k_resolve: the workgroup's 64-entry batches (four regions, flattened), ITEM_B at a
   // time, appended to a global list so that the resolve launch can spread hot tiles (close-up meshes,
   // horizon band) over the whole chip.  The append order is arbitrary; items touch disjoint pixels.
-  __shared__ int s_nb[RB / 64];
-  if (lane == 0) s_nb[wave] = (qn + 63) >> 6;
+  __shared__ int s_nb[RB / 64], s_no[RB / 64];
+  if (lane == 0) { s_nb[wave] = (qn + 63) >> 6; s_no[wave] = qo; }
   __syncthreads();
   if (tid == 0 && !R.no_msaa) {
-    int nb = 0;
+    int nb = 0, no = 0;
 #pragma unroll
-    for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
-    if (nb > 0) {
-      // without objects: ITEM_B batches per item (k_resolve<false>); with objects: one item per 8 envs of the chunk (k_resolve_obj)
-      const int ni = OBJ ? ENVS_PER_BLOCK / RES_ENVS : (nb + ITEM_B - 1) / ITEM_B;
+    for (int r = 0; r < RB / 64; ++r) { nb += s_nb[r]; no += s_no[r]; }
+    if (nb > 0) {                                    // k_resolve: ITEM_B batches of plane-edge entries per item
+      const int ni = (nb + ITEM_B - 1) / ITEM_B;
       const int pos = atomicAdd(R.work, ni);
       for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)blockIdx.x * ITEMS_PER_WG + (uint32_t)i;
     }
+    if (OBJ && no > 0) push_obj_items(R, (uint32_t)blockIdx.x);
   }
 }
 
@@ -1937,11 +1959,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
       int nb = 0;
 #pragma unroll
       for (int r = 0; r < RB / 64; ++r) nb += s_nb[r];
-      if (nb > 0) {                                  // one item per RES_ENVS env positions of the chunk
-        const int ni = ENVS_PER_BLOCK / RES_ENVS;
-        const int pos = atomicAdd(R.work, ni);
-        for (int i = 0; i < ni; ++i) R.items[pos + i] = (uint32_t)rwg * ITEMS_PER_WG + (uint32_t)i;
-      }
+      if (nb > 0) push_obj_items(R, (uint32_t)rwg);
     }
   }
 }
@@ -2045,17 +2063,17 @@ __global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam
   uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
   EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * RES_ENVS;                            // wavefront-local
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
-  const int n_items = R.work[0];                     // written by the raster launch
+  const int n_items = R.work[2];                     // written by the raster launch (push_obj_items)
   const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
   const int n_grabs = (n_items + grab - 1) / grab;
   auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };   // position in the render order -> env
   while (true) {
     int g = 0;
-    if (lane == 0) g = atomicAdd(R.work + 1, 1);
+    if (lane == 0) g = atomicAdd(R.work + 3, 1);
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= n_grabs) break;
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
-      const uint32_t item = R.items[it];
+      const uint32_t item = R.items2[it];
       const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG) * RES_ENVS;
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
@@ -2228,12 +2246,11 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
     hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams, pos);
   }
-  (void)hipMemsetAsync(R.work, 0, 2 * sizeof(int32_t), s);            // work-item count + resolve cursor
+  (void)hipMemsetAsync(R.work, 0, 4 * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
   const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
   const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
-  const size_t lds3 = lds2 + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
   const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
   // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of DT_Q_TILE_GROUP (the last group padded)
   const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + DT_Q_TILE_GROUP - 1) / DT_Q_TILE_GROUP) * DT_Q_TILE_GROUP * ((n_chunks + 7) / 8) * 8));
@@ -2254,15 +2271,16 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
-  if (quad && !obj) {
-    // the exact path ran inside k_raster_q (resolve_region)
-  } else if (!R.no_msaa) {
-    // generic raster: every queued pixel; k_raster_q<OBJ>: the pixels inside mesh-object screen boxes (the plane-only
-    // edge pixels were resolved inside the raster wavefronts)
+  // exact path.  Quad pipeline: the plane-edge pixels were resolved inside k_raster_q (resolve_region); generic raster:
+  // k_resolve drains them (front of the queue regions).  Pixels inside mesh-object screen boxes (far end of the regions)
+  // are k_resolve_obj's, after either raster.
+  if (!R.no_msaa) {
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
-    const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
-    if (obj) hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, quad ? 1 : 0, pos ? envq : (const EnvQ*)nullptr);
-    else hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    if (!quad) hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
+    if (obj) {
+      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
+      hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, 1, pos ? envq : (const EnvQ*)nullptr);
+    }
   }
 }
