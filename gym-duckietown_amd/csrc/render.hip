@@ -26,21 +26,26 @@
 //                 mbcnt, no atomics) to a per-wavefront global queue region.
 //                 Output: px -> wavefront-private LDS transpose -> 12 B (4 px) per lane, three
 //                 dword stores, 384 contiguous bytes per tile row.
-//   k_obj_setup (maps with objects): one workgroup per env projects the env's mesh triangles to screen space
-//                 (per-vertex lighting, texture index, traffic-light card by pattern, segmentation colour) and
-//                 reduces per-object screen boxes.
-//   k_resolve<OBJ>: persistent wavefronts pull work items (8 queue batches of one raster workgroup) from the list
-//                 k_raster appended to and run the exact 4-sample resolve 64 entries at a time
-//                 (coverage per sample, shading once per distinct primitive at the pixel centre;
-//                 mesh triangles z-buffered from a wavefront-local LDS chunk), patching the
-//                 3 bytes of each edge pixel; stream-ordered after k_raster.
+//   k_blk_setup / k_obj_setup (maps with objects): source-pixel boxes of the raster wavefront blocks (env-invariant);
+//                 one workgroup per env projects the env's mesh triangles to screen space (per-vertex lighting,
+//                 texture index, traffic-light card by pattern, segmentation colour), reduces per-object screen boxes
+//                 and writes, per (env, block), the mask of the objects whose box meets the block.
+//   k_raster_q<OBJ,S256> (shared camera, square power-of-two tile textures): quad-record one-ray path +
+//                 the exact path of plane-edge pixels inside the same wavefronts (resolve_region).
+//   k_resolve:    exact 4-sample resolve of the plane-edge pixels the generic k_raster queued (front of the queue
+//                 regions): persistent wavefronts pull work items (8 queue batches of one raster workgroup), 64 entries
+//                 at a time -- coverage per sample, shading once per distinct primitive at the pixel centre --
+//                 and patch the 3 bytes of each pixel; stream-ordered after the raster.
+//   k_resolve_obj: the pixels inside mesh-object screen boxes (far end of the queue regions, either raster), one unit
+//                 per (raster tile, env): triangles streamed and staged in LDS once per unit, z-buffered per sample in
+//                 1/depth space, then the same shading.
 //   Segmentation render (dtsim_render_ex): same kernels on the segmented texel pool, k_cam_setup forces the unlit
 //                 state and the magenta clear / ground colour, k_obj_setup folds the mesh's flat colour into Kd.
 //
 // Roofline: algorithmic bytes per env-step = W*H*3 (921 600 B at 640x480), written once (+ the ~1.3 % edge
 // pixels a second time); LUT / textures / tables are shared by all envs and stay in registers / LDS / L2.
-// Measured (profiles/): the pass is VALU-issue bound -- 64.8 vector instructions per pixel with the
-// vector ALUs saturated -- at 19.7 % of the HBM roofline; float32 shading, uint8 output.
+// Measured (profiles/): the pass is VALU-issue bound -- 44 vector instructions per pixel (round 1: 64.8)
+// with the vector ALUs 75-78 % busy -- at 24 % of the HBM roofline; float32 / integer-filter shading, uint8 output.
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -56,7 +61,7 @@
 #ifndef DT_TRI_CAP
 #define DT_TRI_CAP 128
 #endif
-#define TRI_CAP DT_TRI_CAP  // LDS triangle slots per wavefront in k_resolve<true> (streamed chunks)
+#define TRI_CAP DT_TRI_CAP  // LDS triangle slots per wavefront in k_resolve_obj (streamed chunks)
 
 #define CLS_SKY 0
 #define CLS_GROUND 1
@@ -110,7 +115,7 @@ struct alignas(16) EnvQ {
 };
 static_assert(sizeof(EnvQ) == 64, "EnvQ is 64 bytes");
 
-// coverage-only part of a ScreenTri kept in LDS by k_resolve<true>; the winner's colours are fetched
+// coverage-only part of a ScreenTri kept in LDS by k_resolve_obj; the winner's colours are fetched
 // from global memory.
 struct alignas(16) TriCov { float bx0, bx1, by0, by1; float sx[3], sy[3], iw[3]; float inv_area; int32_t index; int32_t pad; };   // == first half of ScreenTri
 static_assert(sizeof(TriCov) == 64, "TriCov is 64 bytes");
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(RB) void k_blk_setup(RenderParams R, const float4* 
     y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
   }
   if (lane == 0) blockbox[tile * 4 + wave] = make_float4(x0, x1, y0, y1);
-  if (blockIdx.x == 0) {   // triangle range of every object in its map's triangle order (static; k_resolve<true> streams by it)
+  if (blockIdx.x == 0) {   // triangle range of every object in its map's triangle order (static; k_resolve_obj streams by it)
     for (int i = threadIdx.x; i < R.n_maps * DTSIM_MAX_OBJECTS; i += RB) {
       const int mi = i / DTSIM_MAX_OBJECTS, o = i % DTSIM_MAX_OBJECTS;
       const RenderMapDev m = R.maps[mi];
@@ -1509,7 +1514,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 // Anything that is not a fast tile pixel falls into a wave-uniform slow branch that decides ground-fast vs edge and
 // appends edge pixels to the wavefront's queue region; the exact path (resolve_region) drains it at the end of the env loop.
 // With mesh objects (OBJ) the pixels inside object screen boxes are appended from the far end of the region instead and
-// left to k_resolve<true>.
+// left to k_resolve_obj.
 
 #ifndef DT_Q_WAVES
 #define DT_Q_WAVES 5                                 // wavefronts per SIMD the register allocation is held to (96 VGPRs)
@@ -2040,7 +2045,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 // Exact path of the pixels inside mesh-object screen boxes (and, after the generic raster, of every queued pixel).
 // Work unit = (raster tile, env): the entries one env left in the four wavefront regions of a raster workgroup are taken
 // together, up to NB 64-entry batches at a time, so that the env's triangles are streamed, culled and staged ONCE for
-// the 128 x 8 pixels of the tile instead of once per 128 x 2 block (k_resolve<true> of round 1: one pass per
+// the 128 x 8 pixels of the tile instead of once per 128 x 2 block (the round-1 kernel: one pass per
 // (batch, env) pair, ~45 pairs per env and frame).  The raster records the queue fill of every region after every env
 // (qend), so a unit's entries are four contiguous ranges; a work item covers RES_ENVS consecutive env positions of a chunk.
 #ifndef DT_RES_NB
