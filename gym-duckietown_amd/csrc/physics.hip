@@ -217,15 +217,23 @@ __device__ inline Lane lane_pos(const MapView& m, double px, double pz, double a
   }
   const double* cp = m.curves + 8 * (tl->curve_off + best);
   // graphics.py:316-333 bezier_closest: 8-level endpoint-distance bisection, strict <
+  // The reference evaluates both end points at every level; one of them is the end point kept from the level before
+  // (same t, same arithmetic, same value), so only the moved one is evaluated here: 9 curve points instead of 16.
   double tb = 0.0, tt = 1.0;
+  auto dist_at = [&](double t) -> double {
+    double x, z;
+    bezier_point(cp, t, x, z);
+    return sqrt(((x - px) * (x - px) + 0.0) + (z - pz) * (z - pz));
+  };
+  double d_bot = dist_at(tb), d_top = dist_at(tt);
   for (int n = 0; n < 8; ++n) {
     const double mid = (tb + tt) * 0.5;
-    double bx, bz, ux, uz;
-    bezier_point(cp, tb, bx, bz);
-    bezier_point(cp, tt, ux, uz);
-    const double d_bot = sqrt(((bx - px) * (bx - px) + 0.0) + (bz - pz) * (bz - pz));
-    const double d_top = sqrt(((ux - px) * (ux - px) + 0.0) + (uz - pz) * (uz - pz));
-    if (d_bot < d_top) tt = mid; else tb = mid;
+    const bool lower = d_bot < d_top;
+    if (lower) tt = mid; else tb = mid;
+    if (n < 7) {                                       // the last level's end points are not looked at again
+      const double d_mid = dist_at(mid);
+      if (lower) d_top = d_mid; else d_bot = d_mid;
+    }
   }
   const double t = (tb + tt) * 0.5;
   double ptx, ptz;
