@@ -1138,9 +1138,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
       const uint4 q = *reinterpret_cast<const uint4*>(s_px + (lane * 4) % WAVE_PIX);   // same wavefront: DS ops are ordered
       if (st_ok) {
         uint32_t* d32 = reinterpret_cast<uint32_t*>(frames + (size_t)e * npix * 3 + st_off);   // 12-byte aligned
-        d32[0] = q.x | (q.y << 24);
-        d32[1] = (q.y >> 8) | (q.z << 16);
-        d32[2] = (q.z >> 16) | (q.w << 8);
+        // non-temporal: the frame is written once and not read back by this pass (keeps the texels in L2)
+        __builtin_nontemporal_store(q.x | (q.y << 24), d32);
+        __builtin_nontemporal_store((q.y >> 8) | (q.z << 16), d32 + 1);
+        __builtin_nontemporal_store((q.z >> 16) | (q.w << 8), d32 + 2);
       }
     } else {                                           // odd widths: bytes, straight from the owning lane
 #pragma unroll
@@ -1355,64 +1356,71 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
     *p16 = (uint16_t)(odd ? rgb >> 8 : rgb);
   };
 
-  for (int r0 = 0; r0 < n; r0 += RQ_LIST) {          // wave-uniform: rounds of up to RQ_LIST entries
+  // ---- phase 1: per entry, the exact interior test; interior entries get the one-ray colour, the others are
+  // compacted into the wavefront's list for phase 2.
+  // The (up to four) 64-entry batches of a round go through every stage together, so that each dependent memory round
+  // trip (entry -> tables -> tile entry -> quad record -> store) is paid once per round: the phase is latency bound.
+  // Instantiated for 1, 2 and 4 batches: most regions hold one seam's worth of entries, not 256.
+  auto phase1 = [&](auto utag, const int r0) __attribute__((always_inline)) -> int {
+    constexpr int U = decltype(utag)::value;
     int n_list = 0;                                  // wave-uniform
-    // ---- phase 1: per entry, the exact interior test; interior entries get the one-ray colour, the others are
-    // compacted into the wavefront's list for phase 2
-    // The four 64-entry batches of the round go through every stage together, so that each dependent memory round trip
-    // (entry -> tables -> tile entry -> quad record -> store) is paid once per 256 entries: the phase is latency bound.
-    constexpr int U = RQ_LIST / 64;
     bool have[U], interior[U];
-    int pix[U], el[U], env[U];
-    PixTab pt[U];
-    float Xu[U], Zu[U];
-    uint2 te_c[U];
+      int pix[U], el[U], env[U];
+      PixTab pt[U];
+      float Xu[U], Zu[U];
+      uint2 te_c[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      have[u] = r0 + u * 64 + lane < n;
-      // the entries were written by this wavefront a moment ago: bypass the (possibly stale) L1 line
-      const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + u * 64 + lane) : 0u;
-      el[u] = (int)(ent >> 8);
-      const int lp = (int)(ent & 255u);
-      pix[u] = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
-    }
-    float4 qa[U];
-    uint4 qb[U];
+      for (int u = 0; u < U; ++u) {
+        have[u] = r0 + u * 64 + lane < n;
+        // the entries were written by this wavefront a moment ago: bypass the (possibly stale) L1 line
+        const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + u * 64 + lane) : 0u;
+        el[u] = (int)(ent >> 8);
+        const int lp = (int)(ent & 255u);
+        pix[u] = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
+      }
+      float4 qa[U];
+      uint4 qb[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      pt[u] = pixtab[pix[u]];
-      const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
-      qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
-      qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
-      env[u] = (int)fq->env;
-    }
+      for (int u = 0; u < U; ++u) {
+        pt[u] = pixtab[pix[u]];
+        const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
+        qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
+        qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
+        env[u] = (int)fq->env;
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float A = qa[u].x, B = qa[u].y, Cx = qa[u].z, Cz = qa[u].w;
-      const float Xhi = __uint_as_float(qb[u].x), Zhi = __uint_as_float(qb[u].y);
-      Xu[u] = fmaf(pt[u].lf, B, fmaf(pt[u].lr, A, Cx)); Zu[u] = fmaf(pt[u].lf, -A, fmaf(pt[u].lr, B, Cz));
-      uint32_t ta_c;
-      float ox, oz;
-      te_c[u] = tile_entry(Xu[u], Zu[u], Xhi, Zhi, qb[u].z, qb[u].w, ta_c, ox, oz);
-      // distance of the hit to the boundary of the tile that owns it, in cells, against the MSAA reach
-      const float mrg = __half2float(__ushort_as_half((unsigned short)(pt[u].mi >> 16)));   // metres, rounded up
-      const float ux = Xu[u] - ox, uz = Zu[u] - oz;        // in [0, S) inside the owner tile
-      const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
-      const bool in_range = Xu[u] - 0.5f >= lo && Xu[u] - 0.5f <= Xhi && Zu[u] - 0.5f >= lo && Zu[u] - 0.5f <= Zhi;
-      interior[u] = have[u] && in_range && te_c[u].x >= 32u && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
-    }
-    uint4 qc[U];
+      for (int u = 0; u < U; ++u) {
+        const float A = qa[u].x, B = qa[u].y, Cx = qa[u].z, Cz = qa[u].w;
+        const float Xhi = __uint_as_float(qb[u].x), Zhi = __uint_as_float(qb[u].y);
+        Xu[u] = fmaf(pt[u].lf, B, fmaf(pt[u].lr, A, Cx)); Zu[u] = fmaf(pt[u].lf, -A, fmaf(pt[u].lr, B, Cz));
+        uint32_t ta_c;
+        float ox, oz;
+        te_c[u] = tile_entry(Xu[u], Zu[u], Xhi, Zhi, qb[u].z, qb[u].w, ta_c, ox, oz);
+        // distance of the hit to the boundary of the tile that owns it, in cells, against the MSAA reach
+        const float mrg = __half2float(__ushort_as_half((unsigned short)(pt[u].mi >> 16)));   // metres, rounded up
+        const float ux = Xu[u] - ox, uz = Zu[u] - oz;        // in [0, S) inside the owner tile
+        const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
+        const bool in_range = Xu[u] - 0.5f >= lo && Xu[u] - 0.5f <= Xhi && Zu[u] - 0.5f >= lo && Zu[u] - 0.5f <= Zhi;
+        interior[u] = have[u] && in_range && te_c[u].x >= 32u && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
+      }
+      uint4 qc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]);   // always in bounds (record 0 / 1 for non-tiles)
+      for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]);   // always in bounds (record 0 / 1 for non-tiles)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
-      if (interior[u]) store_rgb(env[u], pix[u], rgb);
-      const bool msaa = have[u] && !interior[u];
-      const unsigned long long mm = __ballot(msaa);
-      if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix[u] | ((uint32_t)el[u] << 24);
-      n_list += __popcll(mm);
-    }
+      for (int u = 0; u < U; ++u) {
+        const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
+        if (interior[u]) store_rgb(env[u], pix[u], rgb);
+        const bool msaa = have[u] && !interior[u];
+        const unsigned long long mm = __ballot(msaa);
+        if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix[u] | ((uint32_t)el[u] << 24);
+        n_list += __popcll(mm);
+      }
+    return n_list;
+  };
+  for (int r0 = 0; r0 < n; r0 += RQ_LIST) {          // wave-uniform: rounds of up to RQ_LIST entries
+    const int rem = n - r0;
+    const int n_list = rem > 128 ? phase1(std::integral_constant<int, 4>{}, r0)
+                     : rem > 64 ? phase1(std::integral_constant<int, 2>{}, r0) : phase1(std::integral_constant<int, 1>{}, r0);
     // ---- phase 2: the four samples of the listed pixels, on dense lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1817,6 +1825,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(px[k]) : "v"(hor_v), "v"(rgb), "s"(fm));   // not a one-ray tile pixel: clear colour
       }
     }
+#ifdef DT_Q_ABL_NOSLOW
+    slow = 0ull;
+#endif
     if (slow) {                                      // wave-uniform: some pixel is not a certain tile interior
       // Per pixel slot, and only for the slots that have such lanes (scalar tests on lane masks):
       //   off-grid cell: ground quad, if every sample stays off the grid and inside the quad;
@@ -1948,7 +1959,11 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
   }
 #endif
   if (lane == 0) qcount[rwg * (RB / 64) + wave] = OBJ ? qo : qn;
+#ifdef DT_Q_ABL_NORESOLVE
+  if (qn < 0) {
+#else
   if (qn > 0) {
+#endif
     // exact path for this wavefront's own edge pixels, right here (the frame stores of the env loop are ordered
     // before the byte patches: same wavefront, same addresses)
     __builtin_amdgcn_s_waitcnt(0);                 // queue stores have left the wavefront
