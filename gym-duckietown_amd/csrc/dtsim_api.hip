@@ -68,6 +68,8 @@ struct dtsim {
   int32_t* d_qenv = nullptr;
   double* d_qpose = nullptr;
   dtsim_probe* d_qout = nullptr;
+  dtsim_agent_info* d_agent = nullptr;
+  int render_tables = 0;          // dt_launch_render: which env-invariant tables are valid (camera LUT + maps unchanged)
   int q_cap = 0;
   // render
   uint8_t* frames_own = nullptr;
@@ -274,7 +276,7 @@ void dtsim_destroy(dtsim_t* h) {
     for (auto& p : s.free_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
-                  h->d_qpose, h->d_qout, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
+                  h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
                   h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -304,6 +306,7 @@ static int build_texel_pool(const dtsim_texture* textures, int n_textures, std::
 int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const dtsim_mesh* meshes,
                      int n_meshes) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (n_textures < 0 || n_textures > DTSIM_MAX_TEXTURES) return fail(DTSIM_E_LIMIT, "n_textures %d > %d", n_textures, DTSIM_MAX_TEXTURES);
   if (n_meshes < 0 || n_meshes > DTSIM_MAX_MESHES) return fail(DTSIM_E_LIMIT, "n_meshes %d > %d", n_meshes, DTSIM_MAX_MESHES);
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -417,6 +420,7 @@ static void build_quad_block(std::vector<uint32_t>& out, const uint32_t* pool, i
 
 int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (!h || !maps) return fail(DTSIM_E_INVALID, "null argument");
+  h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (n_maps <= 0 || n_maps > DTSIM_MAX_MAPS) return fail(DTSIM_E_LIMIT, "n_maps %d outside [1,%d]", n_maps, DTSIM_MAX_MAPS);
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -646,6 +650,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
 
 int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (!h->d_lut) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
   if ((rmapx == nullptr) != (rmapy == nullptr)) return fail(DTSIM_E_INVALID, "rmapx/rmapy must both be given");
   if (rmapx && !(h->cfg.flags & DTSIM_F_DISTORTION)) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_DISTORTION");
@@ -846,7 +851,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
-    dt_launch_render(h->stream, h->A, R);
+    h->render_tables = dt_launch_render(h->stream, h->A, R, h->render_tables);
   }
   HIPCHK(hipGetLastError());
   if (getenv("DTSIM_DEBUG_QUEUE") || getenv("DTSIM_DEBUG_TIMERS")) {   // profiling aid: how many pixels took the exact MSAA path (DEBUG_TIMERS: without the in-kernel counters)
@@ -1069,6 +1074,19 @@ int xfer_planar(dtsim* h, void* const* bases, int ncomp, size_t elem, void* host
   return DTSIM_OK;
 }
 
+__global__ void k_agent_info(SimArrays A, int e, dtsim_agent_info* out) {
+  const size_t N = A.N;
+  dtsim_agent_info r;
+  r.pos[0] = A.pos_x[e]; r.pos[1] = 0.0; r.pos[2] = A.pos_z[e];
+  r.angle = A.angle[e]; r.speed = A.speed[e]; r.timestamp = A.timestamp[e];
+  r.wheels[0] = A.wheels[e]; r.wheels[1] = A.wheels[N + e];
+  for (int k = 0; k < 4; ++k) r.lane[k] = A.lane[(size_t)k * N + e];
+  r.prox = A.prox[e]; r.reward = A.reward[e];
+  r.tile[0] = A.tile_i[e]; r.tile[1] = A.tile_j[e]; r.step_count = A.step_count[e];
+  r.in_lane = A.in_lane[e]; r.done = A.done[e]; r.done_code = A.done_code[e]; r.pad = 0;
+  *out = r;
+}
+
 int field_xfer(dtsim* h, int field, void* host, size_t bytes, bool to_host) {
   if (!h || !host) return fail(DTSIM_E_INVALID, "null argument");
   const size_t need = public_bytes(h, field);
@@ -1108,6 +1126,18 @@ int field_xfer(dtsim* h, int field, void* host, size_t bytes, bool to_host) {
   }
 }
 }  // namespace
+
+int dtsim_read_agent(dtsim_t* h, int env, dtsim_agent_info* out) {
+  if (!h || !out) return fail(DTSIM_E_INVALID, "null argument");
+  if (env < 0 || env >= h->N) return fail(DTSIM_E_INVALID, "env %d out of range [0, %d)", env, h->N);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (!h->d_agent) HIPCHK(hipMalloc(&h->d_agent, sizeof(dtsim_agent_info)));
+  hipLaunchKernelGGL(k_agent_info, dim3(1), dim3(1), 0, h->stream, h->A, env, h->d_agent);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, h->d_agent, sizeof(dtsim_agent_info), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return DTSIM_OK;
+}
 
 int dtsim_read(dtsim_t* h, int field, void* dst, size_t bytes) { return field_xfer(h, field, dst, bytes, true); }
 int dtsim_write(dtsim_t* h, int field, const void* src, size_t bytes) {

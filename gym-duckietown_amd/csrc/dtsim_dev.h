@@ -228,7 +228,9 @@ struct RenderParams {
   void* pixtab;                 // [H*W] PixTab (16 B) then [H*W] SampTab (48 B): per-pixel tables of the shared camera
 };
 
-void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R);
+// tables: bit 0 = the per-pixel tables (k_pix_setup), bit 1 = block boxes / object ranges (k_blk_setup) are valid from an
+// earlier launch (they depend on the camera LUT and the maps only); returns the bits that are valid after this launch.
+int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, int tables);
 
 #ifndef DT_OBS_STAGE_ROWS
 #define DT_OBS_STAGE_ROWS 8

@@ -1425,7 +1425,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DT_Q_ABL_NOPHASE2
+    for (int l0 = 0; l0 < 0; l0 += 64) {
+#else
     for (int l0 = 0; l0 < n_list; l0 += 64) {          // wave-uniform
+#endif
       const bool have = l0 + lane < n_list;
       const uint32_t le = have ? w_list[l0 + lane] : 0u;
       const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
@@ -2249,7 +2253,7 @@ __global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam
 
 }  // namespace
 
-void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) {
+int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, int tables) {
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
@@ -2258,12 +2262,13 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
   const bool obj = R.max_tris > 0;
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
-  int32_t* pos = (quad && R.envpos) ? R.envpos : nullptr;
+  int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos);
   if (R.max_tris > 0) {
-    hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
+    if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
+    tables |= 2;
     hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams, pos);
   }
   (void)hipMemsetAsync(R.work, 0, 4 * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj
@@ -2281,7 +2286,8 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
     const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
     PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
-    hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
+    if (!(tables & 1)) hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
+    tables |= 1;
 #define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
@@ -2303,4 +2309,5 @@ void dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R) 
       hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, 1, pos ? envq : (const EnvQ*)nullptr);
     }
   }
+  return tables;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
@@ -41,7 +41,7 @@ EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_step_ex", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_observe", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read_agent", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -129,6 +129,16 @@ class Probe(C.Structure):
     ]
 
 
+class AgentInfo(C.Structure):
+    """dtsim_agent_info: what Simulator.step returns about one env besides the observation."""
+    _fields_ = [
+        ("pos", C.c_double * 3), ("angle", C.c_double), ("speed", C.c_double), ("timestamp", C.c_double),
+        ("wheels", C.c_double * 2), ("lane", C.c_double * 4), ("prox", C.c_double), ("reward", C.c_double),
+        ("tile", C.c_int32 * 2), ("step_count", C.c_int32),
+        ("in_lane", C.c_uint8), ("done", C.c_uint8), ("done_code", C.c_uint8), ("pad", C.c_uint8),
+    ]
+
+
 _lib = None
 
 
@@ -175,6 +185,7 @@ def load(path: str | None = None):
         "dtsim_reset_done": (ci, [vp]),
         "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),
         "dtsim_query": (ci, [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double, C.POINTER(Probe)]),
+        "dtsim_read_agent": (ci, [vp, ci, C.POINTER(AgentInfo)]),
         "dtsim_read": (ci, [vp, ci, vp, sz]),
         "dtsim_write": (ci, [vp, ci, vp, sz]),
         "dtsim_field_devptr": (vp, [vp, ci]),

@@ -96,6 +96,7 @@ class BatchedSimulator:
         # Assets come from `asset_root` (or $DTSIM_ASSET_ROOT: a duckietown-world style data tree with
         # MapFormat1 YAML maps, tiles-processed/<style>/<kind>/texture.* and <kind>.obj/.mtl meshes)
         # with the deterministic fixtures of dtsim/assets.py as the fallback.
+        self.state_version = 0
         self.library = assets.AssetLibrary(asset_root, style)
         use_lib = self.library if self.library.root else None
         names = [map_name] if isinstance(map_name, str) else list(map_name)
@@ -314,6 +315,7 @@ class BatchedSimulator:
     def reset(self, mask: Optional[np.ndarray] = None, states=None):
         """Simulator.reset() for the masked envs (None = all).  `states`: optional
         ctypes array / list of _ffi.InitState to use instead of sampling (parity mode)."""
+        self.state_version += 1                       # any cached read-back of the state is stale now
         if not self._have_reset:
             mask = None                        # the first reset creates every env's world
         if self.device_reset and states is None:
@@ -336,6 +338,7 @@ class BatchedSimulator:
 
     def reset_done(self):
         """Restart (device sampler) every env whose done flag is set; asynchronous, no host round trip."""
+        self.state_version += 1                       # any cached read-back of the state is stale now
         _ffi.check(self._lib, self._lib.dtsim_reset_done(self._h))
 
     def field_device(self, field: int) -> DeviceArray:
@@ -384,6 +387,7 @@ class BatchedSimulator:
         """actions: [n_steps, N, 2] or [N, 2] (float32, or float64 with actions_f64);
         numpy array (host) or an object with __cuda_array_interface__ (device).
         flags: _ffi.STEP_ONE_UPDATE (one update_physics, no frame_skip) / _ffi.STEP_POSE_ONLY (`_update_pos`)."""
+        self.state_version += 1                       # any cached read-back of the state is stale now
         if hasattr(actions, "__cuda_array_interface__"):
             ptr = actions.__cuda_array_interface__["data"][0]
             _ffi.check(self._lib, self._lib.dtsim_step_ex(self._h, C.c_void_p(ptr), int(n_steps), 1, int(flags)))
@@ -510,7 +514,14 @@ class BatchedSimulator:
         _ffi.check(self._lib, self._lib.dtsim_read(self._h, field, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def read_agent(self, env: int = 0) -> "_ffi.AgentInfo":
+        """dtsim_read_agent: pose, speed, wheels, lane pose, proximity, reward / done of one env in one transfer."""
+        out = _ffi.AgentInfo()
+        _ffi.check(self._lib, self._lib.dtsim_read_agent(self._h, int(env), C.byref(out)))
+        return out
+
     def write(self, field: int, arr: np.ndarray):
+        self.state_version += 1                       # any cached read-back of the state is stale now
         if field == _ffi.FIELD_STATE_BLOB:
             a = np.ascontiguousarray(arr, np.uint8)
         else:

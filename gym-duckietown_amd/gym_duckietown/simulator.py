@@ -193,8 +193,25 @@ class Simulator(_EnvBase):
         self.start_pose = mt.start_pose
 
     # ---------------------------------------------------------------- state views --
+    # fields of dtsim_agent_info: one transfer per state version instead of one dtsim_read per value
+    _SNAP = {
+        _ffi.FIELD_POS: lambda a: np.array(a.pos, np.float64), _ffi.FIELD_ANGLE: lambda a: np.float64(a.angle),
+        _ffi.FIELD_SPEED: lambda a: np.float64(a.speed), _ffi.FIELD_TIMESTAMP: lambda a: np.float64(a.timestamp),
+        _ffi.FIELD_WHEELS: lambda a: np.array(a.wheels, np.float64), _ffi.FIELD_LANE: lambda a: np.array(a.lane, np.float64),
+        _ffi.FIELD_PROX: lambda a: np.float64(a.prox), _ffi.FIELD_REWARD: lambda a: np.float64(a.reward),
+        _ffi.FIELD_TILE: lambda a: np.array(a.tile, np.int32), _ffi.FIELD_STEP_COUNT: lambda a: np.int32(a.step_count),
+        _ffi.FIELD_IN_LANE: lambda a: np.uint8(a.in_lane), _ffi.FIELD_DONE: lambda a: np.uint8(a.done),
+        _ffi.FIELD_DONE_CODE: lambda a: np.uint8(a.done_code),
+    }
+
     def _f(self, field):
-        return self._sim.read(field)[0]
+        get = self._SNAP.get(field)
+        if get is None:
+            return self._sim.read(field)[0]
+        snap = getattr(self, "_snapshot", None)
+        if snap is None or snap[0] != self._sim.state_version:
+            snap = self._snapshot = (self._sim.state_version, self._sim.read_agent(0))
+        return get(snap[1])
 
     if gym is None:
         @property

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 5
+#define DTSIM_ABI_VERSION 6
 
 /* error codes */
 #define DTSIM_OK 0
@@ -359,6 +359,20 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
  * compute_reward, _inconvenient_spawn.  poses: [n][3] = x, z, angle.  Synchronous. */
 int dtsim_query(dtsim_t* h, int n, const int32_t* env_idx, const double* poses,
                 double safety_factor, dtsim_probe* out);
+
+/* Everything Simulator.step hands back about ONE env besides the observation -- cur_pos / cur_angle / speed /
+ * timestamp (simulator.py:1551-1584), _compute_done_reward (:1685-1705), get_agent_info (:1586-1612) -- gathered
+ * on the device and copied with one transfer (a 1-env gym loop otherwise pays one dtsim_read per value).
+ * Synchronous. */
+typedef struct dtsim_agent_info {
+  double pos[3], angle, speed, timestamp;
+  double wheels[2];         /* last [left, right] duty passed to the dynamics */
+  double lane[4];           /* dist, dot_dir, angle_deg, angle_rad (0 if not in lane) */
+  double prox, reward;
+  int32_t tile[2], step_count;
+  uint8_t in_lane, done, done_code, pad;
+} dtsim_agent_info;
+int dtsim_read_agent(dtsim_t* h, int env, dtsim_agent_info* out);
 
 int dtsim_read(dtsim_t* h, int field, void* dst, size_t bytes);   /* synchronous D2H */
 int dtsim_write(dtsim_t* h, int field, const void* src, size_t bytes);

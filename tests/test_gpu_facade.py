@@ -321,3 +321,23 @@ def test_vel_steer_env_reports_the_wheel_duties_as_last_action():
     assert np.allclose(info["Simulator"]["action"], wheels, atol=1e-12)
     assert np.allclose(env.last_action, wheels, atol=1e-12) and np.allclose(env.wheelVels, wheels * env.robot_speed, atol=1e-12)
     env.close()
+
+
+def test_read_agent_matches_the_field_reads():
+    """dtsim_read_agent (one transfer) against the per-field reads it replaces in the 1-env gym loop."""
+    from dtsim import BatchedSimulator, _ffi
+    sim = BatchedSimulator("loop_dyn_duckiebots", 5, render=False, domain_rand=False, seed=3)
+    sim.step(np.random.default_rng(1).uniform(0.1, 0.9, (7, 5, 2)).astype(np.float32), n_steps=7)
+    for e in (0, 3, 4):
+        a = sim.read_agent(e)
+        assert np.array_equal(np.array(a.pos), sim.read(_ffi.FIELD_POS)[e])
+        assert a.angle == sim.read(_ffi.FIELD_ANGLE)[e] and a.speed == sim.read(_ffi.FIELD_SPEED)[e]
+        assert a.timestamp == sim.read(_ffi.FIELD_TIMESTAMP)[e] and a.step_count == sim.read(_ffi.FIELD_STEP_COUNT)[e]
+        assert np.array_equal(np.array(a.wheels), sim.read(_ffi.FIELD_WHEELS)[e])
+        assert np.array_equal(np.array(a.lane), sim.read(_ffi.FIELD_LANE)[e])
+        assert a.prox == sim.read(_ffi.FIELD_PROX)[e] and a.reward == sim.read(_ffi.FIELD_REWARD)[e]
+        assert np.array_equal(np.array(a.tile), sim.read(_ffi.FIELD_TILE)[e])
+        assert (a.in_lane, a.done, a.done_code) == (sim.read(_ffi.FIELD_IN_LANE)[e], sim.read(_ffi.FIELD_DONE)[e], sim.read(_ffi.FIELD_DONE_CODE)[e])
+    with pytest.raises(Exception):
+        sim.read_agent(5)
+    sim.close()
