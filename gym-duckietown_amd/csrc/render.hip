@@ -1839,7 +1839,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
       //     the record does not hold), untextured tiles, the horizon band, and the textured cells the cell-granular
       //     test rejected (conservative by up to a cell; k_resolve redoes it exactly on compacted lanes, which is
       //     cheaper than refining here at a few live lanes per wavefront).
-      const EnvFast g = fasts[env];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const unsigned long long sk = candm[k] & ~fastm[k];
@@ -1850,7 +1849,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         if (gm) {
           const float lrk = (k & 1) ? lr2[k / 2].y : lr2[k / 2].x, lfk = (k & 1) ? lf2[k / 2].y : lf2[k / 2].x;
           const float mrgk = __half2float(__ushort_as_half((unsigned short)(Mi[k] >> 16)));
-          const EnvCam c = cams[env];
+          const EnvFast g = fasts[env];              // scalar loads, only on this (ground beyond the map) path: a load at the
+          const EnvCam c = cams[env];                // top of the slow branch would be waited for by every LDS access after it
           const float wx = c.Cx + lrk * c.sa + lfk * c.ca, wz = c.Cz + lrk * c.ca - lfk * c.sa;          // tile-plane hit, world
           const float wxg = fmaf(g.kg, wx - c.Cx, c.Cx), wzg = fmaf(g.kg, wz - c.Cz, c.Cz);              // ground-quad hit
           // every sample's tile-plane hit stays clear of the grid rectangle (an absent tile inside the grid goes to

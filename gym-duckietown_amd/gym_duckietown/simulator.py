@@ -296,12 +296,12 @@ class Simulator(_EnvBase):
         action = np.clip(action, -1, 1) if self._ACTION_MODE == "wheels" else np.asarray(action)
         action = np.array(action, dtype=np.float64)
         self._sim.step(action.reshape(1, 2))
+        obs = self.render_obs()                      # launched right behind the step: one wait for both kernels
         # Simulator.step receives the clipped wheel duties [u_l, u_r] (DuckietownEnv.step computes them from
         # (vel, steering), envs/duckietown_env.py:36-61); update_physics keeps them as last_action / wheelVels (:1555, 1564)
         wheels = np.array(self._f(_ffi.FIELD_WHEELS), dtype=np.float64)
         self.last_action = wheels
         self.wheelVels = wheels * self.robot_speed
-        obs = self.render_obs()
         misc = self.get_agent_info()
         d = self._compute_done_reward()
         misc["Simulator"]["msg"] = d.done_why
