@@ -91,7 +91,6 @@ struct dtsim {
   uint32_t* d_rtiles = nullptr;
   TileLds* d_tilerecs = nullptr;
   ScreenTri* d_stris = nullptr;
-  ObjEnv* d_objenv = nullptr;
   ObjBox* d_objbox = nullptr;
   void* d_objmask = nullptr;    // block boxes [tiles*4][4] floats, then object masks [N][tiles*4] u64
   std::vector<uint32_t> h_pool;       // host copy of the RGBA8 pool (quad blocks are built from it at dtsim_set_maps)
@@ -277,7 +276,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objenv, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -614,14 +613,12 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
   if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
-  if (h->d_objenv) { (void)hipFree(h->d_objenv); h->d_objenv = nullptr; }
   if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
   if (h->d_objmask) { (void)hipFree(h->d_objmask); h->d_objmask = nullptr; }
   h->max_tris = 0;
   for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
   if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
     HIPCHK(hipMalloc(&h->d_stris, sizeof(ScreenTri) * (size_t)h->max_tris * h->N));
-    HIPCHK(hipMalloc(&h->d_objenv, sizeof(ObjEnv) * (size_t)h->N));
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
     HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
@@ -830,7 +827,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.segment = segment ? 1 : 0; R.mesh_seg = h->d_mesh_seg;
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
-  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objenv = h->d_objenv; R.objbox = h->d_objbox;
+  R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objbox = h->d_objbox;
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
   R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
   R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;

@@ -155,7 +155,6 @@ struct alignas(16) ScreenTri {
   int32_t tex;               // texture index of the material chunk, -1 = untextured
 };
 static_assert(sizeof(ScreenTri) == 128, "ScreenTri is 128 bytes");
-struct ObjEnv { int32_t n_tris; float bx0, bx1, by0, by1; int32_t n_obj, pad[2]; };   // union box of the env's live triangles
 struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };          // screen box + triangle range of one object
 
 // raster work decomposition: a workgroup owns a DT_TILE_W x DT_TILE_H pixel tile for 32 consecutive envs
@@ -204,7 +203,6 @@ struct RenderParams {
   // mesh objects: per-env screen-space triangles written by the object setup kernel
   int32_t max_tris, segment;    // triangle slots per env (max over maps), 0 = no objects anywhere; segment: DTSIM_RENDER_SEGMENT
   ScreenTri* stris;             // [N][max_tris]
-  ObjEnv* objenv;               // [N]
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
   float* blockbox;              // [raster tiles * 4][4] source-pixel bounding box of each raster wavefront block (k_blk_setup)
   unsigned long long* objmask;  // [N][raster tiles * 4] objects whose screen box meets the block (bit o), written by k_obj_setup

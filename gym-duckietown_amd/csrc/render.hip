@@ -332,7 +332,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   const EnvCam c = cams[e];
   const RenderMapDev m = R.maps[c.map_id];
   ScreenTri* out = R.stris + (size_t)e * R.max_tris;
-  float bx0 = 1e30f, bx1 = -1e30f, by0 = 1e30f, by1 = -1e30f;
   // per-object screen boxes: LDS min / max through the order-preserving float -> int map
   __shared__ int s_obox[DTSIM_MAX_OBJECTS][4];
   __shared__ float s_oboxf[DTSIM_MAX_OBJECTS][4];
@@ -414,7 +413,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     st.index = t;
     out[t] = st;
     if (ok) {
-      bx0 = fminf(bx0, st.bx0); bx1 = fmaxf(bx1, st.bx1); by0 = fminf(by0, st.by0); by1 = fmaxf(by1, st.by1);
       atomicMin(&s_obox[obj][0], f2ord(st.bx0)); atomicMax(&s_obox[obj][1], f2ord(st.bx1));
       atomicMin(&s_obox[obj][2], f2ord(st.by0)); atomicMax(&s_obox[obj][3], f2ord(st.by1));
     }
@@ -446,23 +444,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
         if (!(bb.y < s_oboxf[o][0] || bb.x > s_oboxf[o][1] || bb.w < s_oboxf[o][2] || bb.z > s_oboxf[o][3])) mk |= 1ull << o;
       R.objmask[(size_t)(pos ? pos[e] : e) * n_blk + b] = mk;   // indexed by position in the render order
     }
-  }
-  __shared__ float red[4][256];
-  red[0][tid] = bx0; red[1][tid] = bx1; red[2][tid] = by0; red[3][tid] = by1;
-  __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
-    if (tid < sft) {
-      red[0][tid] = fminf(red[0][tid], red[0][tid + sft]); red[1][tid] = fmaxf(red[1][tid], red[1][tid + sft]);
-      red[2][tid] = fminf(red[2][tid], red[2][tid + sft]); red[3][tid] = fmaxf(red[3][tid], red[3][tid + sft]);
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    ObjEnv oe;
-    oe.n_tris = red[1][0] >= red[0][0] ? m.n_tris : 0;
-    oe.bx0 = red[0][0]; oe.bx1 = red[1][0]; oe.by0 = red[2][0]; oe.by1 = red[3][0];
-    oe.n_obj = m.n_obj; oe.pad[0] = oe.pad[1] = 0;
-    R.objenv[e] = oe;
   }
 }
 
@@ -893,6 +874,49 @@ __device__ inline PixInv pix_inv(float nx, float ny, bool valid, float tx, float
   return p;
 }
 
+// Per-env camera (domain randomisation): the same quantities per (pixel, env), with everything that only depends on
+// the env folded into DrCam once per env, and the MSAA reach as a cheaper upper bound -- kappa = rho / (1 - rho) <=
+// rho + (4/3) rho^2 for rho <= 1/4 (beyond that the pixel takes the exact path anyway), and both sample-offset terms of
+// pix_inv are bounded by (ax + ry)^2 + fy^2.  A larger reach only sends more pixels to the exact path.
+struct DrCam { float tx, ty, a1, a2, sth, cth, Cy, dy, cex, eys, kgc, ndl_dir; bool directional; };
+
+__device__ inline DrCam dr_cam(const EnvCam& c, float ex_n, float ey_n) {
+  DrCam d;
+  d.tx = c.tx; d.ty = c.ty; d.a1 = c.ty * c.cth; d.a2 = c.ty * c.sth; d.sth = c.sth; d.cth = c.cth; d.Cy = c.Cy;
+  const float ey = ey_n * c.ty;
+  d.dy = ey * fabsf(c.cth); d.cex = ex_n * c.tx; d.eys = ey * fabsf(c.sth);
+  d.kgc = (c.Cy - GROUND_Y) / c.Cy;
+  d.directional = c.L[3] == 0.f;
+  d.ndl_dir = fmaxf(c.cth * c.L[1] + c.sth * c.L[2], 0.f);
+  return d;
+}
+
+__device__ inline PixInv pix_inv_dr(float nx, float ny, bool valid, const DrCam& d, const float L[4]) {
+  PixInv p;
+  p.flags = valid ? PF_VALID : 0u;
+  p.lr = p.lf = p.ndl = p.mrg = 0.f;
+  const float xe = nx * d.tx, yla = fmaf(ny, d.a1, -d.sth), fwd = fmaf(ny, d.a2, d.cth);
+  if (!(yla < 0.f)) {
+    p.flags |= (yla - d.dy >= 0.f) ? PF_SKY : PF_ALWAYS_EDGE;
+    return p;
+  }
+  const float inv = frcp(-yla);
+  const float t = d.Cy * inv;
+  p.lr = t * xe; p.lf = t * fwd;
+  if (d.directional) p.ndl = d.ndl_dir;             // wave-uniform: the DR light is a direction (simulator.py:565-584)
+  else { Ray r; r.xe = xe; r.ye = ny * d.ty; r.yla = yla; r.fwd = fwd; p.ndl = plane_ndl(L, d.sth, d.cth, r, t); }
+  const float rho = d.dy * inv;
+  const float kappa = fmaf(rho * 1.3334f, rho, rho);
+  const float sx = fmaf(fabsf(p.lr), kappa, t * d.cex), fy = fmaf(fabsf(p.lf), kappa, t * d.eys);
+  p.mrg = 1.05f * fsqrt_(fmaf(sx, sx, fy * fy));
+  const float tg = t * d.kgc;
+  if (t >= NEAR_Z && t <= FAR_Z) p.flags |= PF_TILE_OK;
+  if (tg >= NEAR_Z && tg <= FAR_Z) p.flags |= PF_GROUND_OK;
+  if (rho > 0.25f || tg * (1.f + 2.f * rho) > FAR_Z * 0.98f || t * (1.f - 2.f * rho) < NEAR_Z * 1.02f)
+    p.flags |= PF_ALWAYS_EDGE;
+  return p;
+}
+
 // Edge-pixel queue: one fixed region per (workgroup, wavefront) of the raster launch, worst-case
 // sized (every pixel of every env of the chunk), so appends need no atomics; entry =
 // (env-in-chunk << 8) | (row-slot k << 6 | lane).  k_resolve drains the regions 64 entries at a time.
@@ -1003,9 +1027,10 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
     if (DR) {
       const EnvCam c = cams[e];
       base0 = c.base[0]; base1 = c.base[1]; base2 = c.base[2]; dif0 = c.dif[0]; dif1 = c.dif[1]; dif2 = c.dif[2];
+      const DrCam dc = dr_cam(c, ex_n, ey_n);
 #pragma unroll
       for (int k = 0; k < PPT; ++k)
-        pv[k] = pix_inv(nx[k], ny[k], ok[k], c.tx, c.ty, c.sth, c.cth, c.Cy, c.L, ex_n, ey_n);
+        pv[k] = pix_inv_dr(nx[k], ny[k], ok[k], dc, c.L);
     }
     const uint32_t hor_rgb = f.hor_rgb;
     const float A = f.A, B = f.B, Cxi = f.Cxi, Czi = f.Czi;
