@@ -251,7 +251,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
       if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
-      if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * (DT_ITEMS_PER_WG + 4) * sizeof(uint32_t));   // k_resolve's list + k_resolve_obj's (4 per workgroup)
+      if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * (DT_ITEMS_PER_WG + DT_ENVS_PER_BLOCK) * sizeof(uint32_t));   // k_resolve's list + k_resolve_obj's (at most one per env of a workgroup)
       if (e == hipSuccess) e = hipMalloc(&h->d_qend, n_wg * 4 * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }

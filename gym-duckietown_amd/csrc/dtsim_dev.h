@@ -213,7 +213,7 @@ struct RenderParams {
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
   int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj; zeroed per render
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
-  uint32_t* items2;             // [workgroups * 4] work items of k_resolve_obj: raster workgroup * DT_ITEMS_PER_WG + env octet
+  uint32_t* items2;             // [workgroups * DT_ENVS_PER_BLOCK] work items of k_resolve_obj: raster workgroup * DT_ITEMS_PER_WG + env group
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
   // quad-layout fast path (null qtex: the generic k_raster is used)
   const uint8_t* qtex;          // quad blocks, 16 B records

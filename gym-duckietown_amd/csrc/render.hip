@@ -924,7 +924,10 @@ __device__ inline PixInv pix_inv_dr(float nx, float ny, bool valid, const DrCam&
 #define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
 #define GRAB_MAX 16       // work items per cursor atomic, at most
-#define RES_ENVS 8        // env positions of a chunk per k_resolve_obj work item
+#ifndef DT_RES_ENVS
+#define DT_RES_ENVS 8
+#endif
+#define RES_ENVS DT_RES_ENVS  // env positions of a chunk per k_resolve_obj work item
 static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITEMS_PER_WG, "octet items");
 
 // Work items of k_resolve_obj (its own list: R.work[2] = count, [3] = cursor; second part of R.items): one per RES_ENVS
