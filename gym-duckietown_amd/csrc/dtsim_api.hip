@@ -314,6 +314,11 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
   h->h_tex.clear();
   if (int rc = build_texel_pool(textures, n_textures, pool, &h->h_tex)) return rc;
   h->h_pool = pool;
+  // the quad-layout blocks were built from the OLD texel pool (dtsim_set_maps): drop them, so that the generic raster
+  // (which reads d_texels) is used until the next dtsim_set_maps rebuilds them -- never a frame mixing both pools
+  if (h->d_qtex) { (void)hipFree(h->d_qtex); h->d_qtex = nullptr; }
+  if (h->d_qtiles) { (void)hipFree(h->d_qtiles); h->d_qtiles = nullptr; }
+  h->n_qtiles = 0; h->qlog2 = 0;
   if (h->d_texels_seg) { (void)hipFree(h->d_texels_seg); h->d_texels_seg = nullptr; }   // mirrors the old list
   if (h->d_texels) { (void)hipFree(h->d_texels); h->d_texels = nullptr; }
   if (h->d_tex) { (void)hipFree(h->d_tex); h->d_tex = nullptr; }

@@ -713,6 +713,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
   if (e >= N) return;
   const double dt = P.delta_time;
   const bool pose_only = (P.step_flags & DTSIM_STEP_POSE_ONLY) != 0;     // `_update_pos` (simulator.py:2076-2088)
+  // update_physics (simulator.py:1551) and _update_pos (:2076) take the wheel pair as given: the (vel, steering)
+  // kinematics are DuckietownEnv.step's (envs/duckietown_env.py:36-61) and np.clip is Simulator.step's (:1670)
+  const bool raw_wheels = (P.step_flags & (DTSIM_STEP_ONE_UPDATE | DTSIM_STEP_POSE_ONLY)) != 0;
   const int n_updates = (P.step_flags & (DTSIM_STEP_ONE_UPDATE | DTSIM_STEP_POSE_ONLY)) ? 1 : P.frame_skip;
 
   for (int s = 0; s < P.n_steps; ++s) {
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     if (P.actions_f64) { a0 = ((const double*)actions)[aoff]; a1 = ((const double*)actions)[aoff + 1]; }
     else { a0 = (double)((const float*)actions)[aoff]; a1 = (double)((const float*)actions)[aoff + 1]; }
     double left, right;
-    if (P.action_mode == DTSIM_ACTION_VEL_STEER && !pose_only) {
+    if (P.action_mode == DTSIM_ACTION_VEL_STEER && !raw_wheels) {
       const double vel = a0, steer = a1, baseline = A.wheel_dist[e];
       const double k_r_inv = (P.gain + P.trim) / P.k, k_l_inv = (P.gain - P.trim) / P.k;
       const double omega_r = (vel + 0.5 * steer * baseline) / P.radius;
@@ -752,11 +755,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       right = fmax(fmin(u_r, P.limit), -P.limit);
       left = fmax(fmin(u_l, P.limit), -P.limit);
     } else { left = a0; right = a1; }
-    if (!pose_only) {
+    if (!raw_wheels) {
       left = fmin(fmax(left, -1.0), 1.0);   // np.clip(action, -1, 1) simulator.py:1670 (Simulator.step only)
       right = fmin(fmax(right, -1.0), 1.0);
-      A.wheels[e] = left; A.wheels[(size_t)N + e] = right;
     }
+    if (!pose_only) { A.wheels[e] = left; A.wheels[(size_t)N + e] = right; }
 
     // ---- frame_skip x update_physics (simulator.py:1551-1584)
     Dyn q = {A.q_x[e], A.q_y[e], A.q_c[e], A.q_s[e], A.vel_u[e], A.vel_w[e]};

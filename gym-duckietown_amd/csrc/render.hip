@@ -2286,7 +2286,9 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
-  const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0;
+  // (S = 256 tables carry the v_perm cell selector of the S256 kernels, which need a padded grid under 256 tiles)
+  const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
+                    !(R.qlog2 == 8 && R.qmax_tiles >= 256);
   const bool obj = R.max_tris > 0;
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env

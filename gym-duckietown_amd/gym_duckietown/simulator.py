@@ -204,6 +204,10 @@ class Simulator(_EnvBase):
         _ffi.FIELD_DONE_CODE: lambda a: np.uint8(a.done_code),
     }
 
+    # fields the reference derives from cur_pos / cur_angle ON DEMAND (get_agent_info :1586, _compute_done_reward :1685)
+    _DERIVED = (_ffi.FIELD_LANE, _ffi.FIELD_PROX, _ffi.FIELD_REWARD, _ffi.FIELD_TILE, _ffi.FIELD_IN_LANE, _ffi.FIELD_DONE,
+                _ffi.FIELD_DONE_CODE)
+
     def _f(self, field):
         get = self._SNAP.get(field)
         if get is None:
@@ -211,7 +215,32 @@ class Simulator(_EnvBase):
         snap = getattr(self, "_snapshot", None)
         if snap is None or snap[0] != self._sim.state_version:
             snap = self._snapshot = (self._sim.state_version, self._sim.read_agent(0))
+        if field in self._DERIVED and getattr(self, "_pose_written", False):
+            return self._derived_at_written_pose(snap[1])[field]
         return get(snap[1])
+
+    def _derived_at_written_pose(self, a):
+        """`env.cur_pos = ...` / `env.cur_angle = ...` (the reference's `_update_pos` call pattern, :1558) only writes the
+        pose; the snapshot's tile / lane / proximity / reward / done are those of the last step.  The reference evaluates
+        them from the current pose whenever asked, so after a pose write they come from dtsim_query at that pose
+        (_compute_done_reward :1685-1705: invalid pose, then max_steps, then compute_reward)."""
+        cache = getattr(self, "_derived_cache", None)
+        if cache is not None and cache[0] == self._sim.state_version:
+            return cache[1]
+        pr = self._probe(np.array(a.pos, np.float64), float(a.angle))
+        in_lane = bool(pr["in_lane"])
+        lane = np.array([pr["dist"], pr["dot_dir"], pr["angle_deg"], pr["angle_rad"]], np.float64) if in_lane else np.zeros(4)
+        if not pr["valid"]:
+            done, code, reward = 1, 1, REWARD_INVALID_POSE
+        elif int(a.step_count) >= self.max_steps:
+            done, code, reward = 1, 2, 0.0
+        else:
+            done, code, reward = 0, 0, float(pr["reward"])
+        d = {_ffi.FIELD_LANE: lane, _ffi.FIELD_PROX: np.float64(pr["prox"]), _ffi.FIELD_REWARD: np.float64(reward),
+             _ffi.FIELD_TILE: np.array([pr["tile_i"], pr["tile_j"]], np.int32), _ffi.FIELD_IN_LANE: np.uint8(in_lane),
+             _ffi.FIELD_DONE: np.uint8(done), _ffi.FIELD_DONE_CODE: np.uint8(code)}
+        self._derived_cache = (self._sim.state_version, d)
+        return d
 
     if gym is None:
         @property
@@ -239,6 +268,7 @@ class Simulator(_EnvBase):
         arr = self._sim.read(_ffi.FIELD_POS).copy()
         arr[0] = np.asarray(pos, np.float64)
         self._sim.write(_ffi.FIELD_POS, arr)
+        self._pose_written = True                      # derived views now come from dtsim_query at this pose
 
     @property
     def cur_angle(self):
@@ -249,6 +279,7 @@ class Simulator(_EnvBase):
         arr = self._sim.read(_ffi.FIELD_ANGLE).copy()
         arr[0] = float(angle)
         self._sim.write(_ffi.FIELD_ANGLE, arr)
+        self._pose_written = True
 
     @property
     def speed(self):
@@ -277,6 +308,7 @@ class Simulator(_EnvBase):
         self._viewers = {}
 
     def reset(self, segment: bool = False):
+        self._pose_written = False
         self._sim.reset()
         if int(self._sim.env_map[0]) != self._map_idx:   # randomize_maps_on_reset: _load_map(map_name) (simulator.py:541-544)
             self._bind_map(int(self._sim.env_map[0]))
@@ -295,6 +327,7 @@ class Simulator(_EnvBase):
     def step(self, action: np.ndarray):
         action = np.clip(action, -1, 1) if self._ACTION_MODE == "wheels" else np.asarray(action)
         action = np.array(action, dtype=np.float64)
+        self._pose_written = False                     # the step recomputes every derived field on the device
         self._sim.step(action.reshape(1, 2))
         obs = self.render_obs()                      # launched right behind the step: one wait for both kernels
         # Simulator.step receives the clipped wheel duties [u_l, u_r] (DuckietownEnv.step computes them from
@@ -479,9 +512,9 @@ class Simulator(_EnvBase):
             raise NotImplementedError("update_physics(delta_time != env.delta_time)")
         action = np.asarray(action, np.float64)
         self.wheelVels = action * self.robot_speed * 1
-        mode = self._ACTION_MODE
-        self._sim.step(action.reshape(1, 2), flags=_ffi.STEP_ONE_UPDATE)
-        self.last_action = action if mode == "wheels" else np.array(self._f(_ffi.FIELD_WHEELS), dtype=np.float64)
+        self._pose_written = False
+        self._sim.step(action.reshape(1, 2), flags=_ffi.STEP_ONE_UPDATE)   # the wheel pair as given (no kinematics, no clip)
+        self.last_action = action
 
     def get_agent_info(self) -> dict:
         info = {"action": list(self.last_action)}

@@ -307,6 +307,8 @@ int dtsim_step(dtsim_t* h, const void* actions, int n_steps, int actions_on_devi
 
 /* dtsim_step with flags; dtsim_step(...) == dtsim_step_ex(..., 0).
  *   DTSIM_STEP_ONE_UPDATE  one `Simulator.update_physics(action)` (simulator.py:1551-1584) per step: like dtsim_step but
+ *                          the action is the wheel pair update_physics takes -- no (vel, steering) kinematics
+ *                          (DuckietownEnv.step's) and no np.clip (Simulator.step's, :1670) -- and
  *                          frame_skip is not applied (step_count += 1, timestamp += delta_time, speed, every object
  *                          stepped once; reward / done are refreshed for the new state -- they are pure functions of it,
  *                          `_compute_done_reward` :1685 evaluates them on demand in the reference).

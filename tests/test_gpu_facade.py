@@ -263,6 +263,35 @@ def test_update_physics_and_update_pos_follow_the_reference_semantics():
     assert np.array_equal(env._sim.read(_ffi.FIELD_OBJ_CENTER)[0], obj_c)  # objects not stepped
     env.cur_pos, env.cur_angle = pos, ang                               # the reference's call pattern (:1558)
     assert np.array_equal(env.cur_pos, pos) and env.cur_angle == ang
+    # after a pose write the reference derives reward / done / lane from the NEW pose on demand (:1685, :1586)
+    o.cur_pos, o.cur_angle = opos, o.state.angle()
+    d2, r2, _ = o._compute_done_reward()
+    dr2 = env._compute_done_reward()
+    assert dr2.done == d2 and abs(dr2.reward - r2) < 1e-9
+    off = np.array([env.cur_pos[0] + 3.0, 0.0, env.cur_pos[2]])         # far off the road: invalid pose
+    env.cur_pos = off
+    o.cur_pos = off
+    d3, r3, _ = o._compute_done_reward()
+    dr3 = env._compute_done_reward()
+    assert d3 and dr3.done and dr3.reward == r3 == -1000 and dr3.done_code == "invalid-pose"
+    env.close()
+
+
+def test_update_physics_takes_the_wheel_pair_unclipped_in_every_action_mode():
+    """simulator.py:1551: update_physics integrates the wheel pair it is handed -- the (vel, steering) kinematics are
+    DuckietownEnv.step's (envs/duckietown_env.py:36-61) and np.clip(action, -1, 1) is Simulator.step's (:1670).  So
+    DuckietownEnv.update_physics([l, r]) must equal Simulator.update_physics([l, r]), also beyond [-1, 1]."""
+    from gym_duckietown.envs import DuckietownEnv
+    env = DuckietownEnv(map_name="small_loop", domain_rand=False, seed=4, camera_width=64, camera_height=48)
+    o = make_oracle("small_loop", domain_rand=False, seed=4)
+    assert np.array_equal(env.cur_pos, o.cur_pos)
+    for a in (np.array([0.6, 0.2]), np.array([1.4, -1.2]), np.array([-0.3, 0.9])):
+        for _ in range(4):
+            env.update_physics(a)
+            o.update_physics(a)
+        assert np.allclose(env.cur_pos, o.cur_pos, atol=1e-9) and abs(env.cur_angle - o.cur_angle) < 1e-9, a
+        assert np.array_equal(env.last_action, a) and np.allclose(env.wheelVels, a * env.robot_speed)
+        assert np.allclose(env._sim.read(_ffi.FIELD_WHEELS)[0], a)
     env.close()
 
 
