@@ -252,13 +252,13 @@ def main():
     N, K, Wm = args.envs, args.steps, args.warmup
     variant = {
         "c3": dict(maps="small_loop", dr=False, label="Duckietown-small_loop-v0 (fixture)", ref="configs[2]",
-                   kern="k_env_sort + k_raster_q<OBJ=0> (exact path of the edge pixels inside; k_pix_setup tables cached)", extra={}),
+                   kern="k_env_sort + k_raster_v3<OBJ=0> (exact path of the edge pixels inside; k_pix_setup tables cached)", extra={}),
         "c4": dict(maps="loop_pedestrians", dr=True, label="Duckietown-loop_pedestrians-v0 (stand-in: loop_only_duckies with "
                    "static: False, 8 walking duckies), dynamic obstacles + domain randomisation", ref="configs[3]",
                    kern="k_obj_setup + k_raster<DR=1,OBJ=1> + k_resolve + k_resolve_obj", extra={}),
         "c5": dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, label="MultiMap-v0 (loop_only_duckies / "
                    "small_loop_only_duckies alternating per env slot, multimap_env.py:17,44-49)", ref="configs[4]",
-                   kern="k_env_sort + k_obj_setup + k_raster_q<OBJ=1> + k_resolve_obj", extra=dict(map_cycle=True)),
+                   kern="k_env_sort + k_obj_setup + k_raster_v3<OBJ=1> + k_resolve_obj", extra=dict(map_cycle=True)),
     }[args.config]
     sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=True, camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
@@ -297,6 +297,16 @@ def main():
     t_local = time.perf_counter() - t0
     n_r, ms_r = sim.profile_read(_ffi.KERNEL_RENDER)
     n_s, ms_s = sim.profile_read(_ffi.KERNEL_STEP)
+    # run-to-run spread of the render pass: a separate short series AFTER the timed region, one HIP-event reading per launch
+    per_launch = []
+    for t in range(min(K, 16)):
+        one_step(Wm + (t % K))
+        sim.sync()
+        n1, ms1 = sim.profile_read(_ffi.KERNEL_RENDER)
+        if n1 == 1:
+            per_launch.append(ms1)
+    sim.profile_read(_ffi.KERNEL_STEP)
+    per_launch.sort()
     tt = torch.tensor([t_local], device="cpu" if one_gpu else dev, dtype=torch.float64)
     if dist.is_initialized():
         dist.barrier()
@@ -310,11 +320,15 @@ def main():
         # wrap the whole command): they are read from the committed summary of the same command's counter runs and
         # labelled with where they came from; null when that file is for another workload.
         traffic = traffic_source = valu = None
+        traffic_why = "profiles/raster_pmc_latest.json not found"
         pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
         if os.path.exists(pj):
             try:
                 d = json.load(open(pj))
+                traffic_why = (f"the committed counter summary is for config c3 at {d.get('envs')} envs per GPU; this run is "
+                               f"{args.config} at {N}: PMC passes wrap the whole command (rocprofv3), they cannot be taken in-process")
                 if d.get("envs") == N and args.config == "c3":
+                    traffic_why = None
                     traffic = d.get("hbm_bytes_per_launch")
                     traffic_source = d.get("source")
                     if d.get("valu_per_pixel") is not None:
@@ -324,6 +338,21 @@ def main():
                                 "achieved_lane_ops_per_s": d["valu_per_pixel"] * N * W * H / (k_ms * 1e-3)}
             except Exception:
                 pass
+        # the reference's own lane / collision / reward functions per call.  They need /root/reference,
+        # which the bench box does not have: the numbers recorded in the build container are reported, labelled as such.
+        ref_fn = {"status": "not runnable on the bench box (no /root/reference)"}
+        rj = os.path.join(ROOT, "profiles", "reference_function_timings.json")
+        if os.path.exists(rj):
+            try:
+                rd = json.load(open(rj))
+                ref_fn = {"status": "recorded, not measured in this run", "us_per_call": rd.get("us_per_call"), "where": rd.get("where"),
+                          "what": rd.get("what"), "recipe": "oracle/time_reference_functions.py"}
+            except Exception:
+                pass
+        cfg_extra = {}
+        if args.config in ("c4", "c5"):   # object placement of the 8x7 loop maps depends on the reading of get_transform (absent package)
+            cfg_extra["get_transform"] = ("README semantics (duckietown_world absent: object rows of the 8x7 loop maps differ by one tile under the "
+                                          "reference's grid_width call, tests/test_transform_readings.py)")
         line = {
             "metric": "env-steps/sec (4096 envs, 640x480 RGB) at 1/2/4/8 MI355X; % HBM roofline",
             "value": world * N * K / t_max,
@@ -341,12 +370,17 @@ def main():
                                    f"distortion, domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
                                    f"auto-reset from spawn pool [BASELINE.json {variant['ref']}]",
                        "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
-                       "parallelism": f"env-sharded x{world}, no data-path collective"},
+                       "parallelism": f"env-sharded x{world}, no data-path collective", **cfg_extra},
             "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_null_reason": traffic_why,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
+                         "kernel_ms_per_launch": ({"min": per_launch[0], "median": per_launch[len(per_launch) // 2], "max": per_launch[-1],
+                                                   "n": len(per_launch), "source": "separate series after the timed region, one HIP-event reading per launch"}
+                                                  if per_launch else None),
                          "step_kernel_ms": ms_s / max(n_s, 1), "valu": valu},
             "cpu_baseline": cpu_,
+            "reference_functions": ref_fn,
             "gather": gather_,
             "episodes_per_env": done_frac,
             "setup_s": t_setup,
@@ -397,32 +431,23 @@ def main():
             # that the exchange of step t overlaps the simulation of step t+1 (the sim runs on its own HIP stream;
             # only the buffer about to be overwritten is waited for)
             try:
-                bufs = [torch.empty_like(frames) for _ in range(2)]
-                roots = [[torch.empty_like(frames) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-                works = [None, None]
+                from dtsim.sharding import ShardedSimulator
+                ss = ShardedSimulator.wrap(sim, world * N, rank, world)     # the product API: dtsim/sharding.py
                 kp = min(K, 6)
                 sync_all()
                 tg = time.perf_counter()
                 for t in range(kp):
-                    b = t % 2
-                    if works[b] is not None:
-                        works[b].wait()
-                        torch.cuda.current_stream().synchronize()
-                    sim.bind_frames(bufs[b].data_ptr())
-                    one_step(Wm + t)
-                    sim.sync()
-                    works[b] = dist.gather(bufs[b], roots[b], dst=0, async_op=True)
-                for w in works:
-                    if w is not None:
-                        w.wait()
+                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True)
+                ss.flush_gather(dst=0)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
                 sim.bind_frames(None)
                 tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
                 dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
                 gather["to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
-                                                "collective": "gather(uint8 frames, dst=0), double-buffered against the next step"}
-                del bufs, roots
+                                                "collective": "ShardedSimulator.step_render_gather(overlap=True): gather(uint8 frames, dst=0), "
+                                                              "two buffers rotating through dtsim_bind_frames, the exchange of step t behind step t+1"}
+                del ss
             except Exception as ex:
                 sim.bind_frames(None)
                 gather["to_root_overlapped"] = {"error": repr(ex)[:200]}

@@ -98,6 +98,8 @@ struct dtsim {
   uint8_t* d_qtex = nullptr;          // quad-layout blocks for k_raster_q
   uint32_t* d_qtiles = nullptr;
   int n_qtiles = 0, qlog2 = 0;
+  int q3_rows = 0;                    // k_raster_v3: LDS table rows (largest padded grid height), 0 = its layout limits are exceeded
+  bool raster_old = false;            // DTSIM_RASTER_OLD=1 at dtsim_create: keep k_raster_q (A/B timing only)
   float q_per_m = 0.f;
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
@@ -220,6 +222,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(DTSIM_E_INVALID, "device %d out of range", cfg->device);
   HIPCHK(hipSetDevice(cfg->device));
   dtsim* h = new dtsim();
+  { const char* ro = getenv("DTSIM_RASTER_OLD"); h->raster_old = ro && ro[0] == '1'; }   // A/B timing aid: k_raster_q instead of k_raster_v3
   h->cfg = *cfg;
   h->N = cfg->num_envs;
   if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }
@@ -318,7 +321,7 @@ int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, 
   // (which reads d_texels) is used until the next dtsim_set_maps rebuilds them -- never a frame mixing both pools
   if (h->d_qtex) { (void)hipFree(h->d_qtex); h->d_qtex = nullptr; }
   if (h->d_qtiles) { (void)hipFree(h->d_qtiles); h->d_qtiles = nullptr; }
-  h->n_qtiles = 0; h->qlog2 = 0;
+  h->n_qtiles = 0; h->qlog2 = 0; h->q3_rows = 0;
   if (h->d_texels_seg) { (void)hipFree(h->d_texels_seg); h->d_texels_seg = nullptr; }   // mirrors the old list
   if (h->d_texels) { (void)hipFree(h->d_texels); h->d_texels = nullptr; }
   if (h->d_tex) { (void)hipFree(h->d_tex); h->d_tex = nullptr; }
@@ -607,13 +610,18 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   for (void* p : olds) if (p) (void)hipFree(p);
   h->d_blobs = nullptr; h->d_dyn = nullptr; h->d_rmaps = nullptr; h->d_rtiles = nullptr; h->d_robjs = nullptr;
   h->d_tilerecs = nullptr; h->d_qtex = nullptr; h->d_qtiles = nullptr;
-  h->n_qtiles = 0; h->qlog2 = 0; h->q_per_m = 0.f;
+  h->n_qtiles = 0; h->qlog2 = 0; h->q_per_m = 0.f; h->q3_rows = 0;
   if (qlog2 > 0 && !qtiles.empty()) {
     HIPCHK(hipMalloc(&h->d_qtex, qblocks.size() * 4));
     HIPCHK(hipMemcpy(h->d_qtex, qblocks.data(), qblocks.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&h->d_qtiles, qtiles.size() * 4));
     HIPCHK(hipMemcpy(h->d_qtiles, qtiles.data(), qtiles.size() * 4, hipMemcpyHostToDevice));
     h->n_qtiles = (int)qtiles.size() / 2; h->qlog2 = qlog2; h->q_per_m = q_per_m;
+    // ---- k_raster_v3 (render_v3.inc) reads the same pool and table through its own LDS layout: S = 256, padded grids up
+    // to 32 x 24 tiles, up to 4 maps
+    int rows = 0, cols = 0;
+    for (int mi = 0; mi < n_maps; ++mi) { rows = std::max(rows, maps[mi].grid_h + 2 * DT_QRING); cols = std::max(cols, maps[mi].grid_w + 2 * DT_QRING); }
+    if (qlog2 == 8 && rows <= 24 && cols <= 32 && n_maps * 32 <= 128 && !h->raster_old) h->q3_rows = rows;
   }
   HIPCHK(hipMalloc(&h->d_tilerecs, std::max<size_t>(trecs.size(), 1) * sizeof(TileLds)));
   if (!trecs.empty()) HIPCHK(hipMemcpy(h->d_tilerecs, trecs.data(), trecs.size() * sizeof(TileLds), hipMemcpyHostToDevice));
@@ -847,6 +855,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
   R.qtex = h->d_qtex; R.qtiles = h->d_qtiles; R.n_qtiles = h->n_qtiles; R.qlog2 = h->qlog2; R.q_per_m = h->q_per_m;
   R.pixtab = h->d_pixtab;
+  R.q3_rows = h->q3_rows;
   R.envpos = reinterpret_cast<int32_t*>((char*)h->d_envcam + (size_t)h->N * (128 + 64 + 64));
   R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
   R.qmax_tiles = 0;
@@ -865,6 +874,13 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
       if (tc[3]) fprintf(stderr, "[dtsim] k_raster_q phase cycles per wavefront iteration: issue %.0f, wait for quads %.0f, filter+slow+transpose %.0f  (%llu iterations)\n",
                          (double)tc[0] / tc[3], (double)tc[1] / tc[3], (double)tc[2] / tc[3], tc[3]);
       HIPCHK(hipMemset(dbgp, 0, sizeof tc));
+      unsigned long long t3[8];                      // DT_V3_TIMING build variant: k_raster_v3 phase cycles (second KB of the scratch)
+      HIPCHK(hipMemcpy(t3, dbgp + 512, sizeof t3, hipMemcpyDeviceToHost));
+      if (t3[7]) fprintf(stderr, "[dtsim] k_raster_v3 cycles per wavefront iteration (wall clock of the wavefront): issue %.0f, store+prefetch %.0f, "
+                         "wait for the records %.0f, weights+filter %.0f, transpose %.0f, slow+append %.0f; whole iteration %.0f  (%llu iterations)\n",
+                         (double)t3[0] / t3[7], (double)t3[1] / t3[7], (double)t3[2] / t3[7], (double)t3[3] / t3[7], (double)t3[4] / t3[7],
+                         (double)t3[5] / t3[7], (double)t3[6] / t3[7], t3[7]);
+      HIPCHK(hipMemset(dbgp + 512, 0, sizeof t3));
       unsigned long long tr[13];                     // DT_RES_TIMING build variant: k_resolve phase cycles
       HIPCHK(hipMemcpy(tr, dbgp + 64, sizeof tr, hipMemcpyDeviceToHost));
       if (tr[8]) fprintf(stderr, "[dtsim] k_resolve cycles per wavefront: total %.0f = item setup %.0f + entry load %.0f + mesh stream %.0f + z-buffer %.0f + shade %.0f; "

@@ -164,6 +164,9 @@ struct ObjBox { float bx0, bx1, by0, by1; int32_t first, count, pad[2]; };      
 #ifndef DT_PPT
 #define DT_PPT 4                           // pixels per lane: a wavefront's block is 64 * DT_PPT pixels
 #endif
+#ifndef DT_V3_WW
+#define DT_V3_WW 128                       // k_raster_v3 (render_v3.inc): pixel columns of ITS wavefront block (128 / 64 / 32); the workgroup tile stays 128 x 8
+#endif
 #define DT_TILE_W DT_WAVE_W
 #define DT_TILE_H (4 * (64 * DT_PPT / DT_WAVE_W))  // 4 wavefronts stacked vertically
 #ifndef DT_ENVS_PER_BLOCK
@@ -224,6 +227,8 @@ struct RenderParams {
   int32_t* envpos;              // [N] position of each env in the render order (k_env_sort)
   void* dump;                   // 1 KB scratch: masked lanes of the unconditional frame store write here
   void* pixtab;                 // [H*W] PixTab (16 B) then [H*W] SampTab (48 B): per-pixel tables of the shared camera
+  int32_t q3_rows;              // k_raster_v3 (render_v3.inc): rows of its LDS tile table (largest padded grid height); 0: k_raster_q is used
+  int32_t pad3_;
 };
 
 // tables: bit 0 = the per-pixel tables (k_pix_setup), bit 1 = block boxes / object ranges (k_blk_setup) are valid from an

@@ -272,7 +272,8 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
       const float r = fminf(fminf(q.Cx, xmax - q.Cx), fminf(q.Cz, zmax - q.Cz)) - 2.f;
       q.reach = r > 0.f ? (uint32_t)fminf(r, 1.0e9f) : 0u;      // NaN / outside the padded grid -> 0: always clamp
     }
-    q.env = (uint32_t)e; q.pad[0] = q.pad[1] = 0u;
+    q.env = (uint32_t)e; q.pad[1] = 0u;
+    q.pad[0] = (uint32_t)c.map_id * (32u * 4u);     // k_raster_v3: byte offset of the map's columns inside an LDS table row (V3_MAP_COLS entries)
     envq[pos ? pos[e] : e] = q;
   }
 }
@@ -1340,7 +1341,10 @@ __device__ inline void quad_filter3(const uint4& q, float ax, float az, float I,
 }
 
 #define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
-template <bool S256>
+// V3: the LDS tile table layout of k_raster_v3 (render_v3.inc: block offset at (tz << 10 | tx << 2) + the map's column
+// offset EnvQ.pad[0], the cell selector 512 bytes behind it) and its wavefront block shape; (tile_x0, wave_y0) is the
+// origin of the wavefront's block either way.
+template <bool S256, bool V3 = false>
 __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __restrict__ cams, const EnvQ* __restrict__ envq,
                                       const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
                                       const uint8_t* __restrict__ qtex, const uint32_t* s_qt, uint32_t* w_list,
@@ -1351,6 +1355,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   const uint32_t SM = (1u << LS) - 1u;
   const float Sf = (float)(1 << LS), lo = 0.5f * Sf;
   const char* qtb = reinterpret_cast<const char*>(s_qt);
+  constexpr int WWc = V3 ? DT_V3_WW : WAVE_W;          // pixel columns of the wavefront block the entries index
+  const uint32_t tex_min = 32u;                        // block offsets from here on are textured tiles
 
   // Table entry (block byte offset, cell selector) of the tile that OWNS padded quad coordinates (X, Z): tile
   // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
@@ -1360,6 +1366,10 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
     const float Xc = med3f(X - 0.5f, lo, Xhi), Zc = med3f(Z - 0.5f, lo, Zhi);
     const uint32_t ti = (uint32_t)flr_i32(Xc) >> LS, tj = (uint32_t)flr_i32(Zc) >> LS;
     ox = (float)(ti << LS) + 0.5f; oz = (float)(tj << LS) + 0.5f;
+    if (V3) {
+      ta = (tj << 10) + (ti << 2) + tab_b;
+      return make_uint2(*reinterpret_cast<const uint32_t*>(qtb + ta), *reinterpret_cast<const uint32_t*>(qtb + ta + 512));
+    }
     ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
     return *reinterpret_cast<const uint2*>(qtb + ta);
   };
@@ -1404,7 +1414,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + u * 64 + lane) : 0u;
         el[u] = (int)(ent >> 8);
         const int lp = (int)(ent & 255u);
-        pix[u] = (wave_y0 + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;
+        pix[u] = (wave_y0 + lp / WWc) * R.W + tile_x0 + lp % WWc;
       }
       float4 qa[U];
       uint4 qb[U];
@@ -1414,6 +1424,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
         qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
         qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
+        if (V3) qb[u].z = fq->pad[0];
         env[u] = (int)fq->env;
       }
 #pragma unroll
@@ -1429,7 +1440,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const float ux = Xu[u] - ox, uz = Zu[u] - oz;        // in [0, S) inside the owner tile
         const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
         const bool in_range = Xu[u] - 0.5f >= lo && Xu[u] - 0.5f <= Xhi && Zu[u] - 0.5f >= lo && Zu[u] - 0.5f <= Zhi;
-        interior[u] = have[u] && in_range && te_c[u].x >= 32u && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
+        interior[u] = have[u] && in_range && te_c[u].x >= tex_min && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
       }
       uint4 qc[U];
 #pragma unroll
@@ -1465,7 +1476,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       const SampTab sp = samptab[pix];
       const EnvQ* fq = envq + min(e0 + el, R.N - 1);
       const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
-      const uint32_t tab_b = fq->tab_b, pitch4 = fq->pitch4;
+      const uint32_t tab_b = V3 ? fq->pad[0] : fq->tab_b, pitch4 = fq->pitch4;
       const int e = (int)fq->env;
       const EnvCam* c = cams + e;
       const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
@@ -2016,6 +2027,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
   }
 }
 
+#include "render_v3.inc"
+
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
@@ -2321,7 +2334,19 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
 #define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
-    if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
+    // k_raster_v3 (render_v3.inc): S = 256 textures, padded grids up to 32 x 24 tiles, up to 4 maps (else k_raster_q)
+    const bool v3 = R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= V3_MAX_ROWS && R.n_maps * V3_MAP_COLS <= V3_TAB_PITCH / 2 &&
+                    (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP == 0));
+    if (v3) {
+      const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
+#define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, R.frames, R.qtex, \
+                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
+#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP == 0
+      if (obj) LAUNCH_V3(true); else
+#endif
+      LAUNCH_V3(false);
+#undef LAUNCH_V3
+    } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
     else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
 #undef LAUNCH_Q
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path

@@ -1,0 +1,119 @@
+"""GPU parity AT the BASELINE.json configurations themselves (not at reduced sizes / with parts switched off):
+
+  C3  configs[2]: small_loop, 4096 envs, 640x480 + fisheye -- >= 64 envs of the 4096-env batch, stratified over the
+      render order (one per (tile under the camera, heading quadrant) bin of k_env_sort: the first and the last of the
+      order, every XCD slice), rendered by the oracle DIRECTLY (no transitive small batch);
+  C4  configs[3]: loop_pedestrians, domain randomisation + fisheye, 640x480, after 260 steps (duckies mid-walk);
+  C5  configs[4]: MultiMap, both *_only_duckies maps alternating per env slot, 640x480 + fisheye, shared camera:
+      k_raster_v3<OBJ> + k_resolve_obj over more than one env chunk.
+
+Reference: simulator.py:1707-1951 (_render_img), objects.py:384-431 (DuckieObj.step), envs/multimap_env.py:44-49.
+Same thresholds as tests/test_gpu_render.py (stated there); the oracle is oracle/raster.py in its "pixel" lighting mode.
+"""
+import numpy as np
+import pytest
+
+from dtsim import BatchedSimulator, _ffi
+from dtsim import distortion as pdist
+from oracle import raster
+from test_gpu_render import _camera, _obj_states, _scene, _stats
+
+pytestmark = pytest.mark.gpu
+W, H = 640, 480
+
+
+def test_c3_full_size_batch_matches_oracle_directly():
+    N = 4096
+    sim = BatchedSimulator("small_loop", N, camera_width=W, camera_height=H, distortion=True, domain_rand=False, seed=5,
+                           action_mode="vel_steer")
+    acts = np.random.default_rng(0).uniform(-1, 1, (12, N, 2)).astype(np.float32)
+    sim.step(acts, n_steps=12)
+    sim.render()
+    sim.sync()
+    pos, ang = sim.read(_ffi.FIELD_POS), sim.read(_ffi.FIELD_ANGLE)
+    # the sort key of k_env_sort (render.hip): tile under the camera centre and heading quadrant
+    ts = 0.585
+    cx, cz = pos[:, 0] + 0.066 * np.cos(ang), pos[:, 2] - 0.066 * np.sin(ang)
+    ti, tj = np.clip(np.floor(cx / ts), 0, 31).astype(int), np.clip(np.floor(cz / ts), 0, 31).astype(int)
+    quad = np.floor(ang * (2.0 / np.pi) + 0.5).astype(int) & 3
+    key = (((tj << 5) | ti) << 2) | quad
+    order = np.argsort(key, kind="stable")
+    picks = []
+    for k in np.unique(key):                               # one env per bin: first, last and every slice of the order
+        picks.append(int(np.nonzero(key == k)[0][0]))
+    rng = np.random.default_rng(1)
+    picks += [int(order[0]), int(order[-1]), 0, N - 1, 31, 32]
+    picks += [int(order[i]) for i in range(N // 16, N, N // 8)]    # the middle of each XCD's eighth of the order
+    while len(set(picks)) < 64:
+        picks.append(int(rng.integers(N)))
+    picks = sorted(set(picks))
+    assert len(picks) >= 64
+    import torch
+    frames = torch.as_tensor(sim.frames_device(), device="cuda:0")
+    sub = frames[torch.as_tensor(np.array(picks), device="cuda:0")].cpu().numpy()
+    scene = _scene("small_loop")
+    rmap = pdist.distortion_maps(W, H)
+    worst = dict(frac_gt1=0.0, frac_gt2=0.0, mean=0.0)
+    for k, e in enumerate(picks):
+        ref = raster.render_obs(_camera(sim, e, W, H, False), scene, "pixel", rmap)
+        s = _stats(sub[k], ref)
+        assert s["frac_gt1"] <= 1e-3 and s["frac_gt2"] <= 5e-4 and s["mean"] <= 0.02, (e, s)
+        for f in worst:
+            worst[f] = max(worst[f], s[f])
+    print("C3 4096-env batch, %d envs against the oracle: worst" % len(picks), worst)
+    sim.close()
+
+
+def test_c4_config_matches_oracle():
+    """loop_pedestrians + domain randomisation + fisheye at 640x480 after the duckies started walking."""
+    N, steps = 4, 260
+    sim = BatchedSimulator("loop_pedestrians", N, camera_width=W, camera_height=H, distortion=True, domain_rand=True,
+                           seed=31, max_steps=100000)
+    sim.step(np.zeros((steps, N, 2), np.float32), n_steps=steps)
+    assert sim.read(_ffi.FIELD_OBJ_ACTIVE).any()           # somebody is walking
+    sim.render()
+    frames = sim.frames_host()
+    scene = _scene("loop_pedestrians")
+    rmap = pdist.distortion_maps(W, H)
+    n_obj_px = 0
+    for e in range(N):
+        cam = _camera(sim, e, W, H, True)
+        st = _obj_states(sim, e, scene)
+        ref = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
+        no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
+        n_obj_px += int((np.abs(ref.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
+        s = _stats(frames[e], ref)
+        assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, s)
+    assert n_obj_px > 200, n_obj_px
+    sim.close()
+
+
+def test_c5_config_matches_oracle():
+    """MultiMap: two maps alternating per env slot, shared camera, fisheye, more than one env chunk."""
+    N = 72
+    names = ["loop_only_duckies", "small_loop_only_duckies"]
+    sim = BatchedSimulator(names, N, camera_width=W, camera_height=H, distortion=True, domain_rand=False, seed=17,
+                           map_cycle=True, max_steps=100000)
+    # multimap_env.py:44-49: every slot starts on map index 1 and moves on at each of ITS resets: restart the even slots
+    # once more, so that the two maps alternate over the batch as they do in a running MultiMap-v0 job
+    sim.reset(mask=(np.arange(N) % 2 == 0))
+    acts = np.random.default_rng(4).uniform(0.1, 0.6, (6, N, 2)).astype(np.float32)
+    sim.step(acts, n_steps=6)
+    sim.render()
+    frames = sim.frames_host()
+    mid = sim.read(_ffi.FIELD_MAP_ID)
+    assert set(np.unique(mid)) == {0, 1} and mid[0] != mid[1]
+    scenes = [_scene(n) for n in names]
+    rmap = pdist.distortion_maps(W, H)
+    n_obj_px = 0
+    for e in (0, 1, 30, 31, 32, 33, 64, 71):               # both maps, chunk borders, the tail chunk
+        scene = scenes[int(mid[e])]
+        cam = _camera(sim, e, W, H, False)
+        st = _obj_states(sim, e, scene)
+        ref = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
+        no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
+        n_obj_px += int((np.abs(ref.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
+        s = _stats(frames[e], ref)
+        assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, int(mid[e]), s)
+    assert n_obj_px > 200, n_obj_px
+    sim.close()

@@ -268,7 +268,7 @@ def test_update_physics_and_update_pos_follow_the_reference_semantics():
     d2, r2, _ = o._compute_done_reward()
     dr2 = env._compute_done_reward()
     assert dr2.done == d2 and abs(dr2.reward - r2) < 1e-9
-    off = np.array([env.cur_pos[0] + 3.0, 0.0, env.cur_pos[2]])         # far off the road: invalid pose
+    off = np.array([-0.5, 0.0, -0.5])                                   # off the grid: invalid pose
     env.cur_pos = off
     o.cur_pos = off
     d3, r3, _ = o._compute_done_reward()

@@ -40,10 +40,30 @@ class _FakeSim:
 
     def step(self, actions, n_steps=1):
         self.last_actions = np.asarray(actions)
+        self.n_steps_done += n_steps
 
     def frames_tensor(self):
         lo = self.seed - self.BASE
         return _fake_frames(lo, lo + self.n)
+
+    # -- what step_render_gather needs: frames that depend on the step, written into the buffer it is handed
+    n_steps_done = 0
+
+    def render_into(self, buf):
+        """The 'render pass' of step t: every byte is a function of (global env, step), written in two halves with a
+        pause in between -- a gather that read this buffer while it is being rendered into (a torn frame) would ship a
+        mix of two steps."""
+        import time
+        lo = self.seed - self.BASE
+        f = _fake_frames(lo, lo + self.n) + torch.tensor(self.n_steps_done * 13 % 256, dtype=torch.uint8)
+        half = buf.shape[1] // 2
+        buf[:, :half].copy_(f[:, :half])
+        time.sleep(0.02)
+        buf[:, half:].copy_(f[:, half:])
+
+
+def _step_frames(lo, hi, t):
+    return _fake_frames(lo, hi) + torch.tensor(t * 13 % 256, dtype=torch.uint8)
 
 
 def _worker(rank, world, port, total, q):
@@ -81,6 +101,32 @@ def _worker(rank, world, port, total, q):
         ok = ok and bool(torch.equal(allf2, _fake_frames(0, total)))
         rootf = ss.gather_frames(dst=0)
         ok = ok and ((rank == 0 and bool(torch.equal(rootf, _fake_frames(0, total)))) or (rank != 0 and rootf is None))
+        # the learner's loop: gather-to-root of step t overlapped with step t+1, two rotating buffers.
+        # Every frame delivered must be the frame of ITS step, whole (the stand-in renders in two halves with a pause).
+        ss2 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+        a1 = np.zeros((1, total, 2), np.float32)
+        got_steps = []
+        T = 7
+        for t in range(T):
+            tt, fr = ss2.step_render_gather(a1, overlap=True, dst=0)
+            if t == 0:
+                ok = ok and tt is None and fr is None
+                continue
+            ok = ok and tt == t - 1
+            if rank == 0:
+                ok = ok and bool(torch.equal(fr, _step_frames(0, total, tt + 1)))   # step index tt has n_steps_done == tt + 1
+                got_steps.append(tt)
+            else:
+                ok = ok and fr is None
+        tt, fr = ss2.flush_gather(dst=0)
+        ok = ok and tt == T - 1
+        if rank == 0:
+            ok = ok and bool(torch.equal(fr, _step_frames(0, total, T))) and got_steps == list(range(T - 1))
+        # blocking variant: the frames of this very step
+        ss3 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+        for t in range(3):
+            tt, fr = ss3.step_render_gather(a1, overlap=False, dst=0)
+            ok = ok and tt == t and ((rank == 0 and bool(torch.equal(fr, _step_frames(0, total, t + 1)))) or (rank != 0 and fr is None))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
