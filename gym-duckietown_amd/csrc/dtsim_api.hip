@@ -100,6 +100,7 @@ struct dtsim {
   int n_qtiles = 0, qlog2 = 0;
   int q3_rows = 0;                    // k_raster_v3: LDS table rows (largest padded grid height), 0 = its layout limits are exceeded
   bool raster_old = false;            // DTSIM_RASTER_OLD=1 at dtsim_create: keep k_raster_q (A/B timing only)
+  int step_lanes = 1;                 // lanes of a wavefront per env in k_step (physics.hip Coop); DTSIM_STEP_LANES = 1 / 2 / 4 / 8
   float q_per_m = 0.f;
   uint16_t* d_queue = nullptr;
   int32_t* d_qcount = nullptr;
@@ -172,6 +173,7 @@ StepParams step_params(const dtsim* h, int n_steps) {
   P.delta_time = h->cfg.delta_time;
   P.robot_speed = h->cfg.robot_speed;
   P.gain = h->cfg.gain; P.trim = h->cfg.trim; P.radius = h->cfg.radius; P.k = h->cfg.k; P.limit = h->cfg.limit;
+  P.lanes = h->step_lanes;
   return P;
 }
 
@@ -223,6 +225,14 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
   HIPCHK(hipSetDevice(cfg->device));
   dtsim* h = new dtsim();
   { const char* ro = getenv("DTSIM_RASTER_OLD"); h->raster_old = ro && ro[0] == '1'; }   // A/B timing aid: k_raster_q instead of k_raster_v3
+  {  // lanes of a wavefront per env in k_step: as many (up to 4) as keep the launch within ~32 K threads -- a small batch is a
+     // latency problem (one f64 chain per env, 64 wavefronts on 1024 SIMDs at N = 4096), a large one a throughput problem,
+     // where the redundant lanes would cost (profiles/r03_c2_lanes_ab.txt).  DTSIM_STEP_LANES = 1 / 2 / 4 / 8 overrides.
+    const char* sl = getenv("DTSIM_STEP_LANES");
+    int v = sl ? atoi(sl) : 0;
+    if (!(v == 1 || v == 2 || v == 4 || v == 8)) v = cfg->num_envs * 4 <= 32768 ? 4 : cfg->num_envs * 2 <= 32768 ? 2 : 1;
+    h->step_lanes = v;
+  }
   h->cfg = *cfg;
   h->N = cfg->num_envs;
   if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; }

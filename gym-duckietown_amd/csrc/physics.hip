@@ -83,6 +83,24 @@ __device__ inline void proj4(double nx, double nz, const double* c, double& mn, 
 }
 
 // collision.py:129-186: SAT between the agent box (corners ac, axes an) and one OBB.
+// ---- lane co-operation inside one env (DTSIM_STEP_LANES, k_step<SAMPLER, L>) -----------------------------------------
+// With L > 1, L adjacent lanes of a wavefront work on ONE env: everything serial (dynamics, trigonometry, the Bezier
+// bisection) runs redundantly on all of them -- identical inputs, identical results, identical (duplicate) stores -- and
+// the loops over OBJECTS (collision.py:129-186 intersects / intersects_single_obj, simulator.py:1430-1459
+// proximity_penalty2, objects.py step()) are split: lane `sub` takes objects sub, sub + L, ...  Flags are OR-ed and
+// penalties summed over the group with a butterfly of DPP / permute moves, which leaves the same bits in every lane.
+struct Coop { int sub, L; };
+__device__ inline bool grp_any(bool v, const Coop& c) {
+  if (c.L == 1) return v;
+  int x = v ? 1 : 0;
+  for (int d = 1; d < c.L; d <<= 1) x |= __shfl_xor(x, d);
+  return x != 0;
+}
+__device__ inline double grp_sum(double v, const Coop& c) {
+  for (int d = 1; d < c.L; d <<= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
 __device__ inline bool sat_pair(const double* ac, const double* an, const double* oc, const double* on) {
   double a0, a1, b0, b1;
   proj4(an[0], an[1], ac, a0, a1);
@@ -115,28 +133,29 @@ __device__ inline void agent_corners(double px, double pz, double dx, double dz,
 // simulator.py:1473-1492 _collision.  Agent axes = (dir, right): the eigenvectors the
 // reference gets from generate_norm (collision.py:99-106) for the 0.15 x 0.18 box.
 __device__ inline bool collision(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
-                                 const double* ac, double dx, double dz, double rx, double rz) {
+                                 const double* ac, double dx, double dz, double rx, double rz, const Coop co = Coop{0, 1}) {
   const double an[4] = {dx, dz, rx, rz};
   const int ns = m.h->n_static;
-  for (int s = 0; s < ns; ++s) {
+  bool hit = false;
+  for (int s = co.sub; s < ns && !hit; s += co.L) {
     const double* r = m.stat + s * STATIC_WORDS;
-    if (sat_pair(ac, an, r, r + 8)) return true;
+    hit = sat_pair(ac, an, r, r + 8);
   }
   const int nd = m.h->n_dyn;
   const int N = A.N;
-  for (int d = 0; d < nd; ++d) {
+  for (int d = co.sub; d < nd && !hit; d += co.L) {
     double oc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) oc[k] = A.ob_corners[(size_t)(k * DTSIM_MAX_DYNAMIC + d) * N + e];
-    if (sat_pair(ac, an, oc, dyn[d].norm)) return true;
+    hit = sat_pair(ac, an, oc, dyn[d].norm);
   }
-  return false;
+  return grp_any(hit, co);                           // any object: the reference returns on the first hit, same boolean
 }
 
 // simulator.py:1494-1534 _valid_pose, including the second _actual_center inside
 // get_agent_corners (box centred at cur_pos - 0.048 dir).
 __device__ inline bool valid_pose(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
-                                  double px, double pz, double angle, double sf, bool* coll_out) {
+                                  double px, double pz, double angle, double sf, bool* coll_out, const Coop co = Coop{0, 1}) {
   const double ca = cos(angle), sa = sin(angle);
   const double dx = ca, dz = -sa, rx = sa, rz = ca;
   const double cx = px + DT_CENTER_SHIFT * dx, cz = pz + DT_CENTER_SHIFT * dz;
@@ -145,14 +164,14 @@ __device__ inline bool valid_pose(const MapView& m, const SimArrays& A, const Dy
                             drivable_pos(m, cx + w * rx, cz + w * rz) && drivable_pos(m, cx + l * dx, cz + l * dz);
   double ac[8];
   agent_corners(cx, cz, dx, dz, rx, rz, ac);
-  const bool coll = collision(m, A, dyn, e, ac, dx, dz, rx, rz);
+  const bool coll = collision(m, A, dyn, e, ac, dx, dz, rx, rz, co);
   if (coll_out) *coll_out = coll;
   return (!coll) && all_drivable;
 }
 
 // simulator.py:1430-1459 proximity_penalty2 + collision.py:189-211 + objects.py:373-382
 __device__ inline double proximity(const MapView& m, const SimArrays& A, const DynInit* dyn, int e,
-                                   double px, double pz, double angle) {
+                                   double px, double pz, double angle, const Coop co = Coop{0, 1}) {
   const double cx = px + DT_CENTER_SHIFT * cos(angle), cz = pz + DT_CENTER_SHIFT * (-sin(angle));
   const double r1 = DT_AGENT_SAFETY_RAD;
   double total = 0.0;
@@ -160,7 +179,7 @@ __device__ inline double proximity(const MapView& m, const SimArrays& A, const D
   if (ns > 0) {
     bool gate = false;
     double sum = 0.0;
-    for (int s = 0; s < ns; ++s) {
+    for (int s = co.sub; s < ns; s += co.L) {
       const double* r = m.stat + s * STATIC_WORDS;
       const double ddx = r[12] - cx, ddz = r[13] - cz;
       const double d = sqrt((ddx * ddx + 0.0) + ddz * ddz);
@@ -170,16 +189,20 @@ __device__ inline double proximity(const MapView& m, const SimArrays& A, const D
       const double score = (d - r1) - r2;
       if (score < 0) sum += score;
     }
+    if (co.L > 1) { gate = grp_any(gate, co); sum = grp_sum(sum, co); }
     total = gate ? sum : 0.0;
   }
   const int nd = m.h->n_dyn;
   const int N = A.N;
-  for (int d = 0; d < nd; ++d) {
+  double dsum = 0.0;
+  for (int d = co.sub; d < nd; d += co.L) {
     const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddy = 0.0 - A.ob_cy[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
     const double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);     // |agent_pos - center| in 3-D (objects.py:373-382, 525)
     const double score = (dist - r1) - dyn[d].safety_radius;
-    total += fmin(0.0, score);
+    if (co.L == 1) total += fmin(0.0, score);        // the reference's order of additions
+    else dsum += fmin(0.0, score);
   }
+  if (co.L > 1) total += grp_sum(dsum, co);          // (another order of the same additions: within 1 ulp of the sum)
   return total;
 }
 
@@ -703,12 +726,14 @@ __device__ inline int sampler_next_map(const dtsim_reset_sampler& rs, int n_maps
   return cur;
 }
 
-template <bool SAMPLER>
+template <bool SAMPLER, int L>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, StepParams P, const void* actions,
                                                      const dtsim_init_state* pool) {
   extern __shared__ uint64_t lds[];
   const uint64_t* blobs = stage_maps(M, lds);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = gt / L;                              // L adjacent lanes per env (Coop above); L = 1: one thread per env
+  const Coop co{gt % L, L};
   const int N = A.N;
   if (e >= N) return;
   const double dt = P.delta_time;
@@ -786,7 +811,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
       if (pose_only) continue;                         // `_update_pos` stops here
       sc += 1; ts_ += dt;
       speed = sqrt((ddx * ddx + 0.0) + ddz * ddz) / dt;
-      for (int d = 0; d < m.h->n_dyn; ++d) {          // simulator.py:1571-1584
+      for (int d = co.sub; d < m.h->n_dyn; d += L) {  // simulator.py:1571-1584; one object per lane of the env's group
         if (dyn[d].kind == 2) duckiebot_step(A, m, dyn[d], d, e, dt);
         else if (dyn[d].kind == 3) checker_step(A, d, e, dt);
         else duckie_step(A, dyn[d], d, e, dt, SAMPLER ? P.sampler : nullptr, sc);
@@ -812,13 +837,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     tile_at(m, px, pz, ti, tj);
     A.tile_i[e] = ti; A.tile_j[e] = tj;
     const Lane Ln = lane_pos(m, px, pz, ang);
-    const double prox = proximity(m, A, dyn, e, px, pz, ang);
+    if (L > 1) __threadfence_block();                // the objects were stepped by different lanes of the group
+    const double prox = proximity(m, A, dyn, e, px, pz, ang, co);
     A.in_lane[e] = Ln.in_lane;
     A.lane[e] = Ln.dist; A.lane[(size_t)N + e] = Ln.dot_dir;
     A.lane[(size_t)2 * N + e] = Ln.angle_deg; A.lane[(size_t)3 * N + e] = Ln.angle_rad;
     A.prox[e] = prox;
     double reward; uint8_t done, code;
-    if (!valid_pose(m, A, dyn, e, px, pz, ang, 1.0, nullptr)) {
+    if (!valid_pose(m, A, dyn, e, px, pz, ang, 1.0, nullptr, co)) {
       reward = DT_REWARD_INVALID_POSE; done = 1; code = DTSIM_DONE_INVALID_POSE;
     } else if (sc >= P.max_steps) {
       reward = 0.0; done = 1; code = DTSIM_DONE_MAX_STEPS;
@@ -891,9 +917,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_query(SimArrays A, MapSet M, Ste
 
 void dt_launch_step(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,
                     const void* actions, const dtsim_init_state* pool) {
-  const int grid = (A.N + STEP_BLOCK - 1) / STEP_BLOCK;
-  if (P.sampler) hipLaunchKernelGGL(k_step<true>, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
-  else hipLaunchKernelGGL(k_step<false>, dim3(grid), dim3(STEP_BLOCK), (size_t)M.total_words * 8, s, A, M, P, actions, pool);
+  // P.lanes adjacent lanes per env (1, 2, 4 or 8; Coop in this file): more wavefronts for the same envs, object loops split
+  const int L = (P.lanes == 2 || P.lanes == 4 || P.lanes == 8) ? P.lanes : 1;
+  const int grid = (int)(((long long)A.N * L + STEP_BLOCK - 1) / STEP_BLOCK);
+  const size_t lds = (size_t)M.total_words * 8;
+#define LAUNCH_STEP(S_, L_) hipLaunchKernelGGL((k_step<S_, L_>), dim3(grid), dim3(STEP_BLOCK), lds, s, A, M, P, actions, pool)
+  if (P.sampler) { if (L == 8) LAUNCH_STEP(true, 8); else if (L == 4) LAUNCH_STEP(true, 4); else if (L == 2) LAUNCH_STEP(true, 2); else LAUNCH_STEP(true, 1); }
+  else { if (L == 8) LAUNCH_STEP(false, 8); else if (L == 4) LAUNCH_STEP(false, 4); else if (L == 2) LAUNCH_STEP(false, 2); else LAUNCH_STEP(false, 1); }
+#undef LAUNCH_STEP
 }
 
 void dt_launch_reset(hipStream_t s, const SimArrays& A, const MapSet& M, const StepParams& P,

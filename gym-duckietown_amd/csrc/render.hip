@@ -653,6 +653,9 @@ __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, floa
 //                     the per-sample winners are reduced across the wavefront (a handful of pixels of a
 //                     small / distant object, where the pixel-parallel loop would idle most lanes).
 // Depth func LESS with the draw-order tie break, identical in both schedules.
+#ifndef DT_RO_BATCH_CULL
+#define DT_RO_BATCH_CULL 0     // per-batch triangle cull ahead of the per-pixel box tests: measured no gain (profiles/r03_variants_ab.txt, block F)
+#endif
 __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, int lane, float pcx, float pcy,
                                      float wbest[4], int tbest[4], int32_t* dbg) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -695,6 +698,44 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
     // triangle per lane.
     static_assert(TRI_CAP <= 128 && TRI_CAP % 32 == 0, "up to four 32-bit candidate masks");
     uint32_t cand[4] = {0u, 0u, 0u, 0u};
+#if DT_RO_BATCH_CULL
+    // (0) The 64 pixels of a batch are a short piece of one or two frame rows (queue order), while the staged triangles
+    // were culled against the whole unit: first drop, triangle-parallel, the staged triangles whose box misses the
+    // batch's own pixel box -- two triangles per lane, the survivors as scalar bit masks -- so that step (1) only walks
+    // the few triangles that can touch this batch.
+    float bx0 = mine ? pcx : 1e30f, bx1 = mine ? pcx : -1e30f, by0 = mine ? pcy : 1e30f, by1 = mine ? pcy : -1e30f;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      bx0 = fminf(bx0, __shfl_xor(bx0, d)); bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
+      by0 = fminf(by0, __shfl_xor(by0, d)); by1 = fmaxf(by1, __shfl_xor(by1, d));
+    }
+    uint32_t live[4] = {0u, 0u, 0u, 0u};             // wave-uniform: staged triangle j of chunk c can touch the batch
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h * 64 >= fill) break;                     // wave-uniform
+      const int k = h * 64 + lane;
+      bool hit = false;
+      if (k < fill) {
+        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[k]);            // bx0, bx1, by0, by1
+        hit = !(bb.x > bx1 || bb.y < bx0 || bb.z > by1 || bb.w < by0);
+      }
+      const unsigned long long hm = __ballot(hit);
+      live[2 * h] = (uint32_t)hm; live[2 * h + 1] = (uint32_t)(hm >> 32);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t lv = live[c];                         // scalar
+      uint32_t mk = 0u;
+      while (lv) {                                   // wave-uniform: only the triangles that meet the batch's box
+        const int j = __builtin_ctz(lv);
+        lv &= lv - 1u;
+        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[c * 32 + j]);
+        const bool in = (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
+        mk |= in ? (1u << j) : 0u;
+      }
+      cand[c] = mine ? mk : 0u;
+    }
+#else
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c * 32 >= fill) break;                     // wave-uniform
@@ -707,6 +748,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
       }
       cand[c] = mine ? mk : 0u;
     }
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c * 32 >= fill) break;

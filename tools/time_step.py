@@ -1,0 +1,24 @@
+"""Time dtsim_step (physics only) for a given map / N / lanes per env (HIP events around the launches).
+    MAP=loop_pedestrians N=4096 F=32 K=20 DTSIM_STEP_LANES=4 python tools/time_step.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gym-duckietown_amd"))
+import numpy as np
+import torch
+from dtsim import BatchedSimulator, _ffi
+N = int(os.environ.get("N", "4096")); F = int(os.environ.get("F", "32")); K = int(os.environ.get("K", "20"))
+mp = os.environ.get("MAP", "small_loop")
+sim = BatchedSimulator(mp, N, render=False, domain_rand=False, seed=1000, action_mode="vel_steer", auto_reset=True, profile=True,
+                       max_steps=100000)
+sim.make_spawn_pool(min(N, 512))
+acts = torch.rand((F, N, 2), device="cuda:0", dtype=torch.float32) * 1.2 - 0.2
+for _ in range(3):
+    sim.step(acts, n_steps=F)
+sim.sync(); sim.profile_read(_ffi.KERNEL_STEP)
+for _ in range(K):
+    sim.step(acts, n_steps=F)
+sim.sync()
+n, ms = sim.profile_read(_ffi.KERNEL_STEP)
+us = 1e3 * ms / n / F
+print(f"map={mp} N={N} fused={F} lanes={os.environ.get('DTSIM_STEP_LANES', '1')}: {us:.2f} us per step, {N / us:.1f} M env-steps/s; "
+      f"active duckies {int(sim.read(_ffi.FIELD_OBJ_ACTIVE).sum())}, done {int(sim.read(_ffi.FIELD_DONE).sum())}")
