@@ -1517,6 +1517,80 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       const PixTab pt = pixtab[pix];
       const SampTab sp = samptab[pix];
       const EnvQ* fq = envq + min(e0 + el, R.N - 1);
+      if constexpr (V3) {
+        // k_raster_v3's version (round 3): no list of distinct primitives.  The colour of a pixel is the sum over its four
+        // samples of the shade of the sample's primitive AT THE PIXEL CENTRE (GL: graphics.py:172-251), so every tile
+        // sample adds the integer filter of ITS tile's record at the centre cell (same cell index and weights for every
+        // tile: the blocks share one cell grid; a sample that is not on a tile reads the all-zero record 0) to one
+        // accumulator per channel -- 6 v_dot4 per sample, exact -- and sky / ground samples add their colour once per
+        // count.  Tile look-ups go by v_perm like the env loop's; the +-50 m ground-quad test is made in quad coordinates.
+        const float4 qa = *reinterpret_cast<const float4*>(&fq->A);
+        const float A = qa.x, B = qa.y, Cx = qa.z, Cz = qa.w, Xhi = fq->Xhi, Zhi = fq->Zhi;
+        const uint32_t tab = fq->pad[0];
+        const int e = (int)fq->env;
+        const EnvCam* c = cams + e;
+        const float wCy = c->Cy;
+        const float kg = (wCy - GROUND_Y) / wCy;
+        const float qpm = R.maps[c->map_id].inv_tile_size * Sf;            // quad cells per metre of the env's map
+        const float goff = (float)DT_QRING * Sf + 0.5f, ghalf = GROUND_HALF * qpm;   // world 0 and 50 m in padded quad coordinates
+        const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
+        const uint32_t xic = (uint32_t)flr_i32(Xu), zic = (uint32_t)flr_i32(Zu);
+        const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
+        const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
+        uint32_t wl, wh;
+        {
+          const float axI = ax * lit, azI = az * lit;
+          const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (lit - axI) - w01;
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+          const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
+          uint32_t WA, WB;
+          __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
+          wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u); wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
+        }
+        uint32_t aH[3] = {0u, 0u, 0u}, aL[3] = {0u, 0u, 0u};
+        int n_sky = 0, n_gnd = 0;
+        float gX = 0.f, gZ = 0.f;                      // ground hit (quad coordinates) of the lowest-index ground sample
+#pragma unroll
+        for (int s = 3; s >= 0; --s) {
+          const uint32_t hr = sp.dlr[s >> 1], hf = sp.dlf[s >> 1];
+          const float slr = pt.lr + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hr >> 16 : hr)));
+          const float slf = pt.lf + __half2float(__ushort_as_half((unsigned short)((s & 1) ? hf >> 16 : hf)));
+          const float Xs = fmaf(slf, B, fmaf(slr, A, Cx)), Zs = fmaf(slf, -A, fmaf(slr, B, Cz));
+          // the tile that OWNS the sample (ownership on (X - 0.5, Z - 0.5), clamped into the padded grid)
+          const float Xo = Xs - 0.5f, Zo = Zs - 0.5f;
+          const float Xc = med3f(Xo, lo, Xhi), Zc = med3f(Zo, lo, Zhi);
+          const bool s_in = (Xc == Xo) & (Zc == Zo);
+          const uint32_t ta = (__builtin_amdgcn_perm((uint32_t)flr_i32(Zc), (uint32_t)flr_i32(Xc), 0x0c0c0501u) << 2) + tab;
+          const uint32_t* tp = reinterpret_cast<const uint32_t*>(qtb + ta);
+          const uint32_t tb = tp[0], sel = tp[128];
+          const bool is_tile = have & (((sp.flags >> s) & 1u) != 0u) & s_in & (tb != 0u);
+          // ground-quad hit of the sample: camera + kg * (tile-plane hit - camera), inside +-50 m
+          const float Xg = fmaf(kg, Xs - Cx, Cx), Zg = fmaf(kg, Zs - Cz, Cz);
+          const bool is_gnd = have & !is_tile & (((sp.flags >> (4 + s)) & 1u) != 0u) & (fabsf(Xg - goff) <= ghalf) & (fabsf(Zg - goff) <= ghalf);
+          n_gnd += is_gnd; n_sky += !(is_tile | is_gnd);
+          if (is_gnd) { gX = Xg; gZ = Zg; }
+          const uint32_t cell = __builtin_amdgcn_perm(zic, xic, sel);
+          const uint4 rec = *reinterpret_cast<const uint4*>(qtex + (is_tile ? tb + (cell << 4) : 0u));
+          aH[0] = __builtin_amdgcn_udot4(rec.x, wh, aH[0], false); aL[0] = __builtin_amdgcn_udot4(rec.x, wl, aL[0], false);
+          aH[1] = __builtin_amdgcn_udot4(rec.y, wh, aH[1], false); aL[1] = __builtin_amdgcn_udot4(rec.y, wl, aL[1], false);
+          aH[2] = __builtin_amdgcn_udot4(rec.z, wh, aH[2], false); aL[2] = __builtin_amdgcn_udot4(rec.z, wl, aL[2], false);
+        }
+        float acc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] = fmaf((float)n_sky, c->hor[k], (float)((aH[k] << 8) + aL[k]) * (1.f / 65535.f));
+        if (__ballot(n_gnd > 0)) {                     // wave-uniform: shade the ground quad (lit at its corners, bilinear)
+          if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) { gX = fmaf(kg, Xu - Cx, Cx); gZ = fmaf(kg, Zu - Cz, Cz); }   // the centre ray hits the planes
+          const float hs = 0.5f / ghalf;
+          const float a_ = fminf(fmaxf(fmaf(gX - goff, hs, 0.5f), 0.f), 1.f), b_ = fminf(fmaxf(fmaf(gZ - goff, hs, 0.5f), 0.f), 1.f);
+          const float n0 = c->gndl[0] + a_ * (c->gndl[1] - c->gndl[0]), n1 = c->gndl[2] + a_ * (c->gndl[3] - c->gndl[2]);
+          const float ndl = n0 + b_ * (n1 - n0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c->gnd[k] * fminf(c->base[k] + c->dif[k] * ndl, 1.f));
+        }
+        const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
+        if (have) store_rgb(e, pix, pack_rgb(o));
+        continue;
+      }
       const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
       const uint32_t tab_b = V3 ? fq->pad[0] : fq->tab_b, pitch4 = fq->pitch4;
       const int e = (int)fq->env;
@@ -2348,6 +2422,9 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
+#ifdef DT_NO_ENV_SORT     // ablation: envs in index order
+  pos = nullptr;
+#endif
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos);
