@@ -333,9 +333,14 @@ def main():
                     traffic_source = d.get("source")
                     if d.get("valu_per_pixel") is not None:
                         clk = d.get("clock_ghz", 2.1) * 1e9
-                        valu = {"ops_per_pixel": d["valu_per_pixel"], "source": d.get("source"),
-                                "peak_lane_ops_per_s": 1024 * clk / 4 * 64,      # 1024 SIMDs, one wave64 op per 4 cycles (profiles/r02_ubench_valu_rates.txt)
-                                "achieved_lane_ops_per_s": d["valu_per_pixel"] * N * W * H / (k_ms * 1e-3)}
+                        # issue peak as MEASURED on this part (profiles/r02_ubench_valu_rates.txt: the opcodes of this kernel
+                        # sustain one wave64 instruction per ~4.8 cycles per SIMD at 8 wavefronts per SIMD, ~5.4 at 4), at the
+                        # clock the chip holds under this kernel (GRBM_GUI_ACTIVE / duration)
+                        peak = 1024 * clk / 4.8
+                        ach = d["valu_per_pixel"] * N * W * H / 64.0 / (k_ms * 1e-3)
+                        valu = {"ops_per_pixel": d["valu_per_pixel"], "source": d.get("source"), "unit": "wave64 instructions/s",
+                                "peak": peak, "achieved": ach, "frac": ach / peak,
+                                "peak_basis": "1024 SIMDs x clock / 4.8 cycles per instruction (measured issue rate, profiles/r02_ubench_valu_rates.txt)"}
             except Exception:
                 pass
         # the reference's own lane / collision / reward functions per call.  They need /root/reference,

@@ -114,6 +114,15 @@ struct alignas(16) EnvQ {
   uint32_t pad[2];
 };
 static_assert(sizeof(EnvQ) == 64, "EnvQ is 64 bytes");
+// k_raster_v3's per-env constants, in render order: the transform as PAIRS (the scalar operand of a v_pk_fma_f32 is two
+// consecutive scalar registers: loaded as pairs they need no s_mov), everything its env loop reads in one 64-byte scalar
+// load.  [N + 1] entries: the loop prefetches one past its chunk.
+struct alignas(16) EnvV {
+  float A2[2], B2[2], Cx2[2], Cz2[2];
+  float Xhi, Zhi;
+  uint32_t tab3, hor_rgb, reach, env, pad[2];
+};
+static_assert(sizeof(EnvV) == 64, "EnvV is 64 bytes");
 
 // coverage-only part of a ScreenTri kept in LDS by k_resolve_obj; the winner's colours are fetched
 // from global memory.
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_env_sort(SimArrays A, const RenderMapD
 }
 
 __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
-                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2, const int32_t* __restrict__ pos) {
+                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2, const int32_t* __restrict__ pos, EnvV* envv) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
   if (e >= A.N) return;
@@ -275,6 +284,13 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
     q.env = (uint32_t)e; q.pad[1] = 0u;
     q.pad[0] = (uint32_t)c.map_id * (32u * 4u);     // k_raster_v3: byte offset of the map's columns inside an LDS table row (V3_MAP_COLS entries)
     envq[pos ? pos[e] : e] = q;
+    if (envv) {
+      EnvV v;
+      v.A2[0] = v.A2[1] = q.A; v.B2[0] = v.B2[1] = q.B; v.Cx2[0] = v.Cx2[1] = q.Cx; v.Cz2[0] = v.Cz2[1] = q.Cz;
+      v.Xhi = q.Xhi; v.Zhi = q.Zhi; v.tab3 = q.pad[0]; v.hor_rgb = q.hor_rgb; v.reach = q.reach; v.env = q.env; v.pad[0] = v.pad[1] = 0u;
+      envv[pos ? pos[e] : e] = v;
+      if (e == A.N - 1) envv[A.N] = v;               // the entry past the end (prefetched, never used)
+    }
   }
 }
 
@@ -2414,6 +2430,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
+  EnvV* envv = reinterpret_cast<EnvV*>(R.envv);
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
   // (S = 256 tables carry the v_perm cell selector of the S256 kernels, which need a padded grid under 256 tiles)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
@@ -2427,7 +2444,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
 #endif
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
-                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos);
+                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr);
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
@@ -2458,7 +2475,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
                     (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP == 0));
     if (v3) {
       const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
-#define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, R.frames, R.qtex, \
+#define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, R.frames, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
 #if DT_V3_WW == DT_WAVE_W && DT_V3_MAP == 0
       if (obj) LAUNCH_V3(true); else
