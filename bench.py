@@ -252,13 +252,13 @@ def main():
     N, K, Wm = args.envs, args.steps, args.warmup
     variant = {
         "c3": dict(maps="small_loop", dr=False, label="Duckietown-small_loop-v0 (fixture)", ref="configs[2]",
-                   kern="k_env_sort + k_raster_v3<OBJ=0> (exact path of the edge pixels inside; k_pix_setup tables cached)", extra={}),
+                   kern="k_raster_v3<OBJ=0> (exact path of the edge pixels inside; k_pix_setup tables cached)", extra={}),
         "c4": dict(maps="loop_pedestrians", dr=True, label="Duckietown-loop_pedestrians-v0 (stand-in: loop_only_duckies with "
                    "static: False, 8 walking duckies), dynamic obstacles + domain randomisation", ref="configs[3]",
-                   kern="k_obj_setup + k_raster<DR=1,OBJ=1> + k_resolve + k_resolve_obj", extra={}),
+                   kern="k_obj_setup + k_raster_v3dr<OBJ=1> (domain randomisation on the quad records) + k_resolve + k_resolve_obj", extra={}),
         "c5": dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, label="MultiMap-v0 (loop_only_duckies / "
                    "small_loop_only_duckies alternating per env slot, multimap_env.py:17,44-49)", ref="configs[4]",
-                   kern="k_env_sort + k_obj_setup + k_raster_v3<OBJ=1> + k_resolve_obj", extra=dict(map_cycle=True)),
+                   kern="k_obj_setup + k_raster_v3<OBJ=1> + k_resolve_obj", extra=dict(map_cycle=True)),
     }[args.config]
     sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=True, camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,

@@ -258,7 +258,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(frames %zu B): %s", h->frames_bytes, hipGetErrorString(e)); }
     h->frames = h->frames_own;
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
-    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64 + 4) + 64 + ((size_t)h->N + 1) * 64);   // EnvCam[N], EnvFast[N], EnvQ[N], render order [N], (aligned) EnvV[N + 1]
+    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64 + 4) + 64 + ((size_t)h->N + 1) * 64 + (size_t)h->N * 192);   // EnvCam[N], EnvFast[N], EnvQ[N], render order [N], (aligned) EnvV[N + 1], EnvD[N]
     if (e == hipSuccess) e = hipMalloc(&h->d_pixtab, (size_t)cfg->cam_height * cfg->cam_width * 64 + 2048);   // PixTab + SampTab + 1 KB store dump + debug counters
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
@@ -868,6 +868,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.q3_rows = h->q3_rows;
   R.envpos = reinterpret_cast<int32_t*>((char*)h->d_envcam + (size_t)h->N * (128 + 64 + 64));
   R.envv = (char*)h->d_envcam + (((size_t)h->N * (128 + 64 + 64 + 4) + 63) / 64) * 64;
+  R.envd = (char*)R.envv + ((size_t)h->N + 1) * 64;
   R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
   R.qmax_tiles = 0;
   for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);

@@ -48,6 +48,12 @@
 // with the vector ALUs 75-78 % busy -- at 24 % of the HBM roofline; float32 / integer-filter shading, uint8 output.
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
+#ifndef DT_ENV_SORT
+#define DT_ENV_SORT 0
+#endif
+#ifndef DT_V3_DR
+#define DT_V3_DR 1                 // domain randomisation on the quad records (render_v3dr.inc); 0: the generic k_raster<DR=1>
+#endif
 #include <type_traits>
 
 #define RB 256            // threads per workgroup (4 wavefronts)
@@ -145,6 +151,9 @@ __device__ inline CamShared default_cam(float aspect) {
   return s;
 }
 
+struct EnvD;                                          // render_v3dr.inc: per-env constants of k_raster_v3dr
+__device__ inline void fill_envd_at(EnvD* arr, int idx, const EnvCam& c, const EnvQ& q, const RenderMapDev& m, float q_cells, int H, int W);
+
 // Render order of the envs for the quad-layout path: envs standing on the same tile (and facing the same way) are
 // made neighbours, so that the 32 envs a raster workgroup loops over -- and, with the XCD-affine workgroup map of
 // k_raster_q, all the envs one XCD's L2 serves -- look at the same few texture blocks.  A counting sort by
@@ -188,7 +197,8 @@ __global__ __launch_bounds__(1024) void k_env_sort(SimArrays A, const RenderMapD
 }
 
 __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
-                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2, const int32_t* __restrict__ pos, EnvV* envv) {
+                            const RenderMapDev* __restrict__ maps, EnvQ* envq, int qlog2, const int32_t* __restrict__ pos, EnvV* envv,
+                            EnvD* envd, int W, int H) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t N = A.N;
   if (e >= A.N) return;
@@ -291,6 +301,7 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
       envv[pos ? pos[e] : e] = v;
       if (e == A.N - 1) envv[A.N] = v;               // the entry past the end (prefetched, never used)
     }
+    if (envd) fill_envd_at(envd, e, c, q, m, S, H, W);   // domain randomisation on the quad records (index = env: no sort there)
   }
 }
 
@@ -2160,6 +2171,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 }
 
 #include "render_v3.inc"
+#include "render_v3dr.inc"
 
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
@@ -2431,6 +2443,10 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
   EnvV* envv = reinterpret_cast<EnvV*>(R.envv);
+  EnvD* envd = reinterpret_cast<EnvD*>(R.envd);
+  // domain randomisation on the quad records (k_raster_v3dr): same table / texture conditions as k_raster_v3
+  const bool v3dr = R.qtex && R.envd && R.domain_rand && !R.segment && !R.no_msaa && (R.W & 3) == 0 && R.qlog2 == 8 && R.q3_rows > 0 &&
+                    R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_DR;
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
   // (S = 256 tables carry the v_perm cell selector of the S256 kernels, which need a padded grid under 256 tiles)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
@@ -2439,12 +2455,16 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
-#ifdef DT_NO_ENV_SORT     // ablation: envs in index order
+#if !DT_ENV_SORT
+  // Round 3: the sort is off.  It was introduced (round 2) for L2 locality when the pass waited for its record loads; with
+  // k_raster_v3 the pass costs the same with the envs in index order (1.945 / 1.966 ms against 1.963 / 1.973 sorted,
+  // profiles/r03_variants_ab.txt block E) and the 15 us single-workgroup sort launch is saved.  -DDT_ENV_SORT=1 restores it.
   pos = nullptr;
 #endif
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
-                     (float)R.W / (float)R.H, cams, fasts, R.maps, quad ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr);
+                     (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
+                     v3dr ? envd : nullptr, R.W, R.H);
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
@@ -2485,6 +2505,10 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
     } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
     else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
 #undef LAUNCH_Q
+  } else if (v3dr) {
+    const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
+    if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+    else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
