@@ -641,7 +641,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   h->max_tris = 0;
   for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
   if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
-    HIPCHK(hipMalloc(&h->d_stris, sizeof(ScreenTri) * (size_t)h->max_tris * h->N));
+    HIPCHK(hipMalloc(&h->d_stris, (sizeof(ScreenTri) + 16) * (size_t)h->max_tris * h->N));   // + the 16-byte screen boxes behind the triangles
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
     HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
@@ -851,6 +851,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.maps = h->d_rmaps; R.tiles = h->d_rtiles; R.objs = h->d_robjs; R.meshes = h->d_meshes; R.tris = h->d_tris;
   R.envcam = h->d_envcam;
   R.max_tris = h->d_stris ? h->max_tris : 0; R.stris = h->d_stris; R.objbox = h->d_objbox;
+  R.tribox = h->d_stris ? reinterpret_cast<float4*>(h->d_stris + (size_t)h->max_tris * h->N) : nullptr;
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
   R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
   R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;
@@ -901,6 +902,13 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
       if (tr[8]) fprintf(stderr, "[dtsim] k_resolve: longest wavefront %llu, longest batch %llu cycles; %llu (batch, env) pairs with objects in %llu batches, at most %llu in one batch\n",
                          tr[9], tr[10], tr[11], tr[5], tr[12]);
       HIPCHK(hipMemset(dbgp + 64, 0, sizeof tr));
+      int32_t ro[12];                                // DT_RO_STATS build variant: k_resolve_obj's z-buffer
+      HIPCHK(hipMemcpy(ro, dbgp + 768, sizeof ro, hipMemcpyDeviceToHost));
+      unsigned long long rp; memcpy(&rp, ro + 6, 8);
+      if (ro[4]) fprintf(stderr, "[dtsim] k_resolve_obj z-buffer: %d calls (%d triangle-parallel), %.1f staged triangles and %.1f pixels per call, "
+                         "%.2f box candidates per pixel, %.2f passes per call (max over lanes), %.2f if the pairs were spread evenly\n",
+                         ro[4], ro[5], (double)ro[2] / ro[4], (double)ro[3] / ro[4], ro[3] ? (double)ro[8] / ro[3] : 0.0, (double)ro[9] / ro[4], (double)ro[10] / ro[4]);
+      HIPCHK(hipMemset(dbgp + 768, 0, sizeof ro));
     }
     const size_t npix = (size_t)R.W * R.H;
     const size_t n_wg = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);

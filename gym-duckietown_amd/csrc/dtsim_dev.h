@@ -206,6 +206,7 @@ struct RenderParams {
   // mesh objects: per-env screen-space triangles written by the object setup kernel
   int32_t max_tris, segment;    // triangle slots per env (max over maps), 0 = no objects anywhere; segment: DTSIM_RENDER_SEGMENT
   ScreenTri* stris;             // [N][max_tris]
+  float4* tribox;               // [N][max_tris] screen boxes (bx0, bx1, by0, by1) of the triangles: k_resolve_obj's cull stream
   ObjBox* objbox;               // [N][DTSIM_MAX_OBJECTS]
   float* blockbox;              // [raster tiles * 4][4] source-pixel bounding box of each raster wavefront block (k_blk_setup)
   unsigned long long* objmask;  // [N][raster tiles * 4] objects whose screen box meets the block (bit o), written by k_obj_setup

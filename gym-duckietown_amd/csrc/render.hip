@@ -67,6 +67,9 @@
 #ifndef DT_TRI_CAP
 #define DT_TRI_CAP 128
 #endif
+#ifndef DT_TRI_PAD
+#define DT_TRI_PAD 0.5f        // round 3: was 1 px; a quarter fewer box candidates per pixel in k_resolve_obj's z-buffer, same frames
+#endif
 #define TRI_CAP DT_TRI_CAP  // LDS triangle slots per wavefront in k_resolve_obj (streamed chunks)
 
 #define CLS_SKY 0
@@ -434,12 +437,14 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     const float area = (st.sx[1] - st.sx[0]) * (st.sy[2] - st.sy[0]) - (st.sx[2] - st.sx[0]) * (st.sy[1] - st.sy[0]);
     ok = ok && (area != 0.f);
     st.inv_area = ok ? 1.f / area : 0.f;
-    st.bx0 = fminf(fminf(st.sx[0], st.sx[1]), st.sx[2]) - 1.f; st.bx1 = fmaxf(fmaxf(st.sx[0], st.sx[1]), st.sx[2]) + 1.f;
-    st.by0 = fminf(fminf(st.sy[0], st.sy[1]), st.sy[2]) - 1.f; st.by1 = fmaxf(fmaxf(st.sy[0], st.sy[1]), st.sy[2]) + 1.f;
+    // screen box padded by DT_TRI_PAD pixels: the four samples sit within 0.375 px of the pixel centre the box is tested with
+    st.bx0 = fminf(fminf(st.sx[0], st.sx[1]), st.sx[2]) - DT_TRI_PAD; st.bx1 = fmaxf(fmaxf(st.sx[0], st.sx[1]), st.sx[2]) + DT_TRI_PAD;
+    st.by0 = fminf(fminf(st.sy[0], st.sy[1]), st.sy[2]) - DT_TRI_PAD; st.by1 = fmaxf(fmaxf(st.sy[0], st.sy[1]), st.sy[2]) + DT_TRI_PAD;
     if (ok && (st.bx1 < 0.f || st.bx0 > (float)R.W || st.by1 < 0.f || st.by0 > (float)R.H)) { ok = false; st.inv_area = 0.f; }
     if (!ok) { st.bx0 = 1e30f; st.bx1 = -1e30f; st.by0 = 1e30f; st.by1 = -1e30f; }
     st.index = t;
     out[t] = st;
+    if (R.tribox) R.tribox[(size_t)e * R.max_tris + t] = make_float4(st.bx0, st.bx1, st.by0, st.by1);   // the cull stream of k_resolve_obj: 16 B per triangle, contiguous
     if (ok) {
       atomicMin(&s_obox[obj][0], f2ord(st.bx0)); atomicMax(&s_obox[obj][1], f2ord(st.bx1));
       atomicMin(&s_obox[obj][2], f2ord(st.by0)); atomicMax(&s_obox[obj][3], f2ord(st.by1));
@@ -683,7 +688,12 @@ __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, floa
 #ifndef DT_RO_BATCH_CULL
 #define DT_RO_BATCH_CULL 0     // per-batch triangle cull ahead of the per-pixel box tests: measured no gain (profiles/r03_variants_ab.txt, block F)
 #endif
-__device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, int lane, float pcx, float pcy,
+#ifndef DT_RO_PAIRS
+#define DT_RO_PAIRS 1          // pixel-parallel schedule as a balanced (pixel, triangle) pair list (below)
+#endif
+#define RO_PAIR_CAP 512                                  // pair slots per wavefront (16-bit entries)
+#define RO_SCR_BYTES (DT_RO_PAIRS ? 64 * 4 * 8 + RO_PAIR_CAP * 2 : 0)   // per wavefront: sample keys + the pair list
+__device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int fill, bool mine, int lane, float pcx, float pcy,
                                      float wbest[4], int tbest[4], int32_t* dbg) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -724,6 +734,88 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
     // its own mask: the wavefront runs max-over-lanes(candidates) passes of the 4-sample test, with a different
     // triangle per lane.
     static_assert(TRI_CAP <= 128 && TRI_CAP % 32 == 0, "up to four 32-bit candidate masks");
+#if DT_RO_PAIRS
+    // Round 3: balanced.  Walking per-lane candidate masks costs max-over-lanes passes of the 4-sample test -- measured
+    // 18 passes per call where the (pixel, triangle) pairs would fill 5.8 (profiles/r03_variants_ab.txt block G): the
+    // pixels of a batch straddle the dense middle of an object and the empty corners of its box.  Instead (1) the box
+    // test of each staged triangle appends its hits to a wavefront-local pair list (ballot + mbcnt: one 16-bit LDS
+    // write per hit), (2) the list is drained 64 pairs at a time, every lane testing ITS pair, and the per-sample
+    // winners meet in LDS as 64-bit keys (w bits : reversed triangle index) under ds_max_u64 -- LESS depth test with
+    // the draw-order tie break, the same order relation as the register compare; (3) each pixel's lane reads its four
+    // keys back.
+    unsigned long long* zb = reinterpret_cast<unsigned long long*>(w_scr);                   // [64 pixels][4 samples]
+    uint16_t* plist = reinterpret_cast<uint16_t*>(w_scr + 64 * 4 * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zb[lane * 4 + q] = 0ull;
+    int base = 0;
+#ifdef DT_RO_STATS
+    int n_pairs = 0, n_pass = 0;
+#endif
+    auto drain = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int q0 = 0; q0 < base; q0 += 64) {          // wave-uniform
+        const bool act = q0 + lane < base;
+        const uint32_t pr = act ? plist[q0 + lane] : 0u;
+        const int src = pr & 63;
+        const float qx = __shfl(pcx, src), qy = __shfl(pcy, src);
+#ifdef DT_RO_STATS
+        ++n_pass;
+#endif
+        if (act) {
+          const TriCov& st = w_tris[pr >> 6];
+          const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+          const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+          const float ia = st.inv_area;
+          const float e0x = st.sx[0] - qx, e0y = st.sy[0] - qy, e1x = st.sx[1] - qx, e1y = st.sy[1] - qy, e2x = st.sx[2] - qx, e2y = st.sy[2] - qy;
+          const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
+          const float g0x = (e1y - e2y) * ia, g0y = (e2x - e1x) * ia, g1x = (e2y - e0y) * ia, g1y = (e0x - e2x) * ia;
+          const float d0 = st.iw[0] - st.iw[2], d1 = st.iw[1] - st.iw[2];
+          const float wc = fmaf(b1c, d1, fmaf(b0c, d0, st.iw[2]));
+          const float gwx = fmaf(g1x, d1, g0x * d0), gwy = fmaf(g1y, d1, g0y * d0);
+          const uint32_t rix = 0x7fffffffu - (uint32_t)st.index;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                  // the arithmetic of test_tri_inside, term for term
+            const float b0 = fmaf(g0y, oy[q], fmaf(g0x, ox[q], b0c));
+            const float b1 = fmaf(g1y, oy[q], fmaf(g1x, ox[q], b1c));
+            const float b2 = 1.f - b0 - b1;
+            const float w = fmaf(gwy, oy[q], fmaf(gwx, ox[q], wc));
+            const bool in = fminf(fminf(b0, b1), b2) >= 0.f && w <= 1.f / NEAR_Z && w >= 1.f / FAR_Z;
+            if (in) atomicMax(zb + src * 4 + q, ((unsigned long long)__float_as_uint(w) << 32) | rix);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int j = 0; j < fill; ++j) {                   // wave-uniform
+      const float4 bb = *reinterpret_cast<const float4*>(&w_tris[j]);              // bx0, bx1, by0, by1
+      const bool in = mine & (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
+      const unsigned long long m = __ballot(in);
+      if (!m) continue;
+      if (in) plist[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((j << 6) | lane);
+      base += __popcll(m);
+#ifdef DT_RO_STATS
+      n_pairs += __popcll(m);
+#endif
+      if (base > RO_PAIR_CAP - 64) { drain(); base = 0; }
+    }
+    if (base) drain();
+    if (mine) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long k = zb[lane * 4 + q];
+        const float w = __uint_as_float((uint32_t)(k >> 32));
+        const int ix = (int)(0x7fffffffu - (uint32_t)k);
+        if (k != 0ull && (w > wbest[q] || (w == wbest[q] && ix < tbest[q]))) { wbest[q] = w; tbest[q] = ix; }
+      }
+    }
+#ifdef DT_RO_STATS
+    if (dbg && lane == 0) { atomicAdd(dbg + 8, n_pairs); atomicAdd(dbg + 9, n_pass); atomicAdd(dbg + 10, (n_pairs + 63) >> 6); }
+#endif
+#else
     uint32_t cand[4] = {0u, 0u, 0u, 0u};
 #if DT_RO_BATCH_CULL
     // (0) The 64 pixels of a batch are a short piece of one or two frame rows (queue order), while the staged triangles
@@ -776,6 +868,20 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
       cand[c] = mine ? mk : 0u;
     }
 #endif
+#ifdef DT_RO_STATS
+    if (dbg) {                                       // candidate statistics of the pixel-parallel z-buffer (build variant)
+      int nc = __popc(cand[0]) + __popc(cand[1]) + __popc(cand[2]) + __popc(cand[3]);
+      int sum = nc, mx = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { int m = __popc(cand[c]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
+        mx += m; }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+      if (lane == 0) { atomicAdd(dbg + 8, sum); atomicAdd(dbg + 9, mx); atomicAdd(dbg + 10, (sum + 63) >> 6); }
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (c * 32 >= fill) break;
@@ -788,6 +894,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, int fill, bool mine, 
         }
       }
     }
+#endif  // DT_RO_PAIRS
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -2272,6 +2379,8 @@ __global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam
   uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
   EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * RES_ENVS;                            // wavefront-local
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
+  uint32_t* w_scr = reinterpret_cast<uint32_t*>(reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + (RB / 64) * TRI_CAP) +
+                    wave * (RO_SCR_BYTES / 4);       // z-buffer scratch of the pair schedule
   const int n_items = R.work[2];                     // written by the raster launch (push_obj_items)
   const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
   const int n_grabs = (n_items + grab - 1) / grab;
@@ -2383,21 +2492,27 @@ __global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam
               }
               return true;
             };
-            auto fetch = [&](TriCov& tc) -> bool {     // this lane's triangle of the current chunk
+            // Round 3: the cull reads the triangles' screen boxes from their own contiguous array (16 B per triangle, written by
+            // k_obj_setup) and only the survivors load their 64-byte coverage record: the stream used to touch one 128-byte
+            // line per triangle for every (tile, env) unit an object's box meets.
+            const float4* boxes = R.tribox + (size_t)env_p * R.max_tris;
+            auto fetch = [&](float4& bb, int& idx) -> bool {     // this lane's triangle of the current chunk: box + index
               const bool in = t0 + lane < count;
-              if (in) tc = *reinterpret_cast<const TriCov*>(base + first + t0 + lane);
+              idx = first + t0 + lane;
+              if (in) bb = boxes[idx];
               return in;
             };
             int fill = 0;
-            TriCov cur, nxt;
+            float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+            int cur_idx = 0, nxt_idx = 0;
             bool more = advance();
-            bool cur_in = more ? fetch(cur) : false;
+            bool cur_in = more ? fetch(cur, cur_idx) : false;
             while (more) {
               const bool has_next = advance();
-              const bool nxt_in = has_next ? fetch(nxt) : false;
-              const bool pass = cur_in && !(cur.bx0 > x1 || cur.bx1 < x0 || cur.by0 > y1 || cur.by1 < y0);
+              const bool nxt_in = has_next ? fetch(nxt, nxt_idx) : false;
+              const bool pass = cur_in && !(cur.x > x1 || cur.y < x0 || cur.z > y1 || cur.w < y0);
               const unsigned long long pm = __ballot(pass);
-              if (pass) w_tris[fill + __popcll(pm & ((1ull << lane) - 1ull))] = cur;
+              if (pass) w_tris[fill + __popcll(pm & ((1ull << lane) - 1ull))] = *reinterpret_cast<const TriCov*>(base + cur_idx);
               fill += __popcll(pm);
               if (fill > TRI_CAP - 64 || (!has_next && fill > 0)) {   // chunk full, or the last one: z-buffer it
 #pragma unroll
@@ -2406,13 +2521,18 @@ __global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam
 #ifdef DT_RO_NOZ
                   if (fill == 12345) zbest[j][0] = 0.f;
 #else
-                  zbuffer_chunk(w_tris, fill, have[j], lane, (nxv[j] + 1.f) * 0.5f * (float)R.W, (1.f - nyv[j]) * 0.5f * (float)R.H,
-                                zbest[j], tbest[j], nullptr);
+                  zbuffer_chunk(w_tris, w_scr, fill, have[j], lane, (nxv[j] + 1.f) * 0.5f * (float)R.W, (1.f - nyv[j]) * 0.5f * (float)R.H,
+                                zbest[j], tbest[j],
+#ifdef DT_RO_STATS
+                                reinterpret_cast<int32_t*>(reinterpret_cast<char*>(R.pixtab) + (size_t)R.W * R.H * 64 + 1024 + 768));
+#else
+                                nullptr);
+#endif
 #endif
                 }
                 fill = 0;
               }
-              cur = nxt; cur_in = nxt_in; more = has_next;
+              cur = nxt; cur_idx = nxt_idx; cur_in = nxt_in; more = has_next;
             }
           }
 #pragma unroll
@@ -2520,7 +2640,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
     if (!quad) hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
     if (obj) {
-      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov);
+      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
       hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, 1, pos ? envq : (const EnvQ*)nullptr);
     }
   }
