@@ -49,7 +49,7 @@
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
 #ifndef DT_ENV_SORT
-#define DT_ENV_SORT 0
+#define DT_ENV_SORT 0              // 1: envs in k_env_sort order -- half the L2 fills, 4-5 % slower (dt_launch_render)
 #endif
 #ifndef DT_V3_DR
 #define DT_V3_DR 1                 // domain randomisation on the quad records (render_v3dr.inc); 0: the generic k_raster<DR=1>
@@ -169,34 +169,55 @@ __global__ __launch_bounds__(1024) void k_env_sort(SimArrays A, const RenderMapD
   const int tid = threadIdx.x;
   for (int i = tid; i < SORT_BINS; i += 1024) s_hist[i] = 0;
   __syncthreads();
+  // (any order is a valid render order: the bin only needs to be the same in both passes -- single-precision trigonometry,
+  // computed once per env and kept in registers between the histogram and the scatter; N <= 8 * 1024 envs per launch keep
+  // theirs, larger batches recompute)
   auto bin_of = [&](int e) -> int {
     const int mid = A.map_id[e] < 0 ? 0 : A.map_id[e];
     const float its = maps[mid].inv_tile_size;
-    const double ang = A.angle[e];
-    const float px = (float)(A.pos_x[e] + DT_CAMERA_FORWARD_DIST * cos(ang)), pz = (float)(A.pos_z[e] - DT_CAMERA_FORWARD_DIST * sin(ang));
+    const float ang = (float)A.angle[e];
+    float sa, ca;
+    __sincosf(ang, &sa, &ca);
+    const float px = (float)A.pos_x[e] + (float)DT_CAMERA_FORWARD_DIST * ca, pz = (float)A.pos_z[e] - (float)DT_CAMERA_FORWARD_DIST * sa;
     const int ti = min(max((int)floorf(px * its), 0), 31), tj = min(max((int)floorf(pz * its), 0), 31);
-    const int quad = ((int)floor(ang * (2.0 / 3.141592653589793) + 0.5)) & 3;
+    const int quad = ((int)floorf(ang * (float)(2.0 / 3.141592653589793) + 0.5f)) & 3;
     return ((((tj << 5) | ti) << 2) | quad) ^ ((mid * 1237) & (SORT_BINS - 1));
   };
-  for (int e = tid; e < A.N; e += 1024) atomicAdd(&s_hist[bin_of(e)], 1);
+  constexpr int KEEP = 8;
+  int bins[KEEP];
+#pragma unroll
+  for (int k = 0; k < KEEP; ++k) {
+    const int e = tid + k * 1024;
+    bins[k] = e < A.N ? bin_of(e) : -1;
+    if (bins[k] >= 0) atomicAdd(&s_hist[bins[k]], 1);
+  }
+  for (int e = tid + KEEP * 1024; e < A.N; e += 1024) atomicAdd(&s_hist[bin_of(e)], 1);
   __syncthreads();
   // exclusive scan of the bins: each thread owns SORT_BINS / 1024 consecutive bins
   int loc[SORT_BINS / 1024], sum = 0;
 #pragma unroll
   for (int k = 0; k < SORT_BINS / 1024; ++k) { loc[k] = sum; sum += s_hist[tid * (SORT_BINS / 1024) + k]; }
-  s_part[tid] = sum;
+  // block-wide exclusive scan of the 1024 partial sums: within a wavefront by DPP-style shuffles, across the 16 wavefronts through LDS
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if ((tid & 63) >= d) incl += v; }
+  if ((tid & 63) == 63) s_part[tid >> 6] = incl;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int v = tid >= d ? s_part[tid - d] : 0;
-    __syncthreads();
-    s_part[tid] += v;
-    __syncthreads();
+  if (tid < 16) {
+    int w = s_part[tid];
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const int v = __shfl_up(w, d, 16); if (tid >= d) w += v; }
+    s_part[16 + tid] = w;                             // inclusive over the wavefronts
   }
-  const int base = tid ? s_part[tid - 1] : 0;
+  __syncthreads();
+  const int base = incl - sum + ((tid >> 6) ? s_part[16 + (tid >> 6) - 1] : 0);
 #pragma unroll
   for (int k = 0; k < SORT_BINS / 1024; ++k) s_hist[tid * (SORT_BINS / 1024) + k] = base + loc[k];
   __syncthreads();
-  for (int e = tid; e < A.N; e += 1024) pos[e] = atomicAdd(&s_hist[bin_of(e)], 1);
+#pragma unroll
+  for (int k = 0; k < KEEP; ++k)
+    if (bins[k] >= 0) pos[tid + k * 1024] = atomicAdd(&s_hist[bins[k]], 1);
+  for (int e = tid + KEEP * 1024; e < A.N; e += 1024) pos[e] = atomicAdd(&s_hist[bin_of(e)], 1);
 }
 
 __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float aspect, EnvCam* out, EnvFast* fast,
@@ -2576,9 +2597,12 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
 #if !DT_ENV_SORT
-  // Round 3: the sort is off.  It was introduced (round 2) for L2 locality when the pass waited for its record loads; with
-  // k_raster_v3 the pass costs the same with the envs in index order (1.945 / 1.966 ms against 1.963 / 1.973 sorted,
-  // profiles/r03_variants_ab.txt block E) and the 15 us single-workgroup sort launch is saved.  -DDT_ENV_SORT=1 restores it.
+  // Round 3: the sort is off.  It was introduced (round 2) for L2 locality when the pass waited for its record loads.  With
+  // k_raster_v3 the loads hide behind the vector issue, and the sorted order is SLOWER on the headline workload: 2.00-2.01 ms
+  // per step against 1.87-1.93 in index order on the same box (profiles/r03_variants_ab.txt block H) -- neighbours in the
+  // order look at the same scene, so the slow blocks of a frame pile up in the same workgroups and on one XCD.  What the sort
+  // buys is counted L2 fills (FETCH_SIZE 2.08 -> 0.90 GB raw per pass, with the XCD-affine workgroup map only; the fills come
+  // from the 7 MB record pool, which the 256 MB Infinity Cache holds).  -DDT_ENV_SORT=1 restores it.
   pos = nullptr;
 #endif
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
