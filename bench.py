@@ -319,7 +319,7 @@ def main():
         # HBM-side traffic and VALU instruction counts cannot be collected inside this process (rocprofv3 PMC passes
         # wrap the whole command): they are read from the committed summary of the same command's counter runs and
         # labelled with where they came from; null when that file is for another workload.
-        traffic = traffic_source = valu = None
+        traffic = traffic_source = valu = traffic_split = None
         traffic_why = "profiles/raster_pmc_latest.json not found"
         pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
         if os.path.exists(pj):
@@ -331,6 +331,16 @@ def main():
                     traffic_why = None
                     traffic = d.get("hbm_bytes_per_launch")
                     traffic_source = d.get("source")
+                    if d.get("write_KB") is not None and d.get("fetch_KB_raw") is not None:
+                        # what the one number is made of: WRITE_SIZE is the frame (1.04-1.05 x the algorithmic bytes: the exact
+                        # path's byte patches); 2 x FETCH_SIZE counts L2 FILLS, nine tenths of them 16-byte record gathers on a
+                        # 7 MB pool (4 MB of L2 per XCD) that the 256 MB Infinity Cache holds -- an upper bound of the HBM reads
+                        # (profiles/r03_fetch_calibration.txt, profiles/r03_variants_ab.txt blocks H and I)
+                        traffic_split = {"write_bytes": d["write_KB"] * 1024.0, "l2_read_fill_bytes": 2.0 * d["fetch_KB_raw"] * 1024.0,
+                                         "write_over_algorithmic": d["write_KB"] * 1024.0 / (N * FRAME_BYTES),
+                                         "note": "traffic = write_bytes + l2_read_fill_bytes; the read fills are an UPPER bound of HBM reads "
+                                                 "(record gathers of a 7 MB pool resident in the 256 MB Infinity Cache; the counter cannot "
+                                                 "tell a fill from the Infinity Cache from one from HBM)"}
                     if d.get("valu_per_pixel") is not None:
                         clk = d.get("clock_ghz", 2.1) * 1e9
                         # issue peak as MEASURED on this part (profiles/r02_ubench_valu_rates.txt: the opcodes of this kernel
@@ -378,7 +388,7 @@ def main():
                        "parallelism": f"env-sharded x{world}, no data-path collective", **cfg_extra},
             "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic, "traffic_source": traffic_source,
-                         "traffic_null_reason": traffic_why,
+                         "traffic_null_reason": traffic_why, "traffic_split": traffic_split,
                          "kernel_ms": k_ms, "launches": n_r, "algorithmic_bytes_per_launch": N * FRAME_BYTES,
                          "kernel_ms_per_launch": ({"min": per_launch[0], "median": per_launch[len(per_launch) // 2], "max": per_launch[-1],
                                                    "n": len(per_launch), "source": "separate series after the timed region, one HIP-event reading per launch"}
