@@ -1541,12 +1541,17 @@ __device__ inline void quad_filter3(const uint4& q, float ax, float az, float I,
 // V3: the LDS tile table layout of k_raster_v3 (render_v3.inc: block offset at (tz << 10 | tx << 2) + the map's column
 // offset EnvQ.pad[0], the cell selector 512 bytes behind it) and its wavefront block shape; (tile_x0, wave_y0) is the
 // origin of the wavefront's block either way.
-template <bool S256, bool V3 = false>
+// POOL (k_raster_v3, round 3): the four queue regions of a workgroup are drained as ONE list, an equal share per wavefront.
+// w_queue = region 0 of the workgroup, (tile_x0, wave_y0) = origin of the workgroup tile, the wavefront's share = entries
+// [i0, i0 + n) of the concatenation, (p1, p2, p3) = where regions 1..3 start in it.  Per wavefront the regions hold anything
+// from nothing (sky blocks) to several hundred entries (a seam along the block): pooled, the 64-entry batches run full and
+// no wavefront of a workgroup idles while another drains its seam.
+template <bool S256, bool V3 = false, bool POOL = false>
 __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __restrict__ cams, const EnvQ* __restrict__ envq,
                                       const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
                                       const uint8_t* __restrict__ qtex, const uint32_t* s_qt, uint32_t* w_list,
                                       const uint16_t* w_queue, const int n, const int e0, const int tile_x0, const int wave_y0,
-                                      const int lane) {
+                                      const int lane, const int i0 = 0, const int p1 = 0, const int p2 = 0, const int p3 = 0) {
   const int npix = R.W * R.H;
   const int LS = R.qlog2;
   const uint32_t SM = (1u << LS) - 1u;
@@ -1607,11 +1612,19 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         have[u] = r0 + u * 64 + lane < n;
-        // the entries were written by this wavefront a moment ago: bypass the (possibly stale) L1 line
-        const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + u * 64 + lane) : 0u;
+        int qoff = r0 + u * 64 + lane, rx = 0, ry = 0;
+        if (POOL) {                                    // entry of the pooled list -> (region, offset in it)
+          constexpr int wx = DT_TILE_W / WWc, rows = WAVE_PIX / WWc;
+          const int gi = i0 + qoff;
+          const int r = (gi >= p1) + (gi >= p2) + (gi >= p3);
+          qoff = r * QREGION + gi - (r == 0 ? 0 : r == 1 ? p1 : r == 2 ? p2 : p3);
+          rx = (r % wx) * WWc; ry = (r / wx) * rows;
+        }
+        // the entries were written by this wavefront (workgroup) a moment ago: bypass the (possibly stale) L1 line
+        const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + qoff) : 0u;
         el[u] = (int)(ent >> 8);
         const int lp = (int)(ent & 255u);
-        pix[u] = (wave_y0 + lp / WWc) * R.W + tile_x0 + lp % WWc;
+        pix[u] = (wave_y0 + ry + lp / WWc) * R.W + tile_x0 + rx + lp % WWc;
       }
       float4 qa[U];
       uint4 qb[U];
