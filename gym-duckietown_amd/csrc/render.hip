@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     if (ok && (st.bx1 < 0.f || st.bx0 > (float)R.W || st.by1 < 0.f || st.by0 > (float)R.H)) { ok = false; st.inv_area = 0.f; }
     if (!ok) { st.bx0 = 1e30f; st.bx1 = -1e30f; st.by0 = 1e30f; st.by1 = -1e30f; }
     st.index = t;
-    out[t] = st;
+    // culled triangles (outside the view, degenerate, beyond near / far) leave only their inverted box: k_resolve_obj culls on
+    // the boxes and reads the 128-byte record of survivors only
+    if (ok || !R.tribox) out[t] = st;
     if (R.tribox) R.tribox[(size_t)e * R.max_tris + t] = make_float4(st.bx0, st.bx1, st.by0, st.by1);   // the cull stream of k_resolve_obj: 16 B per triangle, contiguous
     if (ok) {
       atomicMin(&s_obox[obj][0], f2ord(st.bx0)); atomicMax(&s_obox[obj][1], f2ord(st.bx1));
