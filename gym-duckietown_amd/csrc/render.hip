@@ -2398,8 +2398,11 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 #ifndef DT_RES_NB
 #define DT_RES_NB 2
 #endif
+#ifndef DT_RO_WAVES
+#define DT_RO_WAVES 3              // wavefronts per SIMD the kernel is compiled for (142 VGPRs as written; 4 caps it at 128)
+#endif
 template <int NB>
-__global__ __launch_bounds__(RB) void k_resolve_obj(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue,
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES, DT_RO_WAVES))) void k_resolve_obj(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue,
                                                     const int back, const EnvQ* __restrict__ envq) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
