@@ -108,6 +108,8 @@ struct dtsim {
   uint16_t* d_qend = nullptr;
   dtsim_reset_sampler* d_sampler = nullptr;   // device copy when a reset sampler is installed
   int map_w[DTSIM_MAX_MAPS] = {0}, map_h[DTSIM_MAX_MAPS] = {0};
+  int32_t* d_obsc_tab = nullptr;  // dtsim_observe_cubic tables (device copy of obsc_tab)
+  std::vector<int32_t> obsc_tab;
   int32_t* d_obs_tab = nullptr;   // dtsim_observe resampling tables (cached per output size)
   int obs_h = 0, obs_w = 0, obs_kx = 0, obs_ky = 0, obs_rpb = 0, obs_rows_in = 0;
   size_t obs_off_by = 0;
@@ -289,7 +291,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1002,6 +1004,44 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
   {
     ProfScope ps(h, DTSIM_KERNEL_OBSERVE);
     dt_launch_observe(h->stream, P);
+  }
+  HIPCHK(hipGetLastError());
+  return DTSIM_OK;
+}
+
+int dtsim_observe_cubic(dtsim_t* h, void* out, int out_h, int out_w, int flags,
+                        const int32_t* first_x, const int32_t* taps_x, const int32_t* first_y, const int32_t* taps_y) {
+  if (!h || !out || !first_x || !taps_x || !first_y || !taps_y) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  const int W = h->cfg.cam_width, H = h->cfg.cam_height;
+  if (out_h <= 0 || out_w <= 0) return fail(DTSIM_E_INVALID, "output size %dx%d", out_w, out_h);
+  if ((size_t)W * 3 * sizeof(int32_t) + 16 > 64 * 1024) return fail(DTSIM_E_LIMIT, "frame rows of %d pixels do not fit the kernel's LDS row", W);
+  for (int i = 0; i < out_w; ++i)
+    if (first_x[i] < -3 || first_x[i] >= W) return fail(DTSIM_E_INVALID, "first_x[%d] = %d out of range", i, first_x[i]);
+  for (int i = 0; i < out_h; ++i)
+    if (first_y[i] < -3 || first_y[i] >= H) return fail(DTSIM_E_INVALID, "first_y[%d] = %d out of range", i, first_y[i]);
+  for (size_t i = 0; i < 4 * (size_t)out_w; ++i) if (taps_x[i] < -32768 || taps_x[i] > 32767) return fail(DTSIM_E_INVALID, "taps_x[%zu] is not a 16-bit tap", i);
+  for (size_t i = 0; i < 4 * (size_t)out_h; ++i) if (taps_y[i] < -32768 || taps_y[i] > 32767) return fail(DTSIM_E_INVALID, "taps_y[%zu] is not a 16-bit tap", i);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  // tables: [first_x | taps_x | first_y | taps_y] in one device buffer, re-sent when they differ from the cached ones
+  std::vector<int32_t> tab;
+  tab.insert(tab.end(), first_x, first_x + out_w); tab.insert(tab.end(), taps_x, taps_x + 4 * (size_t)out_w);
+  tab.insert(tab.end(), first_y, first_y + out_h); tab.insert(tab.end(), taps_y, taps_y + 4 * (size_t)out_h);
+  if (tab != h->obsc_tab || !h->d_obsc_tab) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->d_obsc_tab) { (void)hipFree(h->d_obsc_tab); h->d_obsc_tab = nullptr; }
+    HIPCHK(hipMalloc(&h->d_obsc_tab, tab.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(h->d_obsc_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->obsc_tab = tab;
+  }
+  ObserveParams P{};
+  P.N = h->N; P.H = H; P.W = W; P.oh = out_h; P.ow = out_w; P.kx = 4; P.ky = 4;
+  P.chw = (flags & DTSIM_OBS_CHW) ? 1 : 0; P.f32 = (flags & DTSIM_OBS_F32) ? 1 : 0;
+  P.frames = h->frames; P.out = out;
+  P.bx = h->d_obsc_tab; P.kkx = P.bx + out_w; P.by = P.kkx + 4 * (size_t)out_w; P.kky = P.by + out_h;
+  {
+    ProfScope ps(h, DTSIM_KERNEL_OBSERVE);
+    dt_launch_observe_cubic(h->stream, P);
   }
   HIPCHK(hipGetLastError());
   return DTSIM_OK;

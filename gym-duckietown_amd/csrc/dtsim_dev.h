@@ -263,3 +263,5 @@ struct ObserveParams {
 };
 size_t dt_observe_lds_bytes(const ObserveParams& P);
 void dt_launch_observe(hipStream_t s, const ObserveParams& P);
+// OpenCV INTER_CUBIC: bx / by = first of the four taps per output column / row (borders replicate), kkx / kky = [..][4] 11-bit taps
+void dt_launch_observe_cubic(hipStream_t s, const ObserveParams& P);

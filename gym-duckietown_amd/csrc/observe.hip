@@ -188,7 +188,68 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   observe_vertical(P, s_tmp, e, oy0, oy1, y_first, tid);
 }
 
+// ---- OpenCV INTER_CUBIC (the reference's own ResizeWrapper, wrappers.py:129-138; dtsim/resample.py cubic_coeffs) ----
+// One workgroup per (env, output row).  The four source rows of the output row (replicated at the borders) are combined
+// FIRST, vertically: thread t sums the same dword of the four rows with the row's four 11-bit taps, byte by byte, into
+// int32 -- coalesced dword loads, every needed frame byte read once -- and leaves the 3 W sums in LDS; then thread ox sums
+// four of them per channel with the column's taps.  OpenCV filters rows first and columns second, keeping int32 rows
+// without rounding: both orders are the same exact integer sum (|sum| < 2^31 for 8-bit pixels), and the single rounding
+// is saturate_cast<uchar>((v + 2^21) >> 22).
+__global__ __launch_bounds__(OB) void k_observe_cubic(ObserveParams P) {
+  extern __shared__ uint32_t s_mem[];
+  int32_t* s_v = reinterpret_cast<int32_t*>(s_mem);          // [W * 3] vertical sums
+  const int tid = threadIdx.x;
+  const int e = blockIdx.x / P.oh, oy = blockIdx.x % P.oh;
+  const int in_row_bytes = P.W * 3;
+  const uint8_t* frame = P.frames + (size_t)e * P.H * in_row_bytes;
+  const int y0 = P.by[oy];                               // first of the four rows (may be < 0)
+  const int32_t* ky = P.kky + 4 * oy;
+  const int32_t k0 = ky[0], k1 = ky[1], k2 = ky[2], k3 = ky[3];
+  const uint8_t* r0 = frame + (size_t)min(max(y0, 0), P.H - 1) * in_row_bytes;
+  const uint8_t* r1 = frame + (size_t)min(max(y0 + 1, 0), P.H - 1) * in_row_bytes;
+  const uint8_t* r2 = frame + (size_t)min(max(y0 + 2, 0), P.H - 1) * in_row_bytes;
+  const uint8_t* r3 = frame + (size_t)min(max(y0 + 3, 0), P.H - 1) * in_row_bytes;
+  if ((in_row_bytes & 3) == 0) {
+    for (int i = tid; i < in_row_bytes / 4; i += OB) {
+      const uint32_t a = reinterpret_cast<const uint32_t*>(r0)[i], b = reinterpret_cast<const uint32_t*>(r1)[i];
+      const uint32_t c = reinterpret_cast<const uint32_t*>(r2)[i], d = reinterpret_cast<const uint32_t*>(r3)[i];
+      int4 v;
+      v.x = (int32_t)(a & 255u) * k0 + (int32_t)(b & 255u) * k1 + (int32_t)(c & 255u) * k2 + (int32_t)(d & 255u) * k3;
+      v.y = (int32_t)((a >> 8) & 255u) * k0 + (int32_t)((b >> 8) & 255u) * k1 + (int32_t)((c >> 8) & 255u) * k2 + (int32_t)((d >> 8) & 255u) * k3;
+      v.z = (int32_t)((a >> 16) & 255u) * k0 + (int32_t)((b >> 16) & 255u) * k1 + (int32_t)((c >> 16) & 255u) * k2 + (int32_t)((d >> 16) & 255u) * k3;
+      v.w = (int32_t)(a >> 24) * k0 + (int32_t)(b >> 24) * k1 + (int32_t)(c >> 24) * k2 + (int32_t)(d >> 24) * k3;
+      reinterpret_cast<int4*>(s_v)[i] = v;
+    }
+  } else {
+    for (int i = tid; i < in_row_bytes; i += OB) s_v[i] = (int32_t)r0[i] * k0 + (int32_t)r1[i] * k1 + (int32_t)r2[i] * k2 + (int32_t)r3[i] * k3;
+  }
+  __syncthreads();
+  for (int ox = tid; ox < P.ow; ox += OB) {
+    const int x0 = P.bx[ox];
+    const int32_t* kx = P.kkx + 4 * ox;
+    int32_t acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = min(max(x0 + j, 0), P.W - 1);
+      const int32_t kj = kx[j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += s_v[x * 3 + c] * kj;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t v = (uint32_t)min(max((acc[c] + (1 << 21)) >> 22, 0), 255);
+      const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : (((size_t)e * P.oh + oy) * P.ow + ox) * 3 + c;
+      if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v / 255.0f;
+      else reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v;
+    }
+  }
+}
+
 }  // namespace
+
+void dt_launch_observe_cubic(hipStream_t s, const ObserveParams& P) {
+  hipLaunchKernelGGL(k_observe_cubic, dim3((unsigned)((size_t)P.N * P.oh)), dim3(OB), (size_t)P.W * 3 * sizeof(int32_t) + 16, s, P);
+}
 
 size_t dt_observe_lds_bytes(const ObserveParams& P) {
   const size_t in_row_words = ((size_t)P.W * 3 + 3) >> 2;

@@ -449,13 +449,16 @@ class BatchedSimulator:
     def bind_frames(self, devptr: Optional[int]):
         _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
 
-    def observe(self, height: int, width: int, chw: bool = False, normalize: bool = False, out=None):
+    def observe(self, height: int, width: int, chw: bool = False, normalize: bool = False, out=None, interpolation: str = "pil_bilinear"):
         """Learner-side observation of the last rendered batch, on the device: PIL-exact bilinear resize
-        (learning/utils/wrappers.py ResizeWrapper), optional HWC->CHW (ImgWrapper) and /255 float32
-        (NormalizeWrapper).  Returns a device array ([N,h,w,3] or [N,3,h,w]); `out` may be any object with
+        (learning/utils/wrappers.py ResizeWrapper) or, with interpolation="cv_cubic", the cv2 INTER_CUBIC resize of the
+        reference's own ResizeWrapper (src/gym_duckietown/wrappers.py:129-138); optional HWC->CHW (ImgWrapper) and /255
+        float32 (NormalizeWrapper).  Returns a device array ([N,h,w,3] or [N,3,h,w]); `out` may be any object with
         __cuda_array_interface__ of that shape/dtype (e.g. the send buffer of the frame all-gather)."""
         import torch
         from . import resample
+        if interpolation not in ("pil_bilinear", "cv_cubic"):
+            raise ValueError(f"interpolation {interpolation!r}: 'pil_bilinear' or 'cv_cubic'")
         h, w = int(height), int(width)
         shape = (self.num_envs, 3, h, w) if chw else (self.num_envs, h, w, 3)
         if out is None:
@@ -467,6 +470,14 @@ class BatchedSimulator:
             out = self._obs_buf
         ptr = out.__cuda_array_interface__["data"][0]
         ip = C.POINTER(C.c_int32)
+        flags = (_ffi.OBS_CHW if chw else 0) | (_ffi.OBS_F32 if normalize else 0)
+        if interpolation == "cv_cubic":
+            fx, tx = resample.cubic_coeffs(self.camera_width, w)
+            fy, ty = resample.cubic_coeffs(self.camera_height, h)
+            fx, tx, fy, ty = (np.ascontiguousarray(a, dtype=np.int32) for a in (fx, tx, fy, ty))
+            _ffi.check(self._lib, self._lib.dtsim_observe_cubic(self._h, C.c_void_p(ptr), h, w, flags, fx.ctypes.data_as(ip), tx.ctypes.data_as(ip),
+                                                                fy.ctypes.data_as(ip), ty.ctypes.data_as(ip)))
+            return out
         bx = kx = by = ky = None
         nkx = nky = 0
         if w != self.camera_width:
@@ -475,7 +486,6 @@ class BatchedSimulator:
         if h != self.camera_height:
             b, k = resample.coeffs(self.camera_height, h)
             by, ky, nky = b.ctypes.data_as(ip), k.ctypes.data_as(ip), k.shape[1]
-        flags = (_ffi.OBS_CHW if chw else 0) | (_ffi.OBS_F32 if normalize else 0)
         _ffi.check(self._lib, self._lib.dtsim_observe(self._h, C.c_void_p(ptr), h, w, flags, bx, kx, nkx, by, ky, nky))
         return out
 

@@ -78,3 +78,58 @@ def observation(frames: np.ndarray, out_h: int, out_w: int, chw: bool = False, n
     if normalize:
         out = out.astype(np.float32) / np.float32(255.0)
     return out
+
+
+# ---- OpenCV INTER_CUBIC (the reference's own ResizeWrapper, wrappers.py:129-138) -----------------------------------
+# cv2.resize(img, (w, h), interpolation=cv2.INTER_CUBIC) for 8-bit images, as published in OpenCV's imgproc/resize.cpp
+# (resizeGeneric_ / HResizeCubic / VResizeCubic, fixed-point path): per output coordinate d
+#     fx = (float)((d + 0.5) * scale - 0.5);  sx = floor(fx);  fx -= sx          (scale = in / out in double, fx in float)
+#     interpolateCubic(fx), A = -0.75, in float; taps = saturate_cast<short>(c * 2048) (round half to even)
+# four taps at sx - 1 .. sx + 2 with replicated borders; the horizontal pass keeps int32 rows (no rounding), the
+# vertical pass sums them with its own taps and the pixel is saturate_cast<uchar>((v + (1 << 21)) >> 22).
+# cv2 is not installed in this image: parity UNPINNED against the library itself (its SIMD vertical pass works in float
+# and may differ from the integer path by one LSB at ties); dtsim_observe_cubic is bit-identical to THIS statement.
+CV_COEF_BITS = 11
+
+
+@lru_cache(maxsize=None)
+def cubic_coeffs(in_size: int, out_size: int):
+    """(first int32 [out] = index of the first of the 4 taps (may be < 0: borders replicate), taps int32 [out, 4])."""
+    A = np.float32(-0.75)
+    one, two, three = np.float32(1), np.float32(2), np.float32(3)
+    scale = in_size / out_size                          # double, as cv::resize's inv_scale
+    first = np.zeros(out_size, np.int32)
+    taps = np.zeros((out_size, 4), np.int32)
+    for d in range(out_size):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(math.floor(float(fx)))
+        x = np.float32(fx - np.float32(sx))
+        c = np.empty(4, np.float32)
+        x1 = np.float32(x + one)
+        c[0] = ((A * x1 - np.float32(5) * A) * x1 + np.float32(8) * A) * x1 - np.float32(4) * A
+        c[1] = ((A + two) * x - (A + three)) * x * x + one
+        xm = np.float32(one - x)
+        c[2] = ((A + two) * xm - (A + three)) * xm * xm + one
+        c[3] = one - c[0] - c[1] - c[2]
+        first[d] = sx - 1
+        taps[d] = np.clip(np.rint((c * np.float32(1 << CV_COEF_BITS)).astype(np.float32)), -32768, 32767).astype(np.int32)
+    first.setflags(write=False); taps.setflags(write=False)
+    return first, taps
+
+
+def resize_cubic(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_CUBIC) for uint8 [H, W] or [H, W, C] (restated; see above)."""
+    img = np.ascontiguousarray(img)
+    H, W = img.shape[:2]
+    xi, xt = cubic_coeffs(W, out_w)
+    yi, yt = cubic_coeffs(H, out_h)
+    xi = xi.astype(np.int64); yi = yi.astype(np.int64)
+    src = img.astype(np.int64)
+    hor = np.zeros((H, out_w) + img.shape[2:], np.int64)                  # int32 rows in OpenCV, no rounding in between
+    for k in range(4):
+        hor += src[:, np.clip(xi + k, 0, W - 1)] * xt[:, k].astype(np.int64).reshape((1, out_w) + (1,) * (img.ndim - 2))
+    out = np.zeros((out_h, out_w) + img.shape[2:], np.int64)
+    for k in range(4):
+        out += hor[np.clip(yi + k, 0, H - 1)] * yt[:, k].astype(np.int64).reshape((out_h, 1) + (1,) * (img.ndim - 2))
+    assert np.abs(out).max(initial=0) < 2 ** 31                          # the device (and OpenCV) accumulate in int32
+    return np.clip((out + (1 << (2 * CV_COEF_BITS - 1))) >> (2 * CV_COEF_BITS), 0, 255).astype(np.uint8)

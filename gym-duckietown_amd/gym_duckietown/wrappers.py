@@ -143,41 +143,10 @@ class PyTorchObsWrapper(_ObservationWrapper):
         return observation.transpose(2, 1, 0)
 
 
-def _cubic_taps(in_size: int, out_size: int):
-    """OpenCV resize INTER_CUBIC tables for 8-bit images: source index of the first of 4 taps and the
-    taps in 11-bit fixed point (A = -0.75; imgproc resize.cpp `interpolateCubic`, INTER_RESIZE_COEF_BITS)."""
-    A = -0.75
-    scale = in_size / out_size
-    idx = np.zeros(out_size, np.int64)
-    taps = np.zeros((out_size, 4), np.int64)
-    for d in range(out_size):
-        fx = (d + 0.5) * scale - 0.5
-        sx = int(np.floor(fx))
-        fx -= sx
-        c = np.empty(4)
-        c[0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A
-        c[1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1
-        c[2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1
-        c[3] = 1.0 - c[0] - c[1] - c[2]
-        idx[d] = sx - 1
-        taps[d] = np.clip(np.rint(c * 2048.0), -32768, 32767).astype(np.int64)
-    return idx, taps
-
-
 def resize_cubic(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_CUBIC) for uint8 [H,W,C] (restated)."""
-    img = np.ascontiguousarray(img)
-    H, W = img.shape[:2]
-    xi, xt = _cubic_taps(W, out_w)
-    yi, yt = _cubic_taps(H, out_h)
-    src = img.astype(np.int64)
-    hor = np.zeros((H, out_w) + img.shape[2:], np.int64)                  # int32 rows, no rounding in between
-    for k in range(4):
-        hor += src[:, np.clip(xi + k, 0, W - 1)] * xt[:, k].reshape((1, out_w) + (1,) * (img.ndim - 2))
-    out = np.zeros((out_h, out_w) + img.shape[2:], np.int64)
-    for k in range(4):
-        out += hor[np.clip(yi + k, 0, H - 1)] * yt[:, k].reshape((out_h, 1) + (1,) * (img.ndim - 2))
-    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_CUBIC) for uint8 images: the statement in
+    dtsim/resample.py (also what dtsim_observe_cubic computes on the device for a whole frame batch)."""
+    return resample.resize_cubic(img, out_h, out_w)
 
 
 class ResizeWrapper(_ObservationWrapper):

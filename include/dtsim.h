@@ -355,6 +355,15 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
                   const int32_t* bounds_x, const int32_t* taps_x, int ksize_x,
                   const int32_t* bounds_y, const int32_t* taps_y, int ksize_y);
 
+/* The reference's own ResizeWrapper (src/gym_duckietown/wrappers.py:129-138): cv2.resize(obs, (out_w, out_h),
+ * interpolation=cv2.INTER_CUBIC) of every frame of the batch, on the device -- OpenCV's 8-bit fixed-point path as
+ * published in imgproc/resize.cpp: four taps per axis (A = -0.75) in 11-bit fixed point, replicated borders, int32
+ * rows without intermediate rounding, saturate_cast<uchar>((v + 2^21) >> 22).  first_*[i] = source index of the first
+ * of the four taps of output coordinate i (may be negative), taps_*: [out][4], both as built by dtsim/resample.py
+ * cubic_coeffs (host pointers).  out / flags as dtsim_observe.  Asynchronous, stream-ordered after dtsim_render. */
+int dtsim_observe_cubic(dtsim_t* h, void* out, int out_h, int out_w, int flags,
+                        const int32_t* first_x, const int32_t* taps_x, const int32_t* first_y, const int32_t* taps_y);
+
 /* Geometry queries of the reference at arbitrary poses, evaluated on the device against
  * env env_idx[q]'s world (its map, dynamic objects and visibility): _valid_pose,
  * _collision, _drivable_pos, get_lane_pos2, closest_curve_point, proximity_penalty2,

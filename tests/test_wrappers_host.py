@@ -82,6 +82,20 @@ def test_cubic_resize_properties():
     assert rw.reset().shape == (120, 80, 80)                       # the reference resizes the axis-swapped image
 
 
+def test_cubic_tables_known_answers():
+    """OpenCV's interpolateCubic (A = -0.75) at fx = 0.5 and 0.25, 11-bit fixed point: (-3/32, 19/32, 19/32, -3/32) and
+    (-27/256, 225/256, 67/256, -9/256) -- the halving and doubling cases of cv::resize."""
+    from dtsim import resample
+    first, taps = resample.cubic_coeffs(640, 320)
+    assert first.tolist()[:3] == [-1, 1, 3] and all(t == [-192, 1216, 1216, -192] for t in taps.tolist())
+    first, taps = resample.cubic_coeffs(10, 20)
+    assert first[1] == -1 and taps[1].tolist() == [-216, 1800, 536, -72]
+    assert first[2] == -1 and taps[2].tolist() == [-72, 536, 1800, -216] and first[0] == -2
+    for a, b in ((640, 80), (480, 84), (120, 150), (84, 42)):
+        f, t = resample.cubic_coeffs(a, b)
+        assert np.all(np.abs(t.sum(1) - 2048) <= 1) and f.min() >= -2 and f.max() + 3 <= a + 1
+
+
 def test_undistort_wrapper_sets_flag_and_remaps():
     e = _Env(480, 640)
     u = W.UndistortWrapper(e)
