@@ -2351,11 +2351,16 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
       {  // the chunk's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
-        static_assert(ENVS_PER_BLOCK * sizeof(EnvCam) == 64 * 64, "one 64-byte slice per lane");
+        static_assert((ENVS_PER_BLOCK * sizeof(EnvCam)) % (64 * 64) == 0, "whole 64-byte slices per lane");
+        constexpr int SL = (int)(ENVS_PER_BLOCK * sizeof(EnvCam) / (64 * 64));   // 64-byte slices per lane
         const int ne = min(ENVS_PER_BLOCK, R.N - e0);
-        const uint4* src = reinterpret_cast<const uint4*>(cams + e0) + lane * 4;
-        uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
-        if (lane * 64 < ne * (int)sizeof(EnvCam)) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          const int o = (sl * 64 + lane) * 4;          // uint4 index of the slice
+          const uint4* src = reinterpret_cast<const uint4*>(cams + e0) + o;
+          uint4* dst = reinterpret_cast<uint4*>(w_cams) + o;
+          if (o * 16 < ne * (int)sizeof(EnvCam)) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; }
+        }
       }
       const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
       static_assert(RB / 64 == 4, "region lookup assumes 4 wavefronts");
