@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
-MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 8, 1024, 1024, 56, 8, 64
+MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 32, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
 F_RENDER, F_DISTORTION, F_DOMAIN_RAND, F_AUTO_RESET, F_ACTIONS_F64, F_PROFILE = 1, 2, 4, 8, 16, 32
 ACTION_WHEELS, ACTION_VEL_STEER = 0, 1
@@ -103,8 +103,8 @@ class ResetSampler(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("domain_rand", C.c_int32), ("dynamics_rand", C.c_int32), ("map_cycle", C.c_int32),
         ("max_attempts", C.c_int32), ("accept_start_angle_deg", C.c_double),
-        ("color_sky", C.c_double * 3), ("color_ground", C.c_double * 3), ("start_tile", (C.c_int32 * 2) * 8),
-        ("has_start_pose", C.c_int32 * 8), ("start_pose", (C.c_double * 3) * 8),
+        ("color_sky", C.c_double * 3), ("color_ground", C.c_double * 3), ("start_tile", (C.c_int32 * 2) * MAX_MAPS),
+        ("has_start_pose", C.c_int32 * MAX_MAPS), ("start_pose", (C.c_double * 3) * MAX_MAPS),
     ]
 
 

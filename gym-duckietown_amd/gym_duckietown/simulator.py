@@ -131,7 +131,9 @@ class Simulator(_EnvBase):
         self.randomize_maps_on_reset = bool(randomize_maps_on_reset)
         maps_arg = map_name
         if self.randomize_maps_on_reset:                 # simulator.py:373-378: every map but calibration* / regress*
-            self.map_names = self._all_map_names(env_kwargs.get("asset_root"))
+            # (a list / tuple as map_name restricts the draw to those maps: the way out when the asset tree holds more map
+            # files than the library keeps resident)
+            self.map_names = list(map_name) if isinstance(map_name, (list, tuple)) else self._all_map_names(env_kwargs.get("asset_root"))
             maps_arg = list(self.map_names)
             env_kwargs = dict(env_kwargs, map_random=True)
         try:
@@ -164,8 +166,10 @@ class Simulator(_EnvBase):
             names = sorted(assets.MAPS)
         names = [n for n in names if not n.startswith(("calibration", "regress"))]
         if len(names) > _ffi.MAX_MAPS:
-            logger.warning(f"randomize_maps_on_reset: {len(names)} maps found, keeping the first {_ffi.MAX_MAPS} (DTSIM_MAX_MAPS)")
-            names = names[:_ffi.MAX_MAPS]
+            # the reference draws from EVERY map file (simulator.py:373-378, :547-549): a silent cut would change what reset() can
+            # return.  32 resident maps cover the reference's own tree (~20); beyond that the caller has to choose.
+            raise ValueError(f"randomize_maps_on_reset: {len(names)} map files under the asset root, the library keeps at most "
+                             f"{_ffi.MAX_MAPS} resident (DTSIM_MAX_MAPS); pass map_name=[...] with the maps to draw from")
         return names
 
     def _bind_map(self, idx: int):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 6
+#define DTSIM_ABI_VERSION 7
 
 /* error codes */
 #define DTSIM_OK 0
@@ -41,7 +41,7 @@ extern "C" {
 #define DTSIM_E_LIMIT (-5)     /* a compile-time limit below was exceeded */
 
 /* limits (device tables are LDS-staged) */
-#define DTSIM_MAX_MAPS 8
+#define DTSIM_MAX_MAPS 32
 #define DTSIM_MAX_TILES 1024        /* grid_w * grid_h per map */
 #define DTSIM_MAX_CURVES 1024       /* per map */
 #define DTSIM_MAX_STATIC 56         /* collidable static objects per map */

@@ -199,3 +199,21 @@ def test_segmentation_assets_follow_the_reference_rules():
     assert (flat[..., :3] == 0).all() and (flat[..., 3] == 255).all()
     col = A.segment_texture(tex, "duckie.png", [100, 117, 226])
     assert (col[..., :3] == (100, 117, 226)).all()
+
+
+def test_map_list_of_randomize_maps_on_reset_is_never_cut_silently(tmp_path):
+    """simulator.py:373-378: randomize_maps_on_reset draws from every map file but calibration* / regress*.  The library keeps
+    DTSIM_MAX_MAPS (32) maps resident: a tree with more map files is an error that names the way out, not a shorter list."""
+    from dtsim import _ffi
+    from gym_duckietown.simulator import Simulator
+    d = tmp_path / "maps"
+    d.mkdir()
+    for i in range(_ffi.MAX_MAPS):
+        (d / f"map_{i:02d}.yaml").write_text("tiles: []\n")
+    (d / "calibration_map.yaml").write_text("tiles: []\n")
+    (d / "regress_4way.yaml").write_text("tiles: []\n")
+    names = Simulator._all_map_names(str(tmp_path))
+    assert len(names) == _ffi.MAX_MAPS == 32 and names[0] == "map_00" and "calibration_map" not in names
+    (d / "one_more.yaml").write_text("tiles: []\n")
+    with pytest.raises(ValueError, match="DTSIM_MAX_MAPS"):
+        Simulator._all_map_names(str(tmp_path))
