@@ -113,6 +113,7 @@ struct dtsim {
   int32_t* d_obs_tab = nullptr;   // dtsim_observe resampling tables (cached per output size)
   int obs_h = 0, obs_w = 0, obs_kx = 0, obs_ky = 0, obs_rpb = 0, obs_rows_in = 0;
   size_t obs_off_by = 0;
+  ObserveParams obs_fast{};       // the power-of-two fast-path fields of the cached output size (hfast .. vw)
   int max_tris = 0;
   int n_tilerecs = 0, tex_w = 1, tex_h = 1;
   ObjInstDev* d_robjs = nullptr;
@@ -993,6 +994,50 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
     HIPCHK(hipMalloc(&h->d_obs_tab, tab.size() * sizeof(int32_t)));
     HIPCHK(hipMemcpy(h->d_obs_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     h->obs_h = out_h; h->obs_w = out_w; h->obs_kx = ksize_x; h->obs_ky = ksize_y; h->obs_rpb = rpb; h->obs_rows_in = need;
+    // power-of-two down-scaling: interior columns / rows with identical small-integer taps (k_observe's dot4 / two-lane paths)
+    h->obs_fast = ObserveParams{};
+    auto uniform = [&](const int32_t* bounds, const int32_t* taps, int ksize, int n_in, int n_out, int S, uint32_t* w, int* sh) -> bool {
+      if (n_out < 3 || n_out * S != n_in || 2 * S > ksize || 2 * S > 16) return false;
+      const int32_t* k1 = taps + (size_t)1 * ksize;
+      int common = 22;                                  // trailing zero bits shared by the taps of column 1
+      for (int t = 0; t < 2 * S; ++t) { if (k1[t] <= 0) return false; common = std::min(common, __builtin_ctz((unsigned)k1[t])); }
+      long long sum = 0;
+      for (int t = 0; t < 2 * S; ++t) { const int q = k1[t] >> common; if (q > 255) return false; w[t] = (uint32_t)q; sum += q; }
+      if (sum != (1ll << (22 - common)) || 22 - common < 1 || 22 - common > 7) return false;   // two-lane sums must stay below 2^16
+      for (int o = 1; o < n_out - 1; ++o) {
+        if (bounds[2 * o] != S * o - S / 2 || bounds[2 * o + 1] != 2 * S) return false;
+        for (int t = 0; t < 2 * S; ++t) if (taps[(size_t)o * ksize + t] != k1[t]) return false;
+      }
+      *sh = 22 - common;
+      return true;
+    };
+    if (out_w != W && ((size_t)W * 3) % 4 == 0) {
+      for (int S : {4, 8}) {
+        uint32_t w[16]; int sh = 0;
+        if (!uniform(bounds_x, taps_x, ksize_x, W, out_w, S, w, &sh)) continue;
+        ObserveParams& F = h->obs_fast;
+        F.hfast = S; F.hsh = sh;
+        const int start = -3 * S / 2;                  // first byte of a column's window relative to 3 S ox
+        F.hoff = start & ~3;                           // (two's complement: rounds towards minus infinity)
+        F.hn = (3 * 2 * S + (start - F.hoff) + 3) / 4;
+        if (F.hn != 7 && F.hn != 12) { F.hfast = 0; continue; }
+        for (int b = 0; b < 3 * 2 * S; ++b) {
+          const int p = b + (start - F.hoff);
+          F.hw[b % 3][p / 4] |= w[b / 3] << (8 * (p % 4));
+        }
+        break;
+      }
+    }
+    if (out_h != H && ((size_t)out_w * 3) % 4 == 0) {
+      for (int S : {2, 4, 8}) {
+        uint32_t w[16]; int sh = 0;
+        if (!uniform(by.data(), taps_y, ksize_y, H, out_h, S, w, &sh)) continue;
+        h->obs_fast.vfast = S; h->obs_fast.vsh = sh;
+        for (int t = 0; t < 2 * S; ++t) h->obs_fast.vw[t] = w[t];
+        break;
+      }
+    }
+    if (getenv("DTSIM_OBSERVE_GENERIC")) h->obs_fast = ObserveParams{};   // A/B switch: the table-driven paths only
   }
   ObserveParams P{};
   P.N = h->N; P.H = H; P.W = W; P.oh = out_h; P.ow = out_w; P.kx = h->obs_kx; P.ky = h->obs_ky;
@@ -1001,6 +1046,9 @@ int dtsim_observe(dtsim_t* h, void* out, int out_h, int out_w, int flags,
   P.frames = h->frames; P.out = out;
   P.bx = h->d_obs_tab; P.kkx = h->d_obs_tab + (out_w != W ? 2 * (size_t)out_w : 0);
   P.by = h->d_obs_tab + h->obs_off_by; P.kky = P.by + 2 * (size_t)out_h;
+  P.hfast = h->obs_fast.hfast; P.hn = h->obs_fast.hn; P.hoff = h->obs_fast.hoff; P.hsh = h->obs_fast.hsh;
+  P.vfast = h->obs_fast.vfast; P.vsh = h->obs_fast.vsh;
+  memcpy(P.hw, h->obs_fast.hw, sizeof P.hw); memcpy(P.vw, h->obs_fast.vw, sizeof P.vw);
   {
     ProfScope ps(h, DTSIM_KERNEL_OBSERVE);
     dt_launch_observe(h->stream, P);

@@ -260,6 +260,16 @@ struct ObserveParams {
   const int32_t* kkx;           // [ow][kx] 22-bit fixed-point taps
   const int32_t* by;            // [oh][2]
   const int32_t* kky;           // [oh][ky]
+  // power-of-two down-scaling (640 -> 160 / 80, 480 -> 240 / 120 / 60): away from the borders every output column (row) has the
+  // SAME taps, and they are small integers times a power of two (the triangle filter of scale S normalises to (1, 3, .., 2S-1,
+  // 2S-1, .., 1) / 2S^2).  hfast: 0 off, else S: the 2S taps x 3 channels of a column sit in `hn` aligned dwords starting `hoff`
+  // bytes from 3 S ox; hw[c][d] holds channel c's tap weights at their byte positions of dword d (zeros elsewhere): three
+  // chains of v_dot4_u32_u8 filter a column.  vfast: 0 off, else S: vw[t] the 2S row weights, applied to four bytes at a time
+  // in two 16-bit lanes.  hsh / vsh: the fixed-point shift that is left (22 - log2 of the common factor).
+  int32_t hfast, hn, hoff, hsh;
+  int32_t vfast, vsh;
+  uint32_t hw[3][12];
+  uint32_t vw[16];
 };
 size_t dt_observe_lds_bytes(const ObserveParams& P);
 void dt_launch_observe(hipStream_t s, const ObserveParams& P);

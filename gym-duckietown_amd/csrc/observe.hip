@@ -10,6 +10,7 @@
 // `Image.resize`.  HBM-read bound: every frame byte is read once (plus the row overlap between
 // neighbouring row blocks), the output is 16x smaller at 640x480 -> 160x120.
 #include "dtsim_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -33,7 +34,25 @@ __device__ inline void observe_vertical_t(const ObserveParams& P, const uint8_t*
   for (int i = tid; i < n_out; i += OB) {
     const int oy = oy0 + i / per_row, j0 = (i % per_row) * PER;
     uint32_t v[PER];
-    if (P.oh == P.H) {
+    if (PER == 4 && P.vfast && oy > 0 && oy < P.oh - 1) {
+      // uniform small-integer taps: four bytes per step in two 16-bit lanes (sum of the weights = 2^vsh: a lane never carries)
+      const int S = P.vfast;
+      const uint8_t* p = s_tmp + (size_t)(S * oy - S / 2 - y_first) * tmp_row_bytes + j0;
+      uint32_t lo = 0x00010001u << (P.vsh - 1), hi = lo;                  // the rounding half
+      for (int t = 0; t < 2 * S; ++t) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)t * tmp_row_bytes);
+        lo = __umul24(w & 0x00FF00FFu, P.vw[t]) + lo;
+        hi = __umul24((w >> 8) & 0x00FF00FFu, P.vw[t]) + hi;
+      }
+      lo = (lo >> P.vsh) & 0x00FF00FFu; hi = (hi >> P.vsh) & 0x00FF00FFu;
+      const uint32_t packed = lo | (hi << 8);
+      if (!P.chw && !P.f32) {
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.out) + ((size_t)e * P.oh + oy) * tmp_row_bytes + j0) = packed;
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) v[q] = (packed >> (8 * q)) & 255u;
+    } else if (P.oh == P.H) {
 #pragma unroll
       for (int q = 0; q < PER; ++q) v[q] = s_tmp[(size_t)(oy - y_first) * tmp_row_bytes + j0 + q];
     } else {
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   uint8_t* s_tmp = s_row + (size_t)OBS_STAGE_ROWS * in_row_words * 4 + 32;          // [max_rows_in][ow * 3]
   int32_t* s_bx = reinterpret_cast<int32_t*>(s_tmp + (((size_t)P.max_rows_in * tmp_row_bytes + 3) & ~(size_t)3));   // [ow][2]
   int32_t* s_kx = s_bx + 2 * P.ow;                                                  // [ow][9] (fast path only)
-  if (P.ow != P.W && P.kx <= 9) {
+  if (P.ow != P.W && P.kx <= 9 && !P.hfast) {
     for (int i = tid; i < 2 * P.ow; i += OB) s_bx[i] = P.bx[i];
     for (int i = tid; i < 9 * P.ow; i += OB) s_kx[i] = (i % 9) < P.kx ? P.kkx[(i / 9) * P.kx + (i % 9)] : 0;
   }
@@ -136,7 +155,44 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
     }
     __syncthreads();
     if (pipelined && r0 + OBS_STAGE_ROWS < rows_in) prefetch(r0 + OBS_STAGE_ROWS);
-    if (P.ow != P.W && P.kx <= 9) {
+    if (P.hfast) {
+      // power-of-two scale: every interior column has the same taps; three chains of v_dot4_u32_u8 over the column's aligned
+      // dwords with the channel's weights at their byte positions (kernel arguments: scalar registers)
+      const int S = P.hfast, sh = P.hsh;
+      for (int i = tid; i < nr * P.ow; i += OB) {
+        const int rr = i / P.ow, ox = i % P.ow;
+        uint8_t* dst = s_tmp + (size_t)(r0 + rr) * tmp_row_bytes + ox * 3;
+        if (ox == 0 || ox == P.ow - 1) {             // border columns: clipped, renormalised taps from the tables
+          const uint8_t* src = s_row + rr * in_row_words * 4;
+          const int x0 = P.bx[2 * ox], n = P.bx[2 * ox + 1];
+          const int32_t* k = P.kkx + ox * P.kx;
+          int32_t a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
+          const uint8_t* p = src + x0 * 3;
+          for (int t = 0; t < n; ++t) {
+            const int32_t kt = k[t];
+            a0 += (int32_t)p[3 * t] * kt; a1 += (int32_t)p[3 * t + 1] * kt; a2 += (int32_t)p[3 * t + 2] * kt;
+          }
+          dst[0] = (uint8_t)clip8(a0); dst[1] = (uint8_t)clip8(a1); dst[2] = (uint8_t)clip8(a2);
+          continue;
+        }
+        const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(s_row + rr * in_row_words * 4) + ((3 * S * ox + P.hoff) >> 2);
+        uint32_t a0 = 1u << (sh - 1), a1 = a0, a2 = a0;
+        if (P.hn == 7) {
+#pragma unroll
+          for (int d = 0; d < 7; ++d) {
+            const uint32_t w = wsrc[d];
+            a0 = __builtin_amdgcn_udot4(w, P.hw[0][d], a0, false); a1 = __builtin_amdgcn_udot4(w, P.hw[1][d], a1, false); a2 = __builtin_amdgcn_udot4(w, P.hw[2][d], a2, false);
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 12; ++d) {
+            const uint32_t w = wsrc[d];
+            a0 = __builtin_amdgcn_udot4(w, P.hw[0][d], a0, false); a1 = __builtin_amdgcn_udot4(w, P.hw[1][d], a1, false); a2 = __builtin_amdgcn_udot4(w, P.hw[2][d], a2, false);
+          }
+        }
+        dst[0] = (uint8_t)(a0 >> sh); dst[1] = (uint8_t)(a1 >> sh); dst[2] = (uint8_t)(a2 >> sh);
+      }
+    } else if (P.ow != P.W && P.kx <= 9) {
       // fast path (e.g. 640 -> 160: 8 taps): the 27 bytes of the 9-tap window come from 8 dword LDS reads,
       // are byte-aligned with v_alignbyte and multiplied out with 24-bit integer MADs
       for (int i = tid; i < nr * P.ow; i += OB) {
@@ -186,6 +242,102 @@ __global__ __launch_bounds__(OB) void k_observe(ObserveParams P) {
   }
 
   observe_vertical(P, s_tmp, e, oy0, oy1, y_first, tid);
+}
+
+// ---- power-of-two down-scaling on both axes (640 x 480 -> 160 x 120, 80 x 60, 160 x 240 ...): no staging at all ----------
+// Away from the borders every output pixel has the same small-integer taps (ObserveParams::hw / vw).  A thread owns R = 4
+// vertically adjacent output pixels of one column: it walks the (R + 1) SY input rows they need once, filters each row's
+// window with three v_dot4_u32_u8 chains straight from global memory (HN aligned dwords; neighbouring threads read
+// neighbouring windows, the rows are shared through L1 / L2), rounds to the uint8 intermediate Pillow keeps, and adds it to
+// the one or two outputs the row belongs to.  The frame is read from HBM once; nothing is synchronised.  Border rows /
+// columns (clipped, renormalised taps) are k_observe_border's.
+template <int HN, int SY>
+__global__ __launch_bounds__(OB) void k_observe_pow2(ObserveParams P) {
+  constexpr int R = 4;
+  const int wi = P.ow - 2, G = (P.oh - 2 + R - 1) / R;
+  const int per_env = G * wi;
+  const int idx = blockIdx.x * OB + threadIdx.x;
+  const int e = idx / per_env, rem = idx - e * per_env;
+  if (e >= P.N) return;
+  const int g = rem / wi, ox = 1 + (rem - g * wi);
+  const int oy0 = 1 + g * R;
+  const int SX = P.hfast;
+  const int in_row_bytes = P.W * 3;
+  const uint8_t* col = P.frames + (size_t)e * P.H * in_row_bytes + (3 * SX * ox + P.hoff);
+  const int ybase = SY * oy0 - SY / 2;
+  uint32_t acc[R][3];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[r][c] = 1u << (P.vsh - 1);
+  const uint32_t hhalf = 1u << (P.hsh - 1);
+#pragma unroll
+  for (int t = 0; t < (R + 1) * SY; ++t) {
+    const int y = min(ybase + t, P.H - 1);             // rows past the frame only feed outputs that are not stored
+    const uint32_t* wsrc = reinterpret_cast<const uint32_t*>(col + (size_t)y * in_row_bytes);
+    uint32_t a0 = hhalf, a1 = hhalf, a2 = hhalf;
+#pragma unroll
+    for (int d = 0; d < HN; ++d) {
+      const uint32_t w = wsrc[d];
+      a0 = __builtin_amdgcn_udot4(w, P.hw[0][d], a0, false); a1 = __builtin_amdgcn_udot4(w, P.hw[1][d], a1, false); a2 = __builtin_amdgcn_udot4(w, P.hw[2][d], a2, false);
+    }
+    a0 >>= P.hsh; a1 >>= P.hsh; a2 >>= P.hsh;         // Pillow's uint8 intermediate
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int tt = t - SY * r;                       // compile-time: which tap of output r this row is
+      if (tt >= 0 && tt < 2 * SY) {
+        acc[r][0] = __umul24(a0, P.vw[tt]) + acc[r][0]; acc[r][1] = __umul24(a1, P.vw[tt]) + acc[r][1]; acc[r][2] = __umul24(a2, P.vw[tt]) + acc[r][2];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oy = oy0 + r;
+    if (oy > P.oh - 2) break;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t v = acc[r][c] >> P.vsh;
+      const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : (((size_t)e * P.oh + oy) * P.ow + ox) * 3 + c;
+      if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v / 255.0f;
+      else reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v;
+    }
+  }
+}
+
+// the border pixels of the same output (first / last row and column): Pillow's two passes per pixel from the tables
+__global__ __launch_bounds__(OB) void k_observe_border(ObserveParams P) {
+  const int nb = 2 * P.ow + 2 * (P.oh - 2);
+  const int idx = blockIdx.x * OB + threadIdx.x;
+  const int e = idx / nb, b = idx - e * nb;
+  if (e >= P.N) return;
+  int oy, ox;
+  if (b < P.ow) { oy = 0; ox = b; }
+  else if (b < 2 * P.ow) { oy = P.oh - 1; ox = b - P.ow; }
+  else { const int q = b - 2 * P.ow; oy = 1 + (q >> 1); ox = (q & 1) ? P.ow - 1 : 0; }
+  const int in_row_bytes = P.W * 3;
+  const uint8_t* frame = P.frames + (size_t)e * P.H * in_row_bytes;
+  const int x0 = P.bx[2 * ox], nx = P.bx[2 * ox + 1], y0 = P.by[2 * oy], ny = P.by[2 * oy + 1];
+  const int32_t* kx = P.kkx + ox * P.kx;
+  const int32_t* ky = P.kky + oy * P.ky;
+  int32_t acc[3] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
+  for (int t = 0; t < ny; ++t) {
+    const uint8_t* p = frame + (size_t)(y0 + t) * in_row_bytes + x0 * 3;
+    int32_t a[3] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
+    for (int j = 0; j < nx; ++j) {
+      const int32_t kj = kx[j];
+      a[0] += (int32_t)p[3 * j] * kj; a[1] += (int32_t)p[3 * j + 1] * kj; a[2] += (int32_t)p[3 * j + 2] * kj;
+    }
+    const int32_t kt = ky[t];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += (int32_t)clip8(a[c]) * kt;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t v = clip8(acc[c]);
+    const size_t o = P.chw ? (((size_t)e * 3 + c) * P.oh + oy) * P.ow + ox : (((size_t)e * P.oh + oy) * P.ow + ox) * 3 + c;
+    if (P.f32) reinterpret_cast<float*>(P.out)[o] = (float)v / 255.0f;
+    else reinterpret_cast<uint8_t*>(P.out)[o] = (uint8_t)v;
+  }
 }
 
 // ---- OpenCV INTER_CUBIC (the reference's own ResizeWrapper, wrappers.py:129-138; dtsim/resample.py cubic_coeffs) ----
@@ -258,6 +410,18 @@ size_t dt_observe_lds_bytes(const ObserveParams& P) {
 }
 
 void dt_launch_observe(hipStream_t s, const ObserveParams& P) {
+  if (P.hfast && P.vfast && P.ow >= 3 && P.oh >= 3 && !getenv("DTSIM_OBSERVE_STAGED")) {   // power-of-two scale on both axes
+    const int G = (P.oh - 2 + 3) / 4;
+    const size_t n_in = (size_t)P.N * G * (P.ow - 2), n_b = (size_t)P.N * (2 * P.ow + 2 * (P.oh - 2));
+    const dim3 grid((unsigned)((n_in + OB - 1) / OB)), gridb((unsigned)((n_b + OB - 1) / OB));
+    bool done = true;
+#define DT_POW2(HN_, SY_) hipLaunchKernelGGL((k_observe_pow2<HN_, SY_>), grid, dim3(OB), 0, s, P)
+    if (P.hn == 7 && P.vfast == 2) DT_POW2(7, 2); else if (P.hn == 7 && P.vfast == 4) DT_POW2(7, 4); else if (P.hn == 7 && P.vfast == 8) DT_POW2(7, 8);
+    else if (P.hn == 12 && P.vfast == 2) DT_POW2(12, 2); else if (P.hn == 12 && P.vfast == 4) DT_POW2(12, 4); else if (P.hn == 12 && P.vfast == 8) DT_POW2(12, 8);
+    else done = false;
+#undef DT_POW2
+    if (done) { hipLaunchKernelGGL(k_observe_border, gridb, dim3(OB), 0, s, P); return; }
+  }
   const int n_blocks = (P.oh + P.rows_per_block - 1) / P.rows_per_block;
   hipLaunchKernelGGL(k_observe, dim3((unsigned)((size_t)P.N * n_blocks)), dim3(OB), dt_observe_lds_bytes(P), s, P);
 }

@@ -10,7 +10,10 @@ PIL = pytest.importorskip("PIL.Image")
 
 
 @pytest.mark.parametrize("W,H,ow,oh", [(640, 480, 160, 120), (640, 480, 320, 240), (160, 120, 40, 30), (640, 480, 320, 120), (640, 480, 80, 80), (640, 480, 84, 84), (160, 120, 200, 150),
-                                       (84, 84, 64, 42), (640, 480, 160, 480), (640, 480, 640, 60), (640, 480, 640, 480)])
+                                       (84, 84, 64, 42), (640, 480, 160, 480), (640, 480, 640, 60), (640, 480, 640, 480),
+                                       # power-of-two scales on both axes (k_observe_pow2 + k_observe_border): every (x, y) scale pair
+                                       (640, 480, 160, 240), (640, 480, 160, 60), (640, 480, 80, 240), (640, 480, 80, 120), (640, 480, 80, 60),
+                                       (320, 240, 80, 60), (64, 48, 16, 12), (32, 16, 4, 4)])
 def test_observe_matches_pil(W, H, ow, oh):
     import torch
     N = 5
