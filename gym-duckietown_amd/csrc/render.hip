@@ -65,7 +65,7 @@
 #define WAVE_PIX (64 * PPT)
 #define ENVS_PER_BLOCK DT_ENVS_PER_BLOCK
 #ifndef DT_TRI_CAP
-#define DT_TRI_CAP 128
+#define DT_TRI_CAP 96              // round 3: 128 -> 96 (with 256 pair slots: 40 KB of LDS per workgroup, 4 workgroups per CU; block M)
 #endif
 #ifndef DT_TRI_PAD
 #define DT_TRI_PAD 0.5f        // round 3: was 1 px; a quarter fewer box candidates per pixel in k_resolve_obj's z-buffer, same frames
@@ -714,7 +714,9 @@ __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, floa
 #ifndef DT_RO_PAIRS
 #define DT_RO_PAIRS 1          // pixel-parallel schedule as a balanced (pixel, triangle) pair list (below)
 #endif
-#define RO_PAIR_CAP 512                                  // pair slots per wavefront (16-bit entries)
+#ifndef RO_PAIR_CAP
+#define RO_PAIR_CAP 256                                  // pair slots per wavefront (16-bit entries)
+#endif
 #define RO_SCR_BYTES (DT_RO_PAIRS ? 64 * 4 * 8 + RO_PAIR_CAP * 2 : 0)   // per wavefront: sample keys + the pair list
 __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int fill, bool mine, int lane, float pcx, float pcy,
                                      float wbest[4], int tbest[4], int32_t* dbg) {
@@ -2404,7 +2406,7 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 #define DT_RES_NB 2
 #endif
 #ifndef DT_RO_WAVES
-#define DT_RO_WAVES 3              // wavefronts per SIMD the kernel is compiled for (142 VGPRs as written; 4 caps it at 128)
+#define DT_RO_WAVES 4              // wavefronts per SIMD the kernel is compiled for (142 VGPRs at 3; 4 caps it at 128)
 #endif
 template <int NB>
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES, DT_RO_WAVES))) void k_resolve_obj(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue,
