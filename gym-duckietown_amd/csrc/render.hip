@@ -1123,6 +1123,12 @@ __device__ inline PixInv pix_inv_dr(float nx, float ny, bool valid, const DrCam&
 // sized (every pixel of every env of the chunk), so appends need no atomics; entry =
 // (env-in-chunk << 8) | (row-slot k << 6 | lane).  k_resolve drains the regions 64 entries at a time.
 #define QREGION (WAVE_PIX * ENVS_PER_BLOCK)
+// Queue entry: pixel of the wavefront block (bits 0..7) | env position in the chunk << 8 (bits 8..13).  Object-box entries
+// (far end of the region, k_resolve_obj's) carry bit 15 when the pixel is ALSO a plane edge, i.e. when what the raster
+// stored for it is not final: k_resolve_obj leaves a pixel alone when no mesh triangle covers any of its samples and the
+// bit is clear (the raster's one-ray colour is the pixel).  k_raster_v3 / k_raster_v3dr tell; the other rasters always set it.
+#define QE_PLANE_EDGE 0x8000u
+static_assert(ENVS_PER_BLOCK <= 64, "the env position of a queue entry has six bits");
 #define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
 #define GRAB_MAX 16       // work items per cursor atomic, at most
@@ -1395,7 +1401,7 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         const unsigned long long mk = __ballot(ek);
         if (ek) {
           const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
+          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | QE_PLANE_EDGE | (uint32_t)(k * 64 + lane));   // (this raster does not tell: always "plane edge")
         }
         qo += __popcll(mk);
       }
@@ -1985,7 +1991,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         const unsigned long long mk = __ballot(ek);
         if (ek) {
           const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | (uint32_t)(k * 64 + lane));
+          w_queue[QREGION - 1 - (qo + rank)] = (uint16_t)(etag | QE_PLANE_EDGE | (uint32_t)(k * 64 + lane));
         }
         qo += __popcll(mk);
       }
@@ -2405,6 +2411,9 @@ __global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __
 #ifndef DT_RES_NB
 #define DT_RES_NB 2
 #endif
+#ifndef DT_RO_SKIP_UNCOVERED
+#define DT_RO_SKIP_UNCOVERED 1     // uncovered object-box pixels keep the raster's colour (queue-entry bit QE_PLANE_EDGE)
+#endif
 #ifndef DT_RO_WAVES
 #define DT_RO_WAVES 4              // wavefronts per SIMD the kernel is compiled for (142 VGPRs at 3; 4 caps it at 128)
 #endif
@@ -2489,7 +2498,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
         const ScreenTri* base = R.stris + (size_t)env_p * R.max_tris;
         const uint2* rng = R.objrange + (size_t)__builtin_amdgcn_readfirstlane(c.map_id) * DTSIM_MAX_OBJECTS;
         for (int g0 = 0; g0 < n_p; g0 += 64 * NB) {   // wave-uniform: up to NB batches of the unit at a time
-          bool have[NB];
+          bool have[NB], pedge[NB];
           int pix[NB];
           float nxv[NB], nyv[NB];
           float zbest[NB][4];
@@ -2504,6 +2513,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
             const uint16_t* w_queue = queue + ((size_t)rwg * 4 + r) * QREGION;
             // back: the entries were appended from the far end of the region (k_raster_q<OBJ>: object-box pixels)
             const uint32_t ent = have[j] ? w_queue[back ? QREGION - 1 - li : li] : 0u;
+            pedge[j] = (ent & QE_PLANE_EDGE) != 0u || !back;
             const int lp = ent & 255;
             pix[j] = (tile_y0 + r * (WAVE_PIX / WAVE_W) + lp / WAVE_W) * R.W + tile_x0 + lp % WAVE_W;   // entries only exist for in-image pixels
             if (!have[j]) pix[j] = 0;
@@ -2584,6 +2594,11 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             if (j > 0 && g0 + j * 64 >= n_p) break;                  // wave-uniform
+#if DT_RO_SKIP_UNCOVERED
+            // a pixel no mesh triangle covers, and that is no plane edge either, already holds its colour (the raster's)
+            have[j] = have[j] && (pedge[j] || (tbest[j][0] & tbest[j][1] & tbest[j][2] & tbest[j][3]) >= 0);   // all four < 0  <=>  the AND is negative
+            if (!__ballot(have[j])) continue;                        // wave-uniform: nothing of this batch needs shading
+#endif
             if (have[j]) {
 #ifdef DT_RO_NOSHADE
               const uint32_t v = (uint32_t)tbest[j][0] ^ (uint32_t)tbest[j][1] ^ (uint32_t)tbest[j][2] ^ (uint32_t)tbest[j][3];
