@@ -817,10 +817,12 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
     };
     for (int j = 0; j < fill; ++j) {                   // wave-uniform
       const float4 bb = *reinterpret_cast<const float4*>(&w_tris[j]);              // bx0, bx1, by0, by1
-      const bool in = mine & (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
-      const unsigned long long m = __ballot(in);
+      // four compares straight into scalar masks, ANDed on the scalar unit (as one bool expression the compiler builds the
+      // conjunction out of 0 / 1 integers: 17 vector instructions instead of 4)
+      const unsigned long long m = mm & __ballot(pcx >= bb.x) & __ballot(pcx <= bb.y) & __ballot(pcy >= bb.z) & __ballot(pcy <= bb.w);
       if (!m) continue;
-      if (in) plist[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((j << 6) | lane);
+      if (__builtin_amdgcn_inverse_ballot_w64(m))
+        plist[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((j << 6) | lane);
       base += __popcll(m);
 #ifdef DT_RO_STATS
       n_pairs += __popcll(m);
