@@ -2329,7 +2329,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
 // batches of one raster workgroup's four queue regions) from the global list k_raster appended to.
-__global__ __launch_bounds__(RB) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
+#ifndef DT_RES_WAVES
+#define DT_RES_WAVES 5             // wavefronts per SIMD k_resolve is compiled for (90 VGPRs)
+#endif
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES, DT_RES_WAVES))) void k_resolve(RenderParams R, const EnvCam* __restrict__ cams,
                                                 const uint16_t* __restrict__ queue, const int32_t* __restrict__ qcount) {
   extern __shared__ uint32_t s_mem[];
   TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
