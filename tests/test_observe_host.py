@@ -55,3 +55,18 @@ def test_resize_matches_pil_on_random_sizes():
         want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
         got = resample.resize_bilinear(img, oh, ow)
         assert np.array_equal(got, want), ((H, W), (oh, ow))
+
+
+@pytest.mark.parametrize("n_in,n_out,S", [(640, 160, 4), (640, 80, 8), (480, 240, 2), (480, 120, 4), (480, 60, 8), (320, 80, 4)])
+def test_power_of_two_scales_have_uniform_small_integer_taps(n_in, n_out, S):
+    """What dtsim_observe's fast kernels (k_observe_pow2, the dot4 / two-lane paths of k_observe) rely on, and detect from the tables at
+    run time: for a power-of-two scale S every interior output coordinate has the SAME 2S taps, starting at S*o - S/2, and they are the
+    triangle weights (1, 3, .., 2S-1, 2S-1, .., 3, 1) times 2^(22 - log2(2 S^2)) exactly; only the first and last coordinate are clipped."""
+    bounds, kk = resample.coeffs(n_in, n_out)
+    tri = [2 * t + 1 for t in range(S)] + [2 * t + 1 for t in range(S - 1, -1, -1)]
+    shift = 22 - int(np.log2(2 * S * S))
+    assert sum(tri) == 2 * S * S and kk.shape[1] >= 2 * S
+    for o in range(1, n_out - 1):
+        assert bounds[o, 0] == S * o - S // 2 and bounds[o, 1] == 2 * S
+        assert kk[o, :2 * S].tolist() == [w << shift for w in tri]
+    assert bounds[0, 0] == 0 and bounds[0, 1] < 2 * S and bounds[-1, 0] + bounds[-1, 1] == n_in
