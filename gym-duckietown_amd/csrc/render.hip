@@ -56,6 +56,26 @@
 #endif
 #include <type_traits>
 
+// Format-converting buffer loads (MTBUF): tbuffer_load_format_d16_xyzw with format 8_8_8_8 / UINT returns the four BYTES of one
+// dword as four u16 in two registers -- exactly the operand pairs of v_dot2_u32_u16.  clang has no builtin for it; the LLVM
+// intrinsic is reached by name (its immediates must be literals after inlining).  Checked on the part by tools/ubench/fmt_load.hip.
+typedef int v3_i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 v3_h16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t v3_u32x3 __attribute__((ext_vector_type(3)));
+__device__ v3_h16x4 v3_tbuf_load_d16x4(v3_i32x4 rsrc, int voffset, int soffset, int format, int aux) __asm("llvm.amdgcn.raw.tbuffer.load.v4f16");
+__device__ int v3_buf_load_i32(v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ void v3_buf_store_v3i32(v3_u32x3 data, v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v3i32");
+typedef uint32_t v3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ void v3_buf_store_v4i32(v3_u32x4 data, v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
+#define V3_FMT_8888_UINT 74        // dfmt 10 (8_8_8_8) | nfmt 4 (UINT) << 4
+#define V3_RSRC_W3 0x00027000      // raw buffer descriptor word 3 (the MTBUF instruction carries its own format)
+__device__ inline v3_i32x4 v3_rsrc(const void* p, uint32_t bytes) {
+  v3_i32x4 r;
+  r.x = (int)(uint32_t)reinterpret_cast<uintptr_t>(p); r.y = (int)((reinterpret_cast<uintptr_t>(p) >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = V3_RSRC_W3;
+  return r;
+}
+
+
 #define RB 256            // threads per workgroup (4 wavefronts)
 #define PPT DT_PPT         // pixels per thread
 #define WAVE_W DT_WAVE_W  // pixel columns per wavefront block (dtsim_dev.h)
@@ -2324,7 +2344,16 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 }
 
 #include "render_v3.inc"
+#if DT_V3_DR && !(DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1)   // experimental block shapes / lane maps of k_raster_v3: the generic kernels keep domain randomisation
+#undef DT_V3_DR
+#define DT_V3_DR 0
+#endif
+#if DT_V3_DR
 #include "render_v3dr.inc"
+#else
+struct EnvD { float v[48]; };
+__device__ inline void fill_envd_at(EnvD*, int, const EnvCam&, const EnvQ&, const RenderMapDev&, float, int, int) {}
+#endif
 
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
@@ -2681,12 +2710,12 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
     // k_raster_v3 (render_v3.inc): S = 256 textures, padded grids up to 32 x 24 tiles, up to 4 maps (else k_raster_q)
     const bool v3 = R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= V3_MAX_ROWS && R.n_maps * V3_MAP_COLS <= V3_TAB_PITCH / 2 &&
-                    (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP == 0));
+                    (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP != 1));
     if (v3) {
       const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
 #define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, R.frames, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
-#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP == 0
+#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1
       if (obj) LAUNCH_V3(true); else
 #endif
       LAUNCH_V3(false);
@@ -2694,10 +2723,12 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
     } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
     else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
 #undef LAUNCH_Q
+#if DT_V3_DR
   } else if (v3dr) {
     const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
     if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
     else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+#endif
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER

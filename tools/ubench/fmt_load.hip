@@ -47,7 +47,7 @@ __global__ void k_check(const uint8_t* pool, uint32_t bytes, uint32_t w3, const 
 #define ITERS 256
 #endif
 template <int MODE, int FILL>
-__global__ __launch_bounds__(256) void k_rate(const uint8_t* pool, const uint8_t* pool32, uint32_t n_rec, uint32_t w3, uint32_t* out) {
+__global__ __launch_bounds__(256) void k_rate(const uint8_t* pool, const uint8_t* pool32, uint32_t n_rec, uint32_t w3, uint32_t* out, uint32_t lane_stride) {
   const i32x4 r = make_rsrc(pool, n_rec * 16u, w3), r32 = make_rsrc(pool32, n_rec * 32u, w3);
   const uint32_t wave = (blockIdx.x * 4u + (threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   uint32_t acc = 0, h = wave * 2654435761u + 12345u;
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_rate(const uint8_t* pool, const uint8_t
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       h = h * 1664525u + 1013904223u;
-      rec[k] = ((h >> 8) + lane * ((h >> 5) & 3u ? 1u : 3u)) & (n_rec - 1u);   // mostly unit stride across lanes, sometimes 3
+      // lane_stride 0: mostly unit stride across lanes, sometimes 3 (a texture row under magnification); else that many records
+      rec[k] = ((h >> 8) + lane * (lane_stride ? lane_stride : ((h >> 5) & 3u ? 1u : 3u))) & (n_rec - 1u);
     }
     uint32_t w0 = 0x40004000u + it, w1 = 0x3fff4000u - it;
 #pragma unroll
@@ -141,11 +142,12 @@ int main() {
   if (!w3_ok) { printf("format loads do not return the expected values on this part\n"); w3_ok = w3s[0]; }
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const int blocks = 256 * 5 * 4;                           // 5 workgroups of 4 wavefronts per CU, four rounds
+  uint32_t pool_recs = N, lane_stride = 0;
   auto run = [&](const char* name, auto kern) {
     float best = 1e30f;
     for (int rr = 0; rr < 4; ++rr) {
       CK(hipEventRecord(a));
-      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, pool, pool32, N, w3_ok, out);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, pool, pool32, pool_recs, w3_ok, out, lane_stride);
       CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b));
       if (rr && ms < best) best = ms;
@@ -159,6 +161,16 @@ int main() {
   run("buffer_load_dwordx4 (16 B)   FILL " #FILL, k_rate<3, FILL>); \
   run("3 x tbuffer d16 + dword      FILL " #FILL, k_rate<1, FILL>); \
   run("2 x global dwordx4 (32 B)    FILL " #FILL, k_rate<2, FILL>);
+  printf("-- 8 MB pool (the raster's class), lanes mostly unit stride\n");
   RUNS(0) RUNS(64) RUNS(96)
+  // what a gather costs the texture unit by the number of cache lines its 64 lanes touch: a HOT pool (16 K records = 256 KB:
+  // L2 hits, no fabric traffic), lanes 1 / 9 / 257 records apart (9: every lane its own 128-byte line, 257: the diagonal of a block)
+  pool_recs = 16384;
+  const uint32_t strides[3] = {1, 9, 257};
+  for (int si = 0; si < 3; ++si) {
+    lane_stride = strides[si];
+    printf("-- 256 KB pool, lanes %u records apart\n", lane_stride);
+    RUNS(0) RUNS(96)
+  }
   return 0;
 }
