@@ -100,84 +100,146 @@ class ShardedSimulator:
         return gather_batch(self.local_frames(), self.world, group, dst)
 
     # ---- the learner's exchange, overlapped with the simulation ---------------------------------------
-    def _render_into(self, buf):
-        """Render this rank's envs into `buf` ([n, H, W, 3] uint8, device memory) and wait for the pass: the library
-        writes its frames wherever dtsim_bind_frames points, so the send buffer IS the frame buffer."""
-        if hasattr(self.sim, "render_into"):             # stand-in simulators of the CPU tests
-            self.sim.render_into(buf)
+    # Layout (round 4): per buffer slot ONE preallocated [world*n, ...] tensor on the root; the root's own envs are rendered
+    # (or observed) straight into its slice of it, every other rank's batch is received into ITS slice (point-to-point,
+    # one transfer per xGMI link into the root) -- no torch.cat, no self-copy, and what the learner gets IS that tensor.
+    def _produce(self, buf, what: str, obs):
+        """This rank's payload of the current step into `buf` (device memory), complete on return (host-level wait on the
+        library's stream: the exchange that reads `buf` is enqueued on another stream).  what = "frames": the render pass
+        writes there directly (dtsim_bind_frames); "observe": render into the library's buffer, dtsim_observe into `buf`."""
+        if what == "frames":
+            if hasattr(self.sim, "render_into"):         # stand-in simulators of the CPU tests
+                self.sim.render_into(buf)
+                return
+            self.sim.bind_frames(buf.data_ptr())
+            self.sim.render()
+            self.sim.sync()
             return
-        self.sim.bind_frames(buf.data_ptr())
+        if hasattr(self.sim, "observe_into"):            # stand-in simulators of the CPU tests
+            self.sim.observe_into(buf, *obs[:2])
+            return
         self.sim.render()
+        self.sim.observe(obs[0], obs[1], out=buf, **(obs[2] if len(obs) > 2 else {}))
         self.sim.sync()
 
-    def _frame_like(self):
+    def _payload_shape(self, what: str, obs):
+        n = self.hi - self.lo
+        if hasattr(self.sim, "frames_tensor"):           # stand-in simulators of the CPU tests
+            f = self.sim.frames_tensor()
+            return ((n,) + tuple(f.shape[1:]) if what == "frames" else (n, obs[0], obs[1], 3)), f.dtype, f.device
         import torch
-        if hasattr(self.sim, "frames_tensor"):
-            return torch.empty_like(self.sim.frames_tensor())
-        dev = f"cuda:{self.sim.device_index}"
-        shape = (self.hi - self.lo, self.sim.camera_height, self.sim.camera_width, 3)
-        return torch.empty(shape, dtype=torch.uint8, device=dev)
+        dev = torch.device(f"cuda:{self.sim.device_index}")
+        if what == "frames":
+            return (n, self.sim.camera_height, self.sim.camera_width, 3), torch.uint8, dev
+        kw = obs[2] if len(obs) > 2 else {}
+        shape = (n, 3, obs[0], obs[1]) if kw.get("chw") else (n, obs[0], obs[1], 3)
+        return shape, (torch.float32 if kw.get("normalize") else torch.uint8), dev
+
+    def _exchange_state(self, what: str, obs, dst: int, group):
+        import torch
+        import torch.distributed as dist
+        key = (what, tuple(obs[:2]) if obs else None, dst)
+        gx = getattr(self, "_gx", None)
+        if gx is not None and gx["key"] == key:
+            return gx
+        shape, dtype, dev = self._payload_shape(what, obs)
+        rank = dist.get_rank(group) if self.world > 1 else 0
+        n = shape[0]
+        slots = []
+        for _ in range(2):
+            if rank == dst:
+                recv = torch.empty((self.world * n,) + tuple(shape[1:]), dtype=dtype, device=dev)
+                send = recv[rank * n:(rank + 1) * n]       # the root produces in place
+            else:
+                recv, send = None, torch.empty(shape, dtype=dtype, device=dev)
+            slots.append({"recv": recv, "send": send, "works": None})
+        gx = self._gx = {"key": key, "slots": slots, "t": 0, "rank": rank, "n": n, "what": what}
+        return gx
+
+    def _start_exchange(self, slot, gx, dst: int, group):
+        """Asynchronous gather-to-root of slot's payload: receives into the slices of the root's tensor, one send per other rank."""
+        import torch.distributed as dist
+        slot["waited"] = False
+        if self.world == 1:
+            slot["works"] = []
+            return
+        n, rank = gx["n"], gx["rank"]
+        if rank == dst:
+            ops = [dist.P2POp(dist.irecv, slot["recv"][r * n:(r + 1) * n], r, group) for r in range(self.world) if r != dst]
+        else:
+            ops = [dist.P2POp(dist.isend, slot["send"], dst, group)]
+        slot["works"] = list(dist.batch_isend_irecv(ops))
+        slot["waited"] = False
+
+    @staticmethod
+    def _wait(slot, host: bool):
+        """Wait for the exchange that uses `slot`.  On RCCL a Work.wait() only orders torch's CURRENT STREAM behind the
+        transfer; the library renders on its own stream, so before a buffer is produced into again the HOST waits
+        (host=True) -- stream-level ordering is enough for handing the tensor to torch consumers (host=False)."""
+        works = slot["works"]
+        if works is None:
+            return
+        if not slot.get("waited"):                       # (a second wait() on a gloo receive blocks for ever)
+            for w in works:
+                w.wait()
+            slot["waited"] = True
+        if host:
+            t = slot["send"]
+            if t.is_cuda:
+                import torch
+                torch.cuda.current_stream(t.device).synchronize()
+            slot["works"] = None                         # only now: nothing reads or writes the slot's buffers any more
 
     def step_render_gather(self, global_actions, n_steps: int = 1, *, overlap: bool = True, dst: int = 0, group=None,
-                           local_actions: bool = False):
-        """One learner iteration: step this rank's envs, render them, and gather the frame batch to rank `dst`.
+                           local_actions: bool = False, what: str = "frames", obs=None):
+        """One learner iteration: step this rank's envs, render them, and gather the batch to rank `dst`.
 
-        overlap=False: blocking; returns (t, frames) -- frames = [world*n, H, W, 3] of THIS step on `dst`, None elsewhere.
-        overlap=True (the design of SURVEY 8e): the gather of step t runs while step t+1 is simulated and rendered.
-        Two frame buffers rotate through dtsim_bind_frames: step t renders into buffer t % 2 and its asynchronous
-        gather-to-root starts right away; the call returns the frames of step t-1 (whose gather is waited for here),
-        i.e. the learner runs one step behind the simulator, and `flush_gather()` hands out the last step's.  A buffer
-        is only rendered into again after the gather that reads it has completed (no torn frames): the wait on
-        `works[b]` below.  Returns (t-1, frames of step t-1 on `dst` / None elsewhere), or (None, None) on the first call.
-        3.77 GB per rank per step is xGMI-link bound: this hides the simulation behind the exchange, it
-        does not make the exchange faster -- gather `observe()` output when the learner takes 160x120."""
-        import torch.distributed as dist
+        what="frames": the [n, H, W, 3] uint8 frame batch (3.77 GB per rank at the BASELINE size: xGMI-link bound, DESIGN.md 6);
+        what="observe", obs=(h, w[, observe() keywords]): the dtsim_observe output of the step instead (57.6 KB per env at
+        160 x 120: the exchange the north star's learner can actually keep up with).
+        overlap=False: blocking; returns (t, batch) -- batch = [world*n, ...] of THIS step on `dst`, None elsewhere.
+        overlap=True: the gather of step t runs while step t+1 is simulated and rendered.  Two buffer slots
+        rotate; the call returns the batch of step t-1 (the learner runs one step behind the simulator; `flush_gather()`
+        hands out the last one).  The tensor returned on `dst` is the slot's preallocated receive tensor itself (no copy):
+        it stays valid until the next-but-one call.  A slot is produced into again only after the HOST has seen the end of the
+        transfer that read it.  Returns (t-1, batch) or (None, None) on the first call."""
+        if what not in ("frames", "observe") or (what == "observe" and not obs):
+            raise ValueError("what = 'frames' or 'observe' (with obs=(height, width[, keywords]))")
         if local_actions:                                # already this rank's slice (e.g. a device tensor)
             self.sim.step(global_actions, n_steps)
         else:
             self.step(global_actions, n_steps)
-        if not overlap or self.world == 1:
+        gx = self._exchange_state(what, obs, dst, group)
+        if not overlap:
             t = getattr(self, "_gather_t", 0)
             self._gather_t = t + 1
-            if hasattr(self.sim, "render_into"):         # stand-in simulators of the CPU tests
-                if getattr(self, "_gbuf", None) is None:
-                    self._gbuf = self._frame_like()
-                self.sim.render_into(self._gbuf)
-                return t, gather_batch(self._gbuf, self.world, group, dst)
-            self.sim.render()                            # into the library's own frame buffer
-            return t, self.gather_frames(dst, group)
-        gx = getattr(self, "_gx", None)
-        if gx is None:
-            rank = dist.get_rank(group)
-            gx = self._gx = {"bufs": [self._frame_like() for _ in range(2)], "works": [None, None], "t": 0, "rank": rank,
-                             "roots": [[self._frame_like() for _ in range(self.world)] if rank == dst else None for _ in range(2)]}
+            slot = gx["slots"][0]
+            self._wait(slot, host=True)
+            self._produce(slot["send"], what, obs)
+            self._start_exchange(slot, gx, dst, group)
+            self._wait(slot, host=True)
+            return t, slot["recv"]
         t, b = gx["t"], gx["t"] % 2
-        if gx["works"][b] is not None:                   # the gather of step t-2 read this buffer: it must be done
-            gx["works"][b].wait()
-        self._render_into(gx["bufs"][b])
-        gx["works"][b] = dist.gather(gx["bufs"][b], gx["roots"][b], dst=dst, group=group, async_op=True)
+        slot = gx["slots"][b]
+        self._wait(slot, host=True)                      # the transfer of step t-2 read / wrote this slot
+        self._produce(slot["send"], what, obs)
+        self._start_exchange(slot, gx, dst, group)
         gx["t"] = t + 1
         if t == 0:
             return None, None
-        return t - 1, self._collect(1 - b, dst)
-
-    def _collect(self, b: int, dst: int):
-        import torch
-        gx = self._gx
-        if gx["works"][b] is not None:
-            gx["works"][b].wait()
-            gx["works"][b] = None
-        if gx["rank"] != dst:
-            return None
-        return torch.cat(gx["roots"][b], dim=0)
+        prev = gx["slots"][1 - b]
+        self._wait(prev, host=False)
+        return t - 1, prev["recv"]
 
     def flush_gather(self, dst: int = 0):
-        """Frames of the last step issued by step_render_gather(overlap=True): (t, frames on `dst` / None)."""
+        """Batch of the last step issued by step_render_gather(overlap=True): (t, batch on `dst` / None)."""
         gx = getattr(self, "_gx", None)
         if gx is None or gx["t"] == 0:
             return None, None
         t = gx["t"] - 1
-        out = self._collect(t % 2, dst)
-        if hasattr(self.sim, "bind_frames"):
+        slot = gx["slots"][t % 2]
+        self._wait(slot, host=True)
+        self._wait(gx["slots"][1 - t % 2], host=True)
+        if gx["what"] == "frames" and hasattr(self.sim, "bind_frames"):
             self.sim.bind_frames(None)                   # back to the library's own buffer
-        return t, out
+        return t, slot["recv"]

@@ -7,8 +7,14 @@
   C5  configs[4]: MultiMap, both *_only_duckies maps alternating per env slot, 640x480 + fisheye, shared camera:
       k_raster_v3<OBJ> + k_resolve_obj over more than one env chunk.
 
+  C4 / C5 at N = 4096 (round 4): the same two configurations at the batch size the bench lines are quoted on -- 32 (C4) and 16 (C5)
+      envs of the 4096-env batch picked like the C3 test (first / last env, both sides of 32-env chunk borders, the middle of
+      every XCD's eighth of the chunks, the tail chunk), each rendered by the oracle directly.
+
 Reference: simulator.py:1707-1951 (_render_img), objects.py:384-431 (DuckieObj.step), envs/multimap_env.py:44-49.
-Same thresholds as tests/test_gpu_render.py (stated there); the oracle is oracle/raster.py in its "pixel" lighting mode.
+Thresholds ("Tolerances"): plane-only scenes 1e-3 / 5e-4 / 0.02 (fraction of pixels beyond +-1, beyond +-2, mean |error| in
+1/255); scenes with mesh objects 2e-3 / 1e-3 / 0.03 (silhouette pixels of the meshes flip coverage where float32 edge functions
+meet the oracle's float64 ones).  The oracle is oracle/raster.py in its "pixel" lighting mode.
 """
 import numpy as np
 import pytest
@@ -20,6 +26,26 @@ from test_gpu_render import _camera, _obj_states, _scene, _stats
 
 pytestmark = pytest.mark.gpu
 W, H = 640, 480
+OBJ_TOL = dict(frac_gt1=2e-3, frac_gt2=1e-3, mean=0.03)     # scenes with mesh objects
+
+
+def _stratified_picks(N, n_min, seed):
+    """Env indices of an N-env batch that exercise the raster's work decomposition: envs are rendered in index order, 32 per
+    workgroup chunk, XCD x owning the x-th eighth of the chunks (render_v3.inc: XCD-affine workgroup map)."""
+    picks = [0, 1, 31, 32, 33, 63, 64, N - 1, N - 2, N - 32, N - 33]
+    for x in range(8):                                     # the middle of every XCD's eighth, both sides of a chunk border there
+        m = x * (N // 8) + N // 16
+        picks += [m - 1, m]
+    rng = np.random.default_rng(seed)
+    while len(set(picks)) < n_min:
+        picks.append(int(rng.integers(N)))
+    return sorted(set(int(p) for p in picks if 0 <= p < N))
+
+
+def _frames_of(sim, picks):
+    import torch
+    frames = torch.as_tensor(sim.frames_device(), device="cuda:0")
+    return frames[torch.as_tensor(np.array(picks), device="cuda:0")].cpu().numpy()
 
 
 def test_c3_full_size_batch_matches_oracle_directly():
@@ -116,4 +142,69 @@ def test_c5_config_matches_oracle():
         s = _stats(frames[e], ref)
         assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, int(mid[e]), s)
     assert n_obj_px > 200, n_obj_px
+    sim.close()
+
+
+def test_c4_full_size_batch_matches_oracle_directly():
+    """C4 at the size its bench line is quoted on: 4096 envs of loop_pedestrians with domain randomisation and fisheye after 260
+    steps; k_raster_v3dr + k_resolve + k_resolve_obj over 128 chunks, every XCD slice, the persistent work lists wrapped many times."""
+    N, steps = 4096, 260
+    sim = BatchedSimulator("loop_pedestrians", N, camera_width=W, camera_height=H, distortion=True, domain_rand=True,
+                           seed=31, max_steps=100000)
+    for _ in range(steps // 52):                           # 260 steps, 52 per launch
+        sim.step(np.zeros((52, N, 2), np.float32), n_steps=52)
+    assert sim.read(_ffi.FIELD_OBJ_ACTIVE).any()
+    sim.render()
+    sim.sync()
+    picks = _stratified_picks(N, 32, 2)
+    assert len(picks) >= 32
+    sub = _frames_of(sim, picks)
+    scene = _scene("loop_pedestrians")
+    rmap = pdist.distortion_maps(W, H)
+    worst = dict(frac_gt1=0.0, frac_gt2=0.0, mean=0.0)
+    n_obj_px = 0
+    for k, e in enumerate(picks):
+        cam = _camera(sim, e, W, H, True)
+        st = _obj_states(sim, e, scene)
+        ref = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
+        if k < 6:
+            no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
+            n_obj_px += int((np.abs(ref.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
+        s = _stats(sub[k], ref)
+        assert all(s[f] <= OBJ_TOL[f] for f in OBJ_TOL), (e, s)
+        for f in worst:
+            worst[f] = max(worst[f], s[f])
+    assert n_obj_px > 200, n_obj_px
+    print("C4 4096-env batch, %d envs against the oracle: worst" % len(picks), worst)
+    sim.close()
+
+
+def test_c5_full_size_batch_matches_oracle_directly():
+    """C5's per-GPU share at the size its bench line is quoted on: 4096 envs over both *_only_duckies maps (MultiMap slot
+    alternation), shared camera, fisheye: k_raster_v3<OBJ> + k_resolve_obj."""
+    N = 4096
+    names = ["loop_only_duckies", "small_loop_only_duckies"]
+    sim = BatchedSimulator(names, N, camera_width=W, camera_height=H, distortion=True, domain_rand=False, seed=17,
+                           map_cycle=True, max_steps=100000)
+    sim.reset(mask=(np.arange(N) % 2 == 0))                # multimap_env.py:44-49 (see test_c5_config_matches_oracle)
+    acts = np.random.default_rng(4).uniform(0.1, 0.6, (6, N, 2)).astype(np.float32)
+    sim.step(acts, n_steps=6)
+    sim.render()
+    sim.sync()
+    mid = sim.read(_ffi.FIELD_MAP_ID)
+    assert set(np.unique(mid)) == {0, 1}
+    picks = _stratified_picks(N, 16, 3)
+    assert len(picks) >= 16 and {int(mid[e]) for e in picks} == {0, 1}
+    sub = _frames_of(sim, picks)
+    scenes = [_scene(n) for n in names]
+    rmap = pdist.distortion_maps(W, H)
+    worst = dict(frac_gt1=0.0, frac_gt2=0.0, mean=0.0)
+    for k, e in enumerate(picks):
+        scene = scenes[int(mid[e])]
+        ref = raster.render_obs(_camera(sim, e, W, H, False), scene, "pixel", rmap, obj_states=_obj_states(sim, e, scene))
+        s = _stats(sub[k], ref)
+        assert all(s[f] <= OBJ_TOL[f] for f in OBJ_TOL), (e, int(mid[e]), s)
+        for f in worst:
+            worst[f] = max(worst[f], s[f])
+    print("C5 4096-env batch, %d envs against the oracle: worst" % len(picks), worst)
     sim.close()

@@ -62,6 +62,12 @@ class _FakeSim:
         buf[:, half:].copy_(f[:, half:])
 
 
+    def observe_into(self, buf, h, w):
+        """The 'dtsim_observe' of the current step: [n, h, w, 3] bytes that encode (global env, step, size)."""
+        lo = self.seed - self.BASE
+        buf.copy_(_fake_frames(lo, lo + self.n, h, w) + torch.tensor((self.n_steps_done * 13 + h) % 256, dtype=torch.uint8))
+
+
 def _step_frames(lo, hi, t):
     return _fake_frames(lo, hi) + torch.tensor(t * 13 % 256, dtype=torch.uint8)
 
@@ -118,10 +124,31 @@ def _worker(rank, world, port, total, q):
                 got_steps.append(tt)
             else:
                 ok = ok and fr is None
+            # zero extra copies on the root: what comes back IS the slot's preallocated [world*n, ...] receive tensor, and
+            # the root's own envs were rendered straight into its slice of it
+            slot = ss2._gx["slots"][tt % 2]
+            if rank == 0:
+                ok = ok and fr.data_ptr() == slot["recv"].data_ptr() and tuple(fr.shape) == (total,) + tuple(_fake_frames(0, 1).shape[1:])
+                ok = ok and slot["send"].data_ptr() == slot["recv"][lo:hi].data_ptr()
+            else:
+                ok = ok and slot["recv"] is None
         tt, fr = ss2.flush_gather(dst=0)
         ok = ok and tt == T - 1
         if rank == 0:
             ok = ok and bool(torch.equal(fr, _step_frames(0, total, T))) and got_steps == list(range(T - 1))
+        # the same loop on the dtsim_observe output (what the learner takes at 160 x 120): 4 x 5 stand-in observations
+        ss4 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+        for t in range(4):
+            tt, ob = ss4.step_render_gather(a1, overlap=True, dst=0, what="observe", obs=(4, 5))
+            if t == 0:
+                ok = ok and tt is None and ob is None
+            elif rank == 0:
+                want = _fake_frames(0, total, 4, 5) + torch.tensor(((tt + 1) * 13 + 4) % 256, dtype=torch.uint8)
+                ok = ok and tt == t - 1 and tuple(ob.shape) == (total, 4, 5, 3) and bool(torch.equal(ob, want))
+            else:
+                ok = ok and ob is None
+        tt, ob = ss4.flush_gather(dst=0)
+        ok = ok and tt == 3 and ((rank == 0 and bool(torch.equal(ob, _fake_frames(0, total, 4, 5) + torch.tensor((4 * 13 + 4) % 256, dtype=torch.uint8)))) or (rank != 0 and ob is None))
         # blocking variant: the frames of this very step
         ss3 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
         for t in range(3):
