@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "dtsim_dev.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -939,6 +940,47 @@ int dtsim_bind_frames(dtsim_t* h, void* devptr) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
   if (!h->frames_own) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
   h->frames = devptr ? (uint8_t*)devptr : h->frames_own;
+  return DTSIM_OK;
+}
+
+// ---- RCCL all-gather of the frame batch (include/dtsim.h) ---------------------------------
+// librccl is resolved at first use: the product path of a single GPU never loads it.
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+nccl_allgather_fn g_nccl_allgather = nullptr;
+nccl_errstr_fn g_nccl_errstr = nullptr;
+bool g_nccl_tried = false;
+void resolve_rccl() {
+  if (g_nccl_tried) return;
+  g_nccl_tried = true;
+  void* lib = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);      // (the process's own copy when torch already loaded it)
+    if (lib) break;
+  }
+  if (!lib) return;
+  g_nccl_allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
+  g_nccl_errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(lib, "ncclGetErrorString"));
+}
+}  // namespace
+
+int dtsim_allgather_frames(dtsim_t* h, void* nccl_comm, void* recv, const void* send, size_t send_bytes) {
+  if (!h || !nccl_comm || !recv) return fail(DTSIM_E_INVALID, "bad argument");
+  if (!send) {
+    if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+    send = h->frames;
+    send_bytes = dtsim_frames_bytes(h);
+  }
+  if (send_bytes == 0) return fail(DTSIM_E_INVALID, "empty send buffer");
+  resolve_rccl();
+  if (!g_nccl_allgather) {
+    const char* why = dlerror();
+    return fail(DTSIM_E_STATE, "librccl.so (ncclAllGather) could not be loaded: %s", why ? why : "library or symbol not found");
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int rc = g_nccl_allgather(send, recv, send_bytes, /*ncclUint8*/ 1, nccl_comm, h->stream);
+  if (rc != 0) return fail(DTSIM_E_HIP, "ncclAllGather: %s", g_nccl_errstr ? g_nccl_errstr(rc) : "error");
   return DTSIM_OK;
 }
 

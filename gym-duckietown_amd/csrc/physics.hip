@@ -87,18 +87,15 @@ __device__ inline void proj4(double nx, double nz, const double* c, double& mn, 
 // With L > 1, L adjacent lanes of a wavefront work on ONE env: everything serial (dynamics, trigonometry, the Bezier
 // bisection) runs redundantly on all of them -- identical inputs, identical results, identical (duplicate) stores -- and
 // the loops over OBJECTS (collision.py:129-186 intersects / intersects_single_obj, simulator.py:1430-1459
-// proximity_penalty2, objects.py step()) are split: lane `sub` takes objects sub, sub + L, ...  Flags are OR-ed and
-// penalties summed over the group with a butterfly of DPP / permute moves, which leaves the same bits in every lane.
+// proximity_penalty2, objects.py step()) are split: lane `sub` takes objects sub, sub + L, ...  Flags are OR-ed over the
+// group with a butterfly of permute moves; penalties are added IN OBJECT ORDER by every lane (one shuffle per object), so
+// reward and proximity carry the reference's order of additions -- the same bits -- for every L.
 struct Coop { int sub, L; };
 __device__ inline bool grp_any(bool v, const Coop& c) {
   if (c.L == 1) return v;
   int x = v ? 1 : 0;
   for (int d = 1; d < c.L; d <<= 1) x |= __shfl_xor(x, d);
   return x != 0;
-}
-__device__ inline double grp_sum(double v, const Coop& c) {
-  for (int d = 1; d < c.L; d <<= 1) v += __shfl_xor(v, d);
-  return v;
 }
 
 __device__ inline bool sat_pair(const double* ac, const double* an, const double* oc, const double* on) {
@@ -177,32 +174,44 @@ __device__ inline double proximity(const MapView& m, const SimArrays& A, const D
   double total = 0.0;
   const int ns = m.h->n_static;
   if (ns > 0) {
+    // L lanes per env: lane `sub` scores objects sub, sub + L, ...; the scores of a round are then ADDED IN OBJECT ORDER by every
+    // lane (one shuffle per object), so the sum has the reference's order of additions whatever L is (round-3 advisor: a butterfly
+    // sum made the reward's last bit depend on the batch size)
     bool gate = false;
     double sum = 0.0;
-    for (int s = co.sub; s < ns; s += co.L) {
-      const double* r = m.stat + s * STATIC_WORDS;
-      const double ddx = r[12] - cx, ddz = r[13] - cz;
-      const double d = sqrt((ddx * ddx + 0.0) + ddz * ddz);
-      const double r2 = r[14];
-      const double d2 = d * d, lo = (r1 - r2) * (r1 - r2), hi = (r1 + r2) * (r1 + r2);
-      gate = gate || (lo <= d2 && d2 <= hi) || (d < fabs(r1 - r2));
-      const double score = (d - r1) - r2;
-      if (score < 0) sum += score;
+    for (int s0 = 0; s0 < ns; s0 += co.L) {
+      const int s = s0 + co.sub;
+      double neg = 0.0;
+      if (s < ns) {
+        const double* r = m.stat + s * STATIC_WORDS;
+        const double ddx = r[12] - cx, ddz = r[13] - cz;
+        const double d = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+        const double r2 = r[14];
+        const double d2 = d * d, lo = (r1 - r2) * (r1 - r2), hi = (r1 + r2) * (r1 + r2);
+        gate = gate || (lo <= d2 && d2 <= hi) || (d < fabs(r1 - r2));
+        const double score = (d - r1) - r2;
+        if (score < 0) neg = score;
+      }
+      if (co.L == 1) sum += neg;
+      else for (int j = 0; j < co.L && s0 + j < ns; ++j) sum += __shfl(neg, j, co.L);
     }
-    if (co.L > 1) { gate = grp_any(gate, co); sum = grp_sum(sum, co); }
+    if (co.L > 1) gate = grp_any(gate, co);
     total = gate ? sum : 0.0;
   }
   const int nd = m.h->n_dyn;
   const int N = A.N;
-  double dsum = 0.0;
-  for (int d = co.sub; d < nd; d += co.L) {
-    const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddy = 0.0 - A.ob_cy[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
-    const double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);     // |agent_pos - center| in 3-D (objects.py:373-382, 525)
-    const double score = (dist - r1) - dyn[d].safety_radius;
-    if (co.L == 1) total += fmin(0.0, score);        // the reference's order of additions
-    else dsum += fmin(0.0, score);
+  for (int d0 = 0; d0 < nd; d0 += co.L) {
+    const int d = d0 + co.sub;
+    double pen = 0.0;
+    if (d < nd) {
+      const double ddx = cx - A.ob_cx[(size_t)d * N + e], ddy = 0.0 - A.ob_cy[(size_t)d * N + e], ddz = cz - A.ob_cz[(size_t)d * N + e];
+      const double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);     // |agent_pos - center| in 3-D (objects.py:373-382, 525)
+      const double score = (dist - r1) - dyn[d].safety_radius;
+      pen = fmin(0.0, score);
+    }
+    if (co.L == 1) total += pen;                       // the reference's order of additions ...
+    else for (int j = 0; j < co.L && d0 + j < nd; ++j) total += __shfl(pen, j, co.L);   // ... for every L
   }
-  if (co.L > 1) total += grp_sum(dsum, co);          // (another order of the same additions: within 1 ulp of the sum)
   return total;
 }
 

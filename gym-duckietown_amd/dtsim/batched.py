@@ -449,6 +449,18 @@ class BatchedSimulator:
     def bind_frames(self, devptr: Optional[int]):
         _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
 
+    def allgather_frames(self, nccl_comm: int, recv, send=None):
+        """RCCL all-gather of this rank's frame batch (or of `send`, any object with __cuda_array_interface__, e.g. the
+        observe() output) into `recv` ([n_ranks, ...] device memory), enqueued on the library's stream behind the last
+        render: dtsim_allgather_frames (include/dtsim.h).  `nccl_comm`: the ncclComm_t as an integer (address)."""
+        rp = recv.__cuda_array_interface__["data"][0]
+        sp, sb = None, 0
+        if send is not None:
+            ai = send.__cuda_array_interface__
+            sp = ai["data"][0]
+            sb = int(np.prod(ai["shape"])) * np.dtype(ai["typestr"]).itemsize
+        _ffi.check(self._lib, self._lib.dtsim_allgather_frames(self._h, C.c_void_p(nccl_comm), C.c_void_p(rp), C.c_void_p(sp), C.c_size_t(sb)))
+
     def observe(self, height: int, width: int, chw: bool = False, normalize: bool = False, out=None, interpolation: str = "pil_bilinear"):
         """Learner-side observation of the last rendered batch, on the device: PIL-exact bilinear resize
         (learning/utils/wrappers.py ResizeWrapper) or, with interpolation="cv_cubic", the cv2 INTER_CUBIC resize of the

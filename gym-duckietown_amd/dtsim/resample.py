@@ -97,7 +97,7 @@ def cubic_coeffs(in_size: int, out_size: int):
     """(first int32 [out] = index of the first of the 4 taps (may be < 0: borders replicate), taps int32 [out, 4])."""
     A = np.float32(-0.75)
     one, two, three = np.float32(1), np.float32(2), np.float32(3)
-    scale = in_size / out_size                          # double, as cv::resize's inv_scale
+    scale = 1.0 / (out_size / in_size)                  # cv::resize: inv_scale_x = dsize.width / ssize.width (double), scale_x = 1. / inv_scale_x
     first = np.zeros(out_size, np.int32)
     taps = np.zeros((out_size, 4), np.int32)
     for d in range(out_size):

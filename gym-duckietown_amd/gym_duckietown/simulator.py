@@ -146,6 +146,14 @@ class Simulator(_EnvBase):
                 device=device, style=style, do_reset=False, **env_kwargs)
         except KeyError as e:
             raise InvalidMapException("Cannot load map data", map_name=map_name) from e
+        except Exception as e:
+            # every resident map's tables are staged into LDS by k_step (60 KB budget, dtsim_set_maps: DTSIM_E_LIMIT), and more
+            # than 4 maps leave the quad-record rasters for the generic ones (slower, same frames): say so where it happens
+            from dtsim import _ffi
+            if self.randomize_maps_on_reset and getattr(e, "code", None) == _ffi.E_LIMIT:
+                raise ValueError(f"randomize_maps_on_reset: the {len(maps_arg)} maps do not fit the library's resident-map budget ({e}); "
+                                 "pass map_name=[...] with the maps to draw from") from e
+            raise
         self._bind_map(0)
         self.cam_offset = np.array([0, 0, 0])
         self.reset()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 7
+#define DTSIM_ABI_VERSION 8
 
 /* error codes */
 #define DTSIM_OK 0
@@ -341,6 +341,16 @@ size_t dtsim_frames_bytes(const dtsim_t* h);
 /* Render into caller-owned device memory instead (e.g. a torch tensor that is the
  * send buffer of the RCCL all-gather). NULL restores the internal buffer. */
 int dtsim_bind_frames(dtsim_t* h, void* devptr);
+/* The north star's exchange (no counterpart in the reference, which runs one env per process):
+ * RCCL all-gather of this rank's uint8 frame batch (the buffer dtsim_frames_devptr / dtsim_bind_frames names) into
+ * `recv` = device memory for n_ranks * dtsim_frames_bytes(h) bytes, rank-major, enqueued on the handle's stream behind
+ * the last render (stream-ordered: dtsim_sync or the next call on the handle waits for it).  `nccl_comm` is an
+ * ncclComm_t the CALLER created (one process per GPU; ncclCommInitRank in C, or the communicator of its framework);
+ * librccl.so is resolved with dlopen at the first call -- the library has no link-time dependency on it, and the
+ * call fails with DTSIM_E_STATE where it is absent.  `send` = NULL gathers the frame batch; otherwise `send` /
+ * `send_bytes` name another device buffer of this rank to gather instead (e.g. the dtsim_observe output: 57.6 KB per
+ * env at 160 x 120 instead of 921.6 KB).  The host-side exchange of dtsim/sharding.py (torch.distributed) does not use it. */
+int dtsim_allgather_frames(dtsim_t* h, void* nccl_comm, void* recv, const void* send, size_t send_bytes);
 
 /* Learner-side observation of the rendered frame batch, on the device (what the reference's learners do
  * per env on the host): ResizeWrapper (learning/utils/wrappers.py:38-54, scipy imresize == PIL

@@ -370,3 +370,41 @@ def test_read_agent_matches_the_field_reads():
     with pytest.raises(Exception):
         sim.read_agent(5)
     sim.close()
+
+
+def test_allgather_frames_through_the_c_abi_one_rank():
+    """SURVEY 8(b)'s dtsim_allgather_frames: the RCCL all-gather of the frame batch enqueued by the library on its own stream,
+    with a communicator the caller made (here: a 1-rank ncclComm_t from librccl through ctypes -- the N > 1 path is the same
+    call with more ranks; unmeasured on hardware).  Checks the frame batch and an observe() buffer come back byte for byte."""
+    import ctypes as C
+    import torch
+    from dtsim import BatchedSimulator
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 not present")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    N = 6
+    sim = BatchedSimulator("small_loop", N, camera_width=160, camera_height=120, distortion=False, domain_rand=False, seed=3)
+    sim.step(np.full((N, 2), 0.4, np.float32))
+    sim.render()
+    recv = torch.zeros((1, N, 120, 160, 3), dtype=torch.uint8, device="cuda:0")
+    sim.allgather_frames(comm.value, recv)
+    sim.sync()
+    assert np.array_equal(recv[0].cpu().numpy(), sim.frames_host())
+    obs = sim.observe(60, 80)
+    recv2 = torch.zeros((1, N, 60, 80, 3), dtype=torch.uint8, device="cuda:0")
+    sim.allgather_frames(comm.value, recv2, send=obs)
+    sim.sync()
+    assert np.array_equal(recv2[0].cpu().numpy(), torch.as_tensor(obs, device="cuda:0").cpu().numpy())
+    sim.close()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
