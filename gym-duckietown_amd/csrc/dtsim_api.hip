@@ -93,6 +93,9 @@ struct dtsim {
   TileLds* d_tilerecs = nullptr;
   ScreenTri* d_stris = nullptr;
   ObjBox* d_objbox = nullptr;
+  int4* d_objlayer = nullptr;   // object layers (render.hip k_obj_setup): per (env, object) tile descriptor ...
+  uint4* d_layers = nullptr;    // ... and the per-env arenas of 32-byte source-pixel records
+  int layer_cap = 0;
   void* d_objmask = nullptr;    // block boxes [tiles*4][4] floats, then object masks [N][tiles*4] u64
   std::vector<uint32_t> h_pool;       // host copy of the RGBA8 pool (quad blocks are built from it at dtsim_set_maps)
   void* d_pixtab = nullptr;           // per-pixel tables of the shared camera (k_pix_setup)
@@ -293,7 +296,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objlayer, h->d_layers, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -642,6 +645,9 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
   if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
   if (h->d_objmask) { (void)hipFree(h->d_objmask); h->d_objmask = nullptr; }
+  if (h->d_objlayer) { (void)hipFree(h->d_objlayer); h->d_objlayer = nullptr; }
+  if (h->d_layers) { (void)hipFree(h->d_layers); h->d_layers = nullptr; }
+  h->layer_cap = 0;
   h->max_tris = 0;
   for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
   if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
@@ -649,6 +655,14 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
     HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
+    // object layers: 16384 source pixels per env (512 KB) up to 4096 envs, fewer beyond (at most 2 GB); off with DTSIM_OBJ_LAYERS=0
+    // and for frames wider than 1024 (the rasters keep their source-pixel centres as fp16: exact only below 1024)
+    const char* lay = getenv("DTSIM_OBJ_LAYERS");
+    if (DT_OBJ_LAYERS && !(lay && lay[0] == '0') && h->cfg.cam_width <= 1024 && h->cfg.cam_height <= 1024) {
+      h->layer_cap = h->N <= 4096 ? 16384 : h->N <= 8192 ? 8192 : h->N <= 16384 ? 4096 : 2048;   // 512 KB per env up to 4096 envs, at most 2 GB
+      HIPCHK(hipMalloc(&h->d_objlayer, sizeof(int4) * (size_t)h->N * DTSIM_MAX_OBJECTS));
+      HIPCHK(hipMalloc(&h->d_layers, (size_t)32 * h->layer_cap * h->N));
+    }
   }
   h->n_tilerecs = (int)trecs.size();
   h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
@@ -859,6 +873,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
   R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
   R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;
+  R.objlayer = h->d_objlayer; R.layers = h->d_layers; R.layer_cap = (h->d_layers && !segment) ? h->layer_cap : 0;
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
@@ -925,6 +940,8 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     int32_t dbg[8];
     HIPCHK(hipMemcpy(dbg, h->d_qcount + n_wg * 4, sizeof dbg, hipMemcpyDeviceToHost));
     unsigned long long pairs; memcpy(&pairs, dbg + 6, 8);
+    fprintf(stderr, "[dtsim] object layers: %d objects layered, %d live objects not layered, %d layer pixels rasterised; rasters composited %d box pixels from layers, "
+                    "sent %d on as ambiguous\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4]);
     fprintf(stderr, "[dtsim] resolve mesh pass: %d (batch,env) pairs, %d objects streamed, %d z-buffer calls (%d triangle-parallel), "
                     "%d triangles staged, %d pixels, %llu pixel x triangle tests\n", dbg[0], dbg[1], dbg[4], dbg[5], dbg[2], dbg[3], pairs);
     fprintf(stderr, "[dtsim] exact-path pixels: %lld of %zu (%.2f%%), max per wavefront region %lld\n", tot, npix * h->N,

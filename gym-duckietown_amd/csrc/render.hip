@@ -397,6 +397,279 @@ __global__ __launch_bounds__(RB) void k_blk_setup(RenderParams R, const float4* 
   }
 }
 
+// ---- per-map constants the raster needs (wave-uniform) -------------------------------
+struct MapU { float its, ts, gwf, ghf; int gw, gh, tile_off; };
+
+__device__ inline MapU map_u(const RenderMapDev& m) {
+  MapU u;
+  u.its = m.inv_tile_size; u.ts = m.tile_size; u.gw = m.grid_w; u.gh = m.grid_h;
+  u.gwf = (float)m.grid_w; u.ghf = (float)m.grid_h; u.tile_off = m.tile_off;
+  return u;
+}
+
+// 1-ulp hardware reciprocal / rsqrt / sqrt: a relative error of 1e-7 moves a ground hit by < 1e-3 texel
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline float fsqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+struct Ray { float xe, ye, yla, fwd; };
+
+__device__ inline Ray make_ray(float nx, float ny, float tx, float ty, float sth, float cth) {
+  Ray r;
+  r.xe = nx * tx; r.ye = ny * ty;
+  r.yla = r.ye * cth - sth;      // world-up component of the ray
+  r.fwd = r.ye * sth + cth;      // component along dir
+  return r;
+}
+
+// positional / directional light on a surface with eye-space normal (0, cth, sth) at the
+// eye-space point t*(xe, ye, -1): max(0, N.L)   (tiles; simulator.py:565-591)
+__device__ inline float plane_ndl(const float L[4], float sth, float cth, const Ray& r, float t) {
+  float ndl;
+  if (L[3] == 0.f) ndl = cth * L[1] + sth * L[2];
+  else {
+    const float lx = L[0] - t * r.xe, ly = L[1] - t * r.ye, lz = L[2] + t;
+    ndl = (cth * ly + sth * lz) * frsq(lx * lx + ly * ly + lz * lz);
+  }
+  return fmaxf(ndl, 0.f);
+}
+
+// bilinear GL_LINEAR/GL_REPEAT fetch from the padded texture, times the lit vertex colour I.
+__device__ inline void tile_color(const RenderParams& R, const TileLds& tr, float fx, float fz, const float I[3],
+                                  float out[3]) {
+  if (!(tr.flags & 2u)) {  // untextured tile: white vertex colour
+    out[0] = 255.f * I[0]; out[1] = 255.f * I[1]; out[2] = 255.f * I[2];
+    return;
+  }
+  const float x = fmaf(tr.mxz, fz, fmaf(tr.mxx, fx, tr.ox)), y = fmaf(tr.myz, fz, fmaf(tr.myx, fx, tr.oy));
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float ax = x - x0f, ay = y - y0f;
+  const int x0 = ((int)x0f) & (R.tex_w - 1), y0 = ((int)y0f) & (R.tex_h - 1);
+  const uint32_t* pt = R.texels + tr.tex_off + y0 * (R.tex_w + 1) + x0;
+  uint2 top2, bot2;               // two 8-byte loads: (x0,y0),(x0+1,y0) and the row above
+  __builtin_memcpy(&top2, pt, 8);
+  __builtin_memcpy(&bot2, pt + (R.tex_w + 1), 8);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c00 = (float)((top2.x >> (8 * k)) & 255u), c10 = (float)((top2.y >> (8 * k)) & 255u);
+    const float c01 = (float)((bot2.x >> (8 * k)) & 255u), c11 = (float)((bot2.y >> (8 * k)) & 255u);
+    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
+    out[k] = (top + ay * (bot - top)) * I[k];
+  }
+}
+
+// GL_LINEAR / GL_REPEAT fetch of a mesh texture at (u, v) in texture coordinates; out in 0..1.
+// Any power-of-two size; storage is the padded (h+1) x (w+1) layout of the texel pool.
+__device__ inline void mesh_texel(const RenderParams& R, int tex, float u, float v, float out[3]) {
+  const TexDev td = R.tex[tex];
+  const float x = u * (float)td.w - 0.5f, y = v * (float)td.h - 0.5f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float ax = x - x0f, ay = y - y0f;
+  const int x0 = ((int)x0f) & (td.w - 1), y0 = ((int)y0f) & (td.h - 1);
+  const uint32_t* pt = R.texels + td.off + y0 * (td.w + 1) + x0;
+  const uint32_t t00 = pt[0], t10 = pt[1], t01 = pt[td.w + 1], t11 = pt[td.w + 2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
+    const float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
+    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
+    out[k] = (top + ay * (bot - top)) * (1.f / 255.f);
+  }
+}
+
+__device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
+  const float a = fminf(fmaxf((wx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+  const float b = fminf(fmaxf((wz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
+  const float n0 = c.gndl[0] + a * (c.gndl[1] - c.gndl[0]);
+  const float n1 = c.gndl[2] + a * (c.gndl[3] - c.gndl[2]);
+  return n0 + b * (n1 - n0);
+}
+
+#if DT_OBJ_LAYERS
+// ---- object layers (round 4) ---------------------------------------------------------------------------------------
+// objects.py:123-148 / objmesh.py:360-375 (mesh draw), graphics.py:172-251 (4x MSAA), for the common case of a SMALL object
+// whose screen box meets no other object's: instead of sending every pixel of the box through the queue to k_resolve_obj
+// (a chain of dependent loads per (raster tile, env) unit: profiles/r04_resolve_obj.txt), the object is rasterised HERE,
+// triangle-major, into a tile of the rectilinear image: z-keys of the four samples of each source pixel in LDS (ds_max_u64:
+// LESS depth test with the draw-order tie break, the arithmetic of zbuffer_chunk), then per covered pixel the winners are
+// shaded at the pixel centre (the mesh branch of shade_msaa) and written as four {r, g, b, flag} samples -- colours in 1/256 of
+// an 8-bit step; flag 1 = covered and in front of the tile plane along its ray (so in front of every plane primitive), 2 =
+// covered but not certainly in front: the rasters send such pixels through the queue as before.  The quad-record rasters
+// composite the flag-1 samples over their own plane colour (render_v3.inc / render_v3dr.inc push_obj).
+__device__ inline void obj_layers(const RenderParams& R, const EnvCam& c, const RenderMapDev& m, const int e, const int tid,
+                                  const ScreenTri* __restrict__ out, const float (*s_oboxf)[4]) {
+  __shared__ unsigned long long s_keys[DT_LAYER_MAX_PIX * 4];   // z-keys of the pass's sub-tile: [pixel][sample]
+  __shared__ float s_tri[256][12];                     // the chunk's triangles: sx[3], sy[3], iw[3], inv_area, index, -
+  __shared__ int s_tbox[256];                          // clipped pixel box of each: ix0 | iy0 << 12 | width << 24 (width <= 255 per pass: wider boxes are split by the pass)
+  __shared__ int s_pref[257];                          // exclusive scan of the boxes' ROW counts
+  __shared__ int s_lay[DTSIM_MAX_OBJECTS][5];          // first pixel in the env's arena (-1: no layer), x0, y0, w, h
+  if (tid < DTSIM_MAX_OBJECTS) {
+    int off = -1, x0 = 0, y0 = 0, w = 0, hh = 0;
+    if (tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1]) {
+      // every source pixel whose centre the rasters' box test (box +- the fp16 margin) can accept: box +- 1 px, clipped
+      x0 = max(0, (int)floorf(s_oboxf[tid][0] - 1.f)); y0 = max(0, (int)floorf(s_oboxf[tid][2] - 1.f));
+      const int x1 = min(R.W - 1, (int)ceilf(s_oboxf[tid][1] + 1.f)), y1 = min(R.H - 1, (int)ceilf(s_oboxf[tid][3] + 1.f));
+      w = x1 - x0 + 1; hh = y1 - y0 + 1;
+      off = (w > 0 && hh > 0 && w <= 255 && w * hh <= DT_LAYER_OBJ_PIX) ? 0 : -1;
+    }
+    s_lay[tid][0] = off; s_lay[tid][1] = x0; s_lay[tid][2] = y0; s_lay[tid][3] = w; s_lay[tid][4] = hh;
+  }
+  __syncthreads();
+  if (tid == 0) {                                      // arena offsets, in object order
+    int acc = 0;
+    for (int o = 0; o < m.n_obj; ++o) {
+      if (s_lay[o][0] < 0) continue;
+      const int area = s_lay[o][3] * s_lay[o][4];
+      if (acc + area <= R.layer_cap) { s_lay[o][0] = acc; acc += area; } else s_lay[o][0] = -1;
+    }
+  }
+  __syncthreads();
+  if (tid < DTSIM_MAX_OBJECTS) R.objlayer[(size_t)e * DTSIM_MAX_OBJECTS + tid] = make_int4(s_lay[tid][0], s_lay[tid][1], s_lay[tid][2], s_lay[tid][3]);
+  if (R.dbg && tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1]) {   // DTSIM_DEBUG_QUEUE: layered / live-but-not-layered objects, layer pixels
+    atomicAdd(R.dbg + (s_lay[tid][0] >= 0 ? 0 : 1), 1);
+    if (s_lay[tid][0] >= 0) atomicAdd(R.dbg + 2, s_lay[tid][3] * s_lay[tid][4]);
+  }
+  const uint2* rng = R.objrange + (size_t)c.map_id * DTSIM_MAX_OBJECTS;
+  const float4* boxes = R.tribox + (size_t)e * R.max_tris;
+  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int o = 0; o < m.n_obj; ++o) {                  // workgroup-uniform
+    const int off = s_lay[o][0];
+    if (off < 0) continue;
+    const int x0 = s_lay[o][1], oy0 = s_lay[o][2], w = s_lay[o][3], ohh = s_lay[o][4];
+    const uint2 fc = rng[o];
+    const int rows_pp = max(1, DT_LAYER_MAX_PIX / w);  // rows of the object's tile per pass (the keys of a pass fit the LDS buffer)
+    for (int r0 = 0; r0 < ohh; r0 += rows_pp) {        // ---- one pass: sub-tile rows [y0, y0 + hh)
+      const int y0 = oy0 + r0, hh = min(rows_pp, ohh - r0), npx = w * hh;
+      for (int i = tid; i < npx * 4; i += 256) s_keys[i] = 0ull;
+      for (int t0 = (int)fc.x; t0 < (int)(fc.x + fc.y); t0 += 256) {   // the object's triangles, 256 at a time
+        __syncthreads();                               // keys zeroed / the previous chunk's pairs done
+        // (1) this lane's triangle: clipped pixel box -> LDS, with its set-up; rows -> scan
+        int rows = 0;
+        {
+          const int t = t0 + tid;
+          int ix0 = 0, iy0 = 0, bw = 0;
+          if (t < (int)(fc.x + fc.y)) {
+            const float4 bb = boxes[t];                // bx0, bx1, by0, by1 (inverted for culled triangles)
+            if (bb.x <= bb.y) {
+              ix0 = max(x0, (int)ceilf(bb.x - 0.5f)); iy0 = max(y0, (int)ceilf(bb.z - 0.5f));
+              const int ix1 = min(x0 + w - 1, (int)floorf(bb.y - 0.5f)), iy1 = min(y0 + hh - 1, (int)floorf(bb.w - 0.5f));
+              bw = max(0, ix1 - ix0 + 1); rows = bw > 0 ? max(0, iy1 - iy0 + 1) : 0;
+              if (rows > 0) {
+                const ScreenTri& st = out[t];
+                float* d = s_tri[tid];
+                d[0] = st.sx[0]; d[1] = st.sx[1]; d[2] = st.sx[2]; d[3] = st.sy[0]; d[4] = st.sy[1]; d[5] = st.sy[2];
+                d[6] = st.iw[0]; d[7] = st.iw[1]; d[8] = st.iw[2]; d[9] = st.inv_area; d[10] = __int_as_float(st.index);
+              }
+            }
+          }
+          s_tbox[tid] = ix0 | (iy0 << 12) | (bw << 24);
+        }
+        // exclusive scan of `rows` over the 256 lanes (wave scan + the four wave totals)
+        int inc = rows;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+        __shared__ int s_wtot[4];
+        if (lane == 63) s_wtot[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wbase += q < wave ? s_wtot[q] : 0;
+        s_pref[tid] = wbase + inc - rows;
+        if (tid == 255) s_pref[256] = wbase + inc;
+        __syncthreads();
+        const int n_rows = s_pref[256];
+        // (2) (triangle, row) pairs spread over the 256 lanes; a lane walks its row's columns
+        for (int pr = tid; pr < n_rows; pr += 256) {
+          int lo_ = 0, hi_ = 255;                      // last triangle with pref <= pr
+#pragma unroll
+          for (int it = 0; it < 8; ++it) { const int mid = (lo_ + hi_ + 1) >> 1; if (s_pref[mid] <= pr) lo_ = mid; else hi_ = mid - 1; }
+          const int tl = lo_;
+          const int tb = s_tbox[tl];
+          const int ix0 = tb & 4095, iy = ((tb >> 12) & 4095) + (pr - s_pref[tl]), bw = (int)((uint32_t)tb >> 24);
+          const float* d = s_tri[tl];
+          const float ia = d[9];
+          const float d0 = d[6] - d[8], d1 = d[7] - d[8];
+          const uint32_t rix = 0x7fffffffu - (uint32_t)__float_as_int(d[10]);
+          const float qy = (float)iy + 0.5f;
+          const float e0y = d[3] - qy, e1y = d[4] - qy, e2y = d[5] - qy;
+          unsigned long long* kp = s_keys + ((iy - y0) * w + (ix0 - x0)) * 4;
+          for (int ix = ix0; ix < ix0 + bw; ++ix, kp += 4) {   // the arithmetic of zbuffer_chunk's drain, term for term
+            const float qx = (float)ix + 0.5f;
+            const float e0x = d[0] - qx, e1x = d[1] - qx, e2x = d[2] - qx;
+            const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
+            const float g0x = (e1y - e2y) * ia, g0y = (e2x - e1x) * ia, g1x = (e2y - e0y) * ia, g1y = (e0x - e2x) * ia;
+            const float wc = fmaf(b1c, d1, fmaf(b0c, d0, d[8]));
+            const float gwx = fmaf(g1x, d1, g0x * d0), gwy = fmaf(g1y, d1, g0y * d0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float b0 = fmaf(g0y, oy[q], fmaf(g0x, ox[q], b0c));
+              const float b1 = fmaf(g1y, oy[q], fmaf(g1x, ox[q], b1c));
+              const float b2 = 1.f - b0 - b1;
+              const float wq = fmaf(gwy, oy[q], fmaf(gwx, ox[q], wc));
+              const bool in = fminf(fminf(b0, b1), b2) >= 0.f && wq <= 1.f / NEAR_Z && wq >= 1.f / FAR_Z;
+              if (in) atomicMax(kp + q, ((unsigned long long)__float_as_uint(wq) << 32) | rix);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // (3) resolve the pass's pixels: winners shaded at the pixel centre -> four {r, g, b, flag} samples
+      uint4* arena = R.layers + ((size_t)e * R.layer_cap + off + (size_t)r0 * w) * 2;
+      for (int p = tid; p < npx; p += 256) {
+        unsigned long long k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = s_keys[p * 4 + q];
+        uint32_t rec[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if ((k[0] | k[1] | k[2] | k[3]) != 0ull) {
+          const int py = p / w;
+          const float pcx = (float)(x0 + p - py * w) + 0.5f, pcy = (float)(y0 + py) + 0.5f;
+          const float nx = pcx * sxn - 1.f, ny = 1.f - pcy * syn;
+          int prev_t = -1;
+          uint32_t prev_rg = 0u, prev_b = 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (k[q] == 0ull) continue;
+            const float wq = __uint_as_float((uint32_t)(k[q] >> 32));
+            const int ti = (int)(0x7fffffffu - (uint32_t)k[q]);
+            // in front of the tile plane along the sample's ray?  (then in front of the ground quad and the sky as well)
+            const Ray rs = make_ray(nx + ox[q] * sxn, ny - oy[q] * syn, c.tx, c.ty, c.sth, c.cth);
+            const bool front = !(rs.yla < 0.f) || 1.f / wq < c.Cy * frcp(-rs.yla);
+            if (ti != prev_t) {                        // shade the winner at the PIXEL CENTRE (shade_msaa's mesh branch)
+              const ScreenTri& st = out[ti];
+              const float b0 = ((st.sx[1] - pcx) * (st.sy[2] - pcy) - (st.sx[2] - pcx) * (st.sy[1] - pcy)) * st.inv_area;
+              const float b1 = ((st.sx[2] - pcx) * (st.sy[0] - pcy) - (st.sx[0] - pcx) * (st.sy[2] - pcy)) * st.inv_area;
+              const float b2 = 1.f - b0 - b1;
+              const float inv = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
+              float tx[3] = {1.f, 1.f, 1.f};
+              if (st.tex >= 0) {
+                const float u = (b0 * st.uw[0] + b1 * st.uw[1] + b2 * st.uw[2]) * inv;
+                const float v = (b0 * st.vw[0] + b1 * st.vw[1] + b2 * st.vw[2]) * inv;
+                mesh_texel(R, st.tex, u == u ? u : 0.f, v == v ? v : 0.f, tx);
+              }
+              uint32_t c16[3];
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                const float v = (b0 * st.cw[0][ch] + b1 * st.cw[1][ch] + b2 * st.cw[2][ch]) * inv;
+                c16[ch] = (uint32_t)(fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f) * tx[ch] * 256.f + 0.5f);
+              }
+              prev_t = ti; prev_rg = c16[0] | (c16[1] << 16); prev_b = c16[2];
+            }
+            rec[2 * q] = prev_rg; rec[2 * q + 1] = prev_b | ((front ? 1u : 2u) << 16);
+          }
+        }
+        arena[(size_t)p * 2] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        arena[(size_t)p * 2 + 1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#endif  // DT_OBJ_LAYERS
+
 __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
@@ -508,6 +781,9 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     s_oboxf[tid][0] = ob.bx0; s_oboxf[tid][1] = ob.bx1; s_oboxf[tid][2] = ob.by0; s_oboxf[tid][3] = ob.by1;   // empty when not live
   }
   __syncthreads();
+#if DT_OBJ_LAYERS
+  if (R.layer_cap > 0) obj_layers(R, c, m, e, tid, out, s_oboxf);
+#endif
   if (R.objmask) {
     // which objects' screen boxes meet each raster wavefront block (source-pixel boxes of the blocks: k_blk_setup): the
     // raster reads one 8-byte mask per (env, block) instead of walking the env's object boxes
@@ -523,93 +799,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   }
 }
 
-// ---- per-map constants the raster needs (wave-uniform) -------------------------------
-struct MapU { float its, ts, gwf, ghf; int gw, gh, tile_off; };
-
-__device__ inline MapU map_u(const RenderMapDev& m) {
-  MapU u;
-  u.its = m.inv_tile_size; u.ts = m.tile_size; u.gw = m.grid_w; u.gh = m.grid_h;
-  u.gwf = (float)m.grid_w; u.ghf = (float)m.grid_h; u.tile_off = m.tile_off;
-  return u;
-}
-
-// 1-ulp hardware reciprocal / rsqrt / sqrt: a relative error of 1e-7 moves a ground hit by < 1e-3 texel
-__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ inline float fsqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-struct Ray { float xe, ye, yla, fwd; };
-
-__device__ inline Ray make_ray(float nx, float ny, float tx, float ty, float sth, float cth) {
-  Ray r;
-  r.xe = nx * tx; r.ye = ny * ty;
-  r.yla = r.ye * cth - sth;      // world-up component of the ray
-  r.fwd = r.ye * sth + cth;      // component along dir
-  return r;
-}
-
-// positional / directional light on a surface with eye-space normal (0, cth, sth) at the
-// eye-space point t*(xe, ye, -1): max(0, N.L)   (tiles; simulator.py:565-591)
-__device__ inline float plane_ndl(const float L[4], float sth, float cth, const Ray& r, float t) {
-  float ndl;
-  if (L[3] == 0.f) ndl = cth * L[1] + sth * L[2];
-  else {
-    const float lx = L[0] - t * r.xe, ly = L[1] - t * r.ye, lz = L[2] + t;
-    ndl = (cth * ly + sth * lz) * frsq(lx * lx + ly * ly + lz * lz);
-  }
-  return fmaxf(ndl, 0.f);
-}
-
-// bilinear GL_LINEAR/GL_REPEAT fetch from the padded texture, times the lit vertex colour I.
-__device__ inline void tile_color(const RenderParams& R, const TileLds& tr, float fx, float fz, const float I[3],
-                                  float out[3]) {
-  if (!(tr.flags & 2u)) {  // untextured tile: white vertex colour
-    out[0] = 255.f * I[0]; out[1] = 255.f * I[1]; out[2] = 255.f * I[2];
-    return;
-  }
-  const float x = fmaf(tr.mxz, fz, fmaf(tr.mxx, fx, tr.ox)), y = fmaf(tr.myz, fz, fmaf(tr.myx, fx, tr.oy));
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float ax = x - x0f, ay = y - y0f;
-  const int x0 = ((int)x0f) & (R.tex_w - 1), y0 = ((int)y0f) & (R.tex_h - 1);
-  const uint32_t* pt = R.texels + tr.tex_off + y0 * (R.tex_w + 1) + x0;
-  uint2 top2, bot2;               // two 8-byte loads: (x0,y0),(x0+1,y0) and the row above
-  __builtin_memcpy(&top2, pt, 8);
-  __builtin_memcpy(&bot2, pt + (R.tex_w + 1), 8);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float c00 = (float)((top2.x >> (8 * k)) & 255u), c10 = (float)((top2.y >> (8 * k)) & 255u);
-    const float c01 = (float)((bot2.x >> (8 * k)) & 255u), c11 = (float)((bot2.y >> (8 * k)) & 255u);
-    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
-    out[k] = (top + ay * (bot - top)) * I[k];
-  }
-}
-
-// GL_LINEAR / GL_REPEAT fetch of a mesh texture at (u, v) in texture coordinates; out in 0..1.
-// Any power-of-two size; storage is the padded (h+1) x (w+1) layout of the texel pool.
-__device__ inline void mesh_texel(const RenderParams& R, int tex, float u, float v, float out[3]) {
-  const TexDev td = R.tex[tex];
-  const float x = u * (float)td.w - 0.5f, y = v * (float)td.h - 0.5f;
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float ax = x - x0f, ay = y - y0f;
-  const int x0 = ((int)x0f) & (td.w - 1), y0 = ((int)y0f) & (td.h - 1);
-  const uint32_t* pt = R.texels + td.off + y0 * (td.w + 1) + x0;
-  const uint32_t t00 = pt[0], t10 = pt[1], t01 = pt[td.w + 1], t11 = pt[td.w + 2];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
-    const float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
-    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
-    out[k] = (top + ay * (bot - top)) * (1.f / 255.f);
-  }
-}
-
-__device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
-  const float a = fminf(fmaxf((wx + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-  const float b = fminf(fmaxf((wz + GROUND_HALF) * (0.5f / GROUND_HALF), 0.f), 1.f);
-  const float n0 = c.gndl[0] + a * (c.gndl[1] - c.gndl[0]);
-  const float n1 = c.gndl[2] + a * (c.gndl[3] - c.gndl[2]);
-  return n0 + b * (n1 - n0);
-}
 
 // max(|a|, |b|) in one instruction (source modifiers; no NaN canonicalisation needed: inputs are finite)
 __device__ inline float absmax(float a, float b) { float r; asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -1567,6 +1756,29 @@ __device__ inline void quad_filter3(const uint4& q, float ax, float az, float I,
                          (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
 #pragma unroll
   for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
+}
+
+// Object layers (k_obj_setup / obj_layers): composite the four samples of one source pixel (two 16-byte halves a, b) over the
+// pixel's own 8-bit plane colour rgb = 0x00BBGGRR -- covered samples (flag 1) replace the plane colour, (sum + 2) / 4 with
+// the layer colours in 1/256 of a step; amb: some sample is covered but not certainly in front of the planes (flag 2): the
+// pixel takes the queue instead.  An uncovered pixel keeps its colour bit for bit.
+__device__ inline uint32_t layer_composite(const uint4 a, const uint4 b, const uint32_t rgb, bool& amb) {
+  const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
+  uint32_t sr = 0u, sg = 0u, sb = 0u, ncov = 0u;
+  amb = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t f = hi[q] >> 16;
+    const bool cov = f == 1u;
+    amb |= f == 2u;
+    sr += cov ? (lo[q] & 0xFFFFu) : 0u; sg += cov ? (lo[q] >> 16) : 0u; sb += cov ? (hi[q] & 0xFFFFu) : 0u;
+    ncov += cov ? 1u : 0u;
+  }
+  if (ncov == 0u) return rgb;
+  const uint32_t np = 4u - ncov;
+  const uint32_t r = (sr + np * ((rgb & 255u) << 8) + 512u) >> 10, g = (sg + np * (((rgb >> 8) & 255u) << 8) + 512u) >> 10,
+                 bl = (sb + np * (((rgb >> 16) & 255u) << 8) + 512u) >> 10;
+  return min(r, 255u) | (min(g, 255u) << 8) | (min(bl, 255u) << 16);
 }
 
 #define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
@@ -2653,7 +2865,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 
 }  // namespace
 
-int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, int tables) {
+int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in, int tables) {
+  RenderParams R = R_in;
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
@@ -2667,6 +2880,11 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
                     !(R.qlog2 == 8 && R.qmax_tiles >= 256);
   const bool obj = R.max_tris > 0;
+  // object layers are read by k_raster_v3<OBJ> / k_raster_v3dr<OBJ> only: off for every other raster (they queue every box pixel)
+  {
+    const bool v3_obj = quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1;
+    if (!DT_OBJ_LAYERS || !(obj && (v3_obj || v3dr)) || !R.objlayer || !R.layers || (R.W & 3) != 0) R.layer_cap = 0;
+  }
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
