@@ -1351,10 +1351,25 @@ static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITE
 
 // Work items of k_resolve_obj (its own list: R.work[2] = count, [3] = cursor; second part of R.items): one per RES_ENVS
 // env positions of a raster workgroup that queued object-box pixels.
-__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg) {
-  const int ni = ENVS_PER_BLOCK / RES_ENVS;
-  const int pos = atomicAdd(R.work + 2, ni);
-  for (int i = 0; i < ni; ++i) R.items2[pos + i] = rwg * ITEMS_PER_WG + (uint32_t)i;
+// groups: bit g = env group g of the chunk (RES_ENVS positions) has object-box entries in some region of the workgroup; the
+// quad-record rasters pass what they queued (round 4: 60 % of the items used to be empty), the others every group.
+__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg, uint32_t groups = ~0u) {
+  const int ng = ENVS_PER_BLOCK / RES_ENVS;
+  groups &= (1u << ng) - 1u;
+  const int ni = __popc(groups);
+  if (ni == 0) return;
+  int pos = atomicAdd(R.work + 2, ni);
+  for (int i = 0; i < ng; ++i) if ((groups >> i) & 1u) R.items2[pos++] = rwg * ITEMS_PER_WG + (uint32_t)i;
+}
+// which env groups of the chunk have entries in THIS wavefront's region: qend_v = the region's fill after each env (lane = position)
+__device__ inline uint32_t obj_groups_of(int qend_v, int lane) {
+  const int up = __shfl_up(qend_v, 1);
+  const bool has = lane < ENVS_PER_BLOCK && qend_v != (lane == 0 ? 0 : up);
+  const unsigned long long m = __ballot(has);
+  uint32_t g = 0u;
+#pragma unroll
+  for (int i = 0; i < ENVS_PER_BLOCK / RES_ENVS; ++i) g |= ((m >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
+  return g;
 }
 
 template <bool DR, bool OBJ>
@@ -2691,18 +2706,32 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
     if (lane == 0) g = atomicAdd(R.work + 3, 1);
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= n_grabs) break;
+    // Round 4: the item loop is software-pipelined -- the id of the item after next and the queue fills (qend) of the next
+    // item are loaded while the current one is processed: the kernel is a chain of dependent round trips per (tile, env)
+    // unit (profiles/r04_variants_ab.txt block G), these were two of them.
+    static_assert(RB / 64 == 4, "four regions per raster workgroup");
+    auto load_qend = [&](uint32_t item_, int endv_[4]) {
+      const int rwg_ = (int)(item_ / ITEMS_PER_WG);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) endv_[r] = lane < ENVS_PER_BLOCK ? (int)R.qend[((size_t)rwg_ * 4 + r) * ENVS_PER_BLOCK + lane] : 0;
+    };
+    uint32_t item_cur = R.items2[g], item_nxt = g + n_grabs < n_items ? R.items2[g + n_grabs] : 0u;
+    int endv_nxt[4];
+    load_qend(item_cur, endv_nxt);
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
-      const uint32_t item = R.items2[it];
+      const uint32_t item = item_cur;
+      int endv[4], startv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) endv[r] = endv_nxt[r];
+      item_cur = item_nxt;
+      if (it + n_grabs < n_items) load_qend(item_cur, endv_nxt);
+      item_nxt = it + 2 * n_grabs < n_items ? R.items2[it + 2 * n_grabs] : 0u;
       const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG) * RES_ENVS;
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
       const int ne = min(ENVS_PER_BLOCK, R.N - e0);
       if (p0 >= ne) continue;
       // per-region entry ranges of the chunk's envs: lane l <-> position e0 + l
-      static_assert(RB / 64 == 4, "four regions per raster workgroup");
-      int endv[4], startv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) endv[r] = lane < ENVS_PER_BLOCK ? (int)R.qend[((size_t)rwg * 4 + r) * ENVS_PER_BLOCK + lane] : 0;
       bool any = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
