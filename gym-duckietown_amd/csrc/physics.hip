@@ -230,6 +230,10 @@ __device__ inline void bezier_point(const double* cp, double t, double& x, doubl
 }
 
 // simulator.py:1337-1409 closest_curve_point + get_lane_pos2
+// (Not lane-cooperative, by measurement -- round 4, profiles/r04_c2_lane_pose_ab.txt: the curve argmax split over the L lanes of
+// an env (2 / 6 / 12 dot products, a (value, index) butterfly with np.argmax's first-maximum tie break) and the bisection's two
+// initial end points on two lanes leave the step where it was or 1 - 2 % slower on the 12-curve junction map: the bisection has
+// ONE new curve point per level, the chain is serial.)
 __device__ inline Lane lane_pos(const MapView& m, double px, double pz, double angle) {
   Lane L;
   L.in_lane = false; L.curve_idx = -1;

@@ -8,7 +8,12 @@ import torch
 from dtsim import BatchedSimulator, _ffi
 N = int(os.environ.get("N", "4096")); F = int(os.environ.get("F", "32")); K = int(os.environ.get("K", "20"))
 mp = os.environ.get("MAP", "small_loop")
-sim = BatchedSimulator(mp, N, render=False, domain_rand=False, seed=1000, action_mode="vel_steer", auto_reset=True, profile=True,
+kw = {}
+if mp == "junction_map":                      # every drivable tile kind x orientation (2 / 6 / 12 curves per tile): oracle/fixtures.py
+    sys.path.insert(0, ROOT)
+    from oracle.fixtures import junction_map
+    kw["map_data"] = junction_map()
+sim = BatchedSimulator(mp, N, render=False, **kw, domain_rand=False, seed=1000, action_mode="vel_steer", auto_reset=True, profile=True,
                        max_steps=100000)
 sim.make_spawn_pool(min(N, 512))
 acts = torch.rand((F, N, 2), device="cuda:0", dtype=torch.float32) * 1.2 - 0.2
