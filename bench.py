@@ -330,14 +330,14 @@ def main():
         # wrap the whole command): they are read from the committed summary of the same command's counter runs and
         # labelled with where they came from; null when that file is for another workload.
         traffic = traffic_source = valu = traffic_split = None
-        traffic_why = "profiles/raster_pmc_latest.json not found"
-        pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json")
+        traffic_why = "no committed counter summary for this config under profiles/ (tools/prof_bench_short.sh + tools/make_traffic_json.py)"
+        pj = os.path.join(ROOT, "profiles", "raster_pmc_latest.json" if args.config == "c3" else f"raster_pmc_{args.config}.json")
         if os.path.exists(pj):
             try:
                 d = json.load(open(pj))
-                traffic_why = (f"the committed counter summary is for config c3 at {d.get('envs')} envs per GPU; this run is "
+                traffic_why = (f"the committed counter summary is for config {d.get('config', 'c3')} at {d.get('envs')} envs per GPU; this run is "
                                f"{args.config} at {N}: PMC passes wrap the whole command (rocprofv3), they cannot be taken in-process")
-                if d.get("envs") == N and args.config == "c3":
+                if d.get("envs") == N and d.get("config", "c3") == args.config:
                     traffic_why = None
                     traffic = d.get("hbm_bytes_per_launch")
                     traffic_source = d.get("source")
@@ -348,9 +348,10 @@ def main():
                         # (profiles/r03_fetch_calibration.txt, profiles/r03_variants_ab.txt blocks H and I)
                         traffic_split = {"write_bytes": d["write_KB"] * 1024.0, "l2_read_fill_bytes": 2.0 * d["fetch_KB_raw"] * 1024.0,
                                          "write_over_algorithmic": d["write_KB"] * 1024.0 / (N * FRAME_BYTES),
-                                         "note": "traffic = write_bytes + l2_read_fill_bytes; the read fills are an UPPER bound of HBM reads "
-                                                 "(record gathers of a 7 MB pool resident in the 256 MB Infinity Cache; the counter cannot "
-                                                 "tell a fill from the Infinity Cache from one from HBM)"}
+                                         "note": "traffic = write_bytes + l2_read_fill_bytes over every kernel of the render pass; the read fills are an UPPER "
+                                                 "bound of HBM reads (record gathers of a 7 MB pool resident in the 256 MB Infinity Cache; the counter "
+                                                 "cannot tell a fill from the Infinity Cache from one from HBM)"
+                                                 + ("" if args.config == "c3" else "; with mesh objects also the per-env screen-space triangles and the queue")}
                     if d.get("valu_per_pixel") is not None:
                         clk = d.get("clock_ghz", 2.1) * 1e9
                         # issue peak as MEASURED on this part (profiles/r02_ubench_valu_rates.txt: the opcodes of this kernel

@@ -18,8 +18,10 @@ def counters(db):
 
 out_dir, envs = sys.argv[1], int(sys.argv[2])
 source = sys.argv[3] if len(sys.argv) > 3 else out_dir          # label carried into bench.py's roofline.traffic_source
-valu_per_pixel = float(sys.argv[4]) if len(sys.argv) > 4 else None
-clock_ghz = float(sys.argv[5]) if len(sys.argv) > 5 else None
+valu_per_pixel = float(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+clock_ghz = float(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+config = sys.argv[6] if len(sys.argv) > 6 else "c3"           # c3 -> raster_pmc_latest.json, c4 / c5 -> raster_pmc_<config>.json
+out_name = "raster_pmc_latest.json" if config == "c3" else f"raster_pmc_{config}.json"
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 detail = {}
 for db in glob.glob(os.path.join(out_dir, "*", "*.db")):
@@ -34,8 +36,8 @@ for db in glob.glob(os.path.join(out_dir, "*", "*.db")):
                 detail.setdefault(short, {})[c + "_KB_per_launch"] = v
                 tot[c] += v
 hbm = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
-json.dump({"envs": envs, "hbm_bytes_per_launch": hbm, "fetch_KB_raw": tot["FETCH_SIZE"], "write_KB": tot["WRITE_SIZE"],
+json.dump({"envs": envs, "config": config, "hbm_bytes_per_launch": hbm, "fetch_KB_raw": tot["FETCH_SIZE"], "write_KB": tot["WRITE_SIZE"],
            "per_kernel": detail, "source": source, "valu_per_pixel": valu_per_pixel, "clock_ghz": clock_ghz,
            "note": "render pass = every kernel dtsim_render launches; FETCH_SIZE doubled per MI355X_MICROARCH.md"},
-          open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "raster_pmc_latest.json"), "w"), indent=1)
+          open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", out_name), "w"), indent=1)
 print("hbm bytes per render pass:", hbm, detail)

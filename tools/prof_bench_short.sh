@@ -1,12 +1,14 @@
 #!/bin/bash
 # the passes bench.py's roofline object leans on: kernel trace + stats, then FETCH_SIZE, WRITE_SIZE and the SQ instruction
 # counters each in their own run (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+#   bash tools/prof_bench_short.sh TAG [c3|c4|c5]   ->  gpurun_out/prof_bench_TAG/summary.txt (+ make_traffic_json.py for roofline.traffic)
 TAG=${1:-r02}
+CFG=${2:-c3}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_bench_$TAG
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 20 --warmup 3 --cpu-steps 0"
+ARGS="--config $CFG --steps 20 --warmup 3 --cpu-steps 0 --windows 2 --no-gather"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/write -o write -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/write.log 2>&1
