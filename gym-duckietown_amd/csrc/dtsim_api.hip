@@ -93,6 +93,7 @@ struct dtsim {
   TileLds* d_tilerecs = nullptr;
   ScreenTri* d_stris = nullptr;
   ObjBox* d_objbox = nullptr;
+  uint4* d_units = nullptr;     // work units of k_resolve_clu: clusters of objects with overlapping screen boxes, per env (k_obj_setup)
   int4* d_objlayer = nullptr;   // object layers (render.hip k_obj_setup): per (env, object) tile descriptor ...
   uint4* d_layers = nullptr;    // ... and the per-env arenas of 32-byte source-pixel records
   int layer_cap = 0;
@@ -296,7 +297,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objlayer, h->d_layers, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_units, h->d_objlayer, h->d_layers, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -645,6 +646,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
   if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
   if (h->d_objmask) { (void)hipFree(h->d_objmask); h->d_objmask = nullptr; }
+  if (h->d_units) { (void)hipFree(h->d_units); h->d_units = nullptr; }
   if (h->d_objlayer) { (void)hipFree(h->d_objlayer); h->d_objlayer = nullptr; }
   if (h->d_layers) { (void)hipFree(h->d_layers); h->d_layers = nullptr; }
   h->layer_cap = 0;
@@ -655,6 +657,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
     HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
+    HIPCHK(hipMalloc(&h->d_units, sizeof(uint4) * (size_t)h->N * 256));   // (env, object cluster, tile-row band) units: 256 per env on average
     // object layers: 16384 source pixels per env (512 KB) up to 4096 envs, fewer beyond (at most 2 GB); off with DTSIM_OBJ_LAYERS=0
     // and for frames wider than 1024 (the rasters keep their source-pixel centres as fp16: exact only below 1024)
     const char* lay = getenv("DTSIM_OBJ_LAYERS");
@@ -873,6 +876,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
   R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
   R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;
+  R.units = h->d_units; R.units_cap = h->d_units ? h->N * 256 : 0; R.pad4_ = 0;
   R.objlayer = h->d_objlayer; R.layers = h->d_layers; R.layer_cap = (h->d_layers && !segment) ? h->layer_cap : 0;
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;

@@ -215,7 +215,7 @@ struct RenderParams {
   int32_t* qcount;              // [workgroups][4]
   uint16_t* qend;               // [workgroups][4][DT_ENVS_PER_BLOCK] queue fill of each region after each env of the chunk (mesh-object renders)
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
-  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj; zeroed per render
+  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj, [4], [5] units of k_resolve_clu; zeroed per render
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
   uint32_t* items2;             // [workgroups * DT_ENVS_PER_BLOCK] work items of k_resolve_obj: raster workgroup * DT_ITEMS_PER_WG + env group
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
@@ -232,10 +232,13 @@ struct RenderParams {
   void* envd;                   // [N] EnvD (render_v3dr.inc, 192 B): k_raster_v3dr's per-env constants (domain randomisation)
   int32_t q3_rows;              // k_raster_v3 (render_v3.inc): rows of its LDS tile table (largest padded grid height); 0: k_raster_q is used
   int32_t layer_cap;            // object layers (round 4): source pixels per env in `layers`; 0 = off
+  int32_t units_cap, pad4_;     // capacity of `units`
   // Object layers: k_obj_setup rasterises every mesh object whose screen box is small and meets no other object's into a
   // per-(env, object) tile of the RECTILINEAR image -- per pixel four MSAA samples {r, g, b (1/256 of an 8-bit step), flag} --
   // and the quad-record rasters composite those samples over their own plane colour, instead of queueing the pixel for
   // k_resolve_obj.  objlayer[env][object] = {first pixel of its tile in the env's arena or -1, x0, y0, tile width}.
+  uint4* units;                 // [N * DTSIM_MAX_OBJECTS] work units of k_resolve_clu (round 4): {env, member objects (64-bit mask: a cluster of
+                                // objects whose screen boxes overlap), 0}, appended by k_obj_setup; count = work[4], cursor = work[5]
   int4* objlayer;               // [N][DTSIM_MAX_OBJECTS]
   uint4* layers;                // [N][layer_cap][2]: 32 bytes per source pixel
 };

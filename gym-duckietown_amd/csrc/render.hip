@@ -51,6 +51,11 @@
 #ifndef DT_ENV_SORT
 #define DT_ENV_SORT 0              // 1: envs in k_env_sort order -- half the L2 fills, 4-5 % slower (dt_launch_render)
 #endif
+#ifndef DT_RESOLVE_CLU
+#define DT_RESOLVE_CLU 0           // round 4: object-box pixels by k_resolve_clu (one WORKGROUP per (env, object cluster, band of raster tile rows): blocks ->
+                                   // entry ranges, triangles staged once, per-batch cull) instead of k_resolve_obj.  Built, parity-green (48 GPU tests), and no
+                                   // faster: 0.83 ms against 0.85 on C5, 1.06 against 0.79 on C4 (profiles/r04_variants_ab.txt block G): off
+#endif
 #ifndef DT_V3_DR
 #define DT_V3_DR 1                 // domain randomisation on the quad records (render_v3dr.inc); 0: the generic k_raster<DR=1>
 #endif
@@ -784,6 +789,32 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
 #if DT_OBJ_LAYERS
   if (R.layer_cap > 0) obj_layers(R, c, m, e, tid, out, s_oboxf);
 #endif
+  __shared__ int s_lab[DTSIM_MAX_OBJECTS];             // cluster label of each object (-1: not live)
+  __shared__ uint32_t s_band[DTSIM_MAX_OBJECTS];      // per cluster root: the bands of raster tile rows its members' boxes meet
+  if (R.units) {
+    // Work units of k_resolve_clu: clusters of live objects whose screen boxes (+ 1.5 px: the rasters' box margin) overlap,
+    // transitively -- every queued object-box pixel of the env lies in the boxes of exactly one cluster.  Label propagation
+    // by one wavefront (lane = object, labels in LDS; a wavefront's DS operations execute in order).
+    if (tid < DTSIM_MAX_OBJECTS) {
+      s_band[tid] = 0u;
+      const bool live = tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1];
+      s_lab[tid] = live ? tid : -1;
+      for (int it = 0; it < m.n_obj; ++it) {           // wave-uniform bound
+        int l = s_lab[tid];
+        if (l >= 0)
+          for (int p = 0; p < m.n_obj; ++p) {
+            const int lp = s_lab[p];
+            if (lp >= 0 && lp < l &&
+                !(s_oboxf[p][1] + 1.5f < s_oboxf[tid][0] - 1.5f || s_oboxf[p][0] - 1.5f > s_oboxf[tid][1] + 1.5f ||
+                  s_oboxf[p][3] + 1.5f < s_oboxf[tid][2] - 1.5f || s_oboxf[p][2] - 1.5f > s_oboxf[tid][3] + 1.5f)) l = lp;
+          }
+        const bool ch = l != s_lab[tid];
+        if (!__ballot(ch)) break;
+        s_lab[tid] = l;
+      }
+    }
+    __syncthreads();                                   // labels complete before the block loop below reads them
+  }
   if (R.objmask) {
     // which objects' screen boxes meet each raster wavefront block (source-pixel boxes of the blocks: k_blk_setup): the
     // raster reads one 8-byte mask per (env, block) instead of walking the env's object boxes
@@ -795,6 +826,24 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
       for (int o = 0; o < m.n_obj; ++o)
         if (!(bb.y < s_oboxf[o][0] || bb.x > s_oboxf[o][1] || bb.w < s_oboxf[o][2] || bb.z > s_oboxf[o][3])) mk |= 1ull << o;
       R.objmask[(size_t)(pos ? pos[e] : e) * n_blk + b] = mk;   // indexed by position in the render order
+      if (R.units && mk) {                             // the band of this block's tile row, for the clusters of the objects it meets
+        const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, tiles_y = (R.H + DT_TILE_H - 1) / DT_TILE_H;
+        const int band = ((b >> 2) / tiles_x) / max(2, (tiles_y + 31) / 32);
+        unsigned long long t = mk;
+        while (t) { const int o = __builtin_ctzll(t); t &= t - 1ull; atomicOr(&s_band[s_lab[o]], 1u << band); }
+      }
+    }
+    __syncthreads();
+    if (R.units && tid < m.n_obj && s_lab[tid] == tid) {   // cluster root: one unit per band its members' boxes meet
+      unsigned long long mk = 0ull;
+      for (int p = 0; p < m.n_obj; ++p) if (s_lab[p] == tid) mk |= 1ull << p;
+      uint32_t bands = s_band[tid];
+      const int nbd = __popc(bands);
+      if (nbd) {
+        int ui = atomicAdd(R.work + 4, nbd);
+        if (ui + nbd > R.units_cap) bands = 0u;        // (never with the capacity dtsim_set_maps allocates: 256 units per env on average)
+        while (bands) { const int bd = __builtin_ctz(bands); bands &= bands - 1u; R.units[ui++] = make_uint4((uint32_t)e, (uint32_t)mk, (uint32_t)(mk >> 32), (uint32_t)bd); }
+      }
     }
   }
 }
@@ -927,8 +976,9 @@ __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, floa
 #define RO_PAIR_CAP 256                                  // pair slots per wavefront (16-bit entries)
 #endif
 #define RO_SCR_BYTES (DT_RO_PAIRS ? 64 * 4 * 8 + RO_PAIR_CAP * 2 : 0)   // per wavefront: sample keys + the pair list
+// sel (round 4, k_resolve_clu): the staged triangles to test are w_tris[sel[0 .. fill)] (a per-batch cull of a larger staged set)
 __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int fill, bool mine, int lane, float pcx, float pcy,
-                                     float wbest[4], int tbest[4], int32_t* dbg) {
+                                     float wbest[4], int tbest[4], int32_t* dbg, const uint16_t* sel = nullptr) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -948,7 +998,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
       const float qx = __shfl(pcx, src), qy = __shfl(pcy, src);
       float wb[4] = {0.f, 0.f, 0.f, 0.f};
       int tb[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-      for (int k = lane; k < fill; k += 64) test_tri(w_tris[k], qx, qy, wb, tb);   // tb starts at "no triangle" = +inf: ties keep the lower index
+      for (int k = lane; k < fill; k += 64) test_tri(w_tris[sel ? (int)sel[k] : k], qx, qy, wb, tb);   // tb starts at "no triangle" = +inf: ties keep the lower index
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         float wmax = wb[s];
@@ -1024,7 +1074,8 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    for (int j = 0; j < fill; ++j) {                   // wave-uniform
+    for (int jj = 0; jj < fill; ++jj) {                // wave-uniform
+      const int j = sel ? (int)sel[jj] : jj;
       const float4 bb = *reinterpret_cast<const float4*>(&w_tris[j]);              // bx0, bx1, by0, by1
       // four compares straight into scalar masks, ANDed on the scalar unit (as one bool expression the compiler builds the
       // conjunction out of 0 / 1 integers: 17 vector instructions instead of 4)
@@ -2892,6 +2943,211 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
   }
 }
 
+// ---- k_resolve_clu (round 4): the object-box pixels of k_raster_v3<OBJ> / k_raster_v3dr<OBJ>, one work unit per (env, CLUSTER of
+// objects whose screen boxes overlap) instead of one per (raster tile, env) -------------------------------------------------
+// Reference: objects.py:123-148, objmesh.py:360-375 (mesh draw), graphics.py:172-251 (4x MSAA): as k_resolve_obj, same z-buffer
+// (zbuffer_chunk) and shading (shade_msaa<true>).  Why: k_resolve_obj is a chain of dependent round trips per unit (vector ALUs
+// 56 % busy, 61 % of the wavefront time in s_waitcnt) over ~ 70 k units of ~ 100 pixels per launch, each re-streaming and
+// re-culling its objects' triangles; there are only ~ 0.8 live objects per env (profiles/r04_variants_ab.txt block G).  Here a
+// WORKGROUP takes an (env, cluster, band of raster tile rows) unit from the list k_obj_setup wrote (bands bound a unit's size: a
+// close-up object is split over several workgroups): (a) the band's raster blocks whose object mask meets the
+// cluster and that hold entries of this env -> a list in LDS with the prefix sums of their entry counts (the entries of one env in
+// one region are contiguous: qend); (b) the cluster's live triangles staged ONCE in LDS; (c) the four wavefronts take 64-entry
+// batches of the concatenated ranges: entry -> pixel -> source position, "mine" = inside a member's box (the raster's test; clusters
+// are > 3 px apart), triangle-parallel cull of the staged set against the batch's pixel box -> selection list -> the pair-list
+// z-buffer on the selection -> shade -> store.  Clusters with more live triangles than CLU_TRI_CAP re-stage per round (slow, rare).
+#ifndef CLU_TRI_CAP
+#define CLU_TRI_CAP 384
+#endif
+static_assert(CLU_TRI_CAP <= 1024, "pair entries carry the staged slot in 10 bits");
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES, DT_RO_WAVES)))
+void k_resolve_clu(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue, const int32_t* __restrict__ pos) {
+  extern __shared__ uint32_t s_mem[];
+  TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int npix = R.W * R.H;
+  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H), n_blk = n_tiles * 4;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.tile_recs);
+    for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
+  }
+  TriCov* s_tris = reinterpret_cast<TriCov*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4));          // [CLU_TRI_CAP]
+  uint2* s_blk = reinterpret_cast<uint2*>(s_tris + CLU_TRI_CAP);                                       // [n_blk + 1]: {block | first entry << 16, prefix of the counts}
+  uint32_t* w_scr = reinterpret_cast<uint32_t*>(s_blk + n_blk + 1) + wave * ((RO_SCR_BYTES + CLU_TRI_CAP * 2) / 4);   // per wavefront: z-buffer scratch, then the selection list
+  uint16_t* w_sel = reinterpret_cast<uint16_t*>(w_scr + RO_SCR_BYTES / 4);
+  __shared__ int s_unit, s_nb, s_nt, s_live;
+  const int n_units = min(R.work[4], R.units_cap);
+  const float ox_mrg = 1.0f;                           // membership margin: the rasters' box margin is <= 0.95 px, clusters are > 3 px apart
+  while (true) {
+    __syncthreads();                                   // the previous unit is done with the LDS lists (and the tile records are in)
+    if (tid == 0) { s_unit = atomicAdd(R.work + 5, 1); s_nb = 0; s_nt = 0; s_live = 0; }
+    __syncthreads();
+    const int u = s_unit;
+    if (u >= n_units) break;
+    const uint4 un = R.units[u];
+    const int e = (int)un.x;
+    const unsigned long long cm = ((unsigned long long)un.z << 32) | un.y;
+    const EnvCam c = cams[e];
+    const MapU m = map_u(R.maps[c.map_id]);
+    const ScreenTri* base = R.stris + (size_t)e * R.max_tris;
+    const float4* boxes = R.tribox + (size_t)e * R.max_tris;
+    const uint2* rng = R.objrange + (size_t)c.map_id * DTSIM_MAX_OBJECTS;
+    const ObjBox* obox = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
+    const int p = pos ? pos[e] : e, chunk = p / ENVS_PER_BLOCK, pp = p % ENVS_PER_BLOCK;
+    // (a) blocks with entries of this env whose object mask meets the cluster
+    const unsigned long long* masks = R.objmask + (size_t)p * n_blk;
+    const int band_rows = max(2, ((n_tiles / tiles_x) + 31) / 32);
+    const int b_lo = (int)un.w * band_rows * tiles_x * 4, b_hi = min(n_blk, b_lo + band_rows * tiles_x * 4);   // the unit's band of raster tile rows
+    for (int b = b_lo + tid; b < b_hi; b += RB) {
+      if (!(masks[b] & cm)) continue;
+      const uint16_t* qe = R.qend + ((size_t)(chunk * n_tiles + (b >> 2)) * 4 + (b & 3)) * ENVS_PER_BLOCK;
+      const int end = (int)qe[pp], start = pp ? (int)qe[pp - 1] : 0;
+      if (end > start) s_blk[atomicAdd(&s_nb, 1)] = make_uint2((uint32_t)b | ((uint32_t)start << 16), (uint32_t)(end - start));
+    }
+    // live triangles of the cluster (boxes only): does the set fit the staging area?
+    {
+      unsigned long long mm = cm;
+      int cnt = 0;
+      while (mm) {
+        const uint2 fc = rng[__builtin_ctzll(mm)];
+        mm &= mm - 1ull;
+        for (int t = (int)fc.x + tid; t < (int)(fc.x + fc.y); t += RB) { const float4 bb = boxes[t]; cnt += bb.x <= bb.y ? 1 : 0; }
+      }
+      if (cnt) atomicAdd(&s_live, cnt);
+    }
+    __syncthreads();
+    const int nb = s_nb, n_live = s_live;
+    if (nb == 0 || n_live == 0) continue;              // nothing queued for this cluster (workgroup-uniform)
+    // counts -> exclusive prefix sums, by wavefront 0 (64 list items per step)
+    if (wave == 0) {
+      int carry = 0;
+      for (int i0 = 0; i0 < nb; i0 += 64) {
+        const int i = i0 + lane;
+        const int cnt = i < nb ? (int)s_blk[i].y : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+        if (i < nb) s_blk[i].y = (uint32_t)(carry + inc - cnt);
+        carry += __shfl(inc, 63);
+      }
+      if (lane == 0) s_blk[nb] = make_uint2(0u, (uint32_t)carry);
+    }
+    // (b) stage the cluster's live triangles (coverage halves), all of them when they fit
+    const bool one_pass = n_live <= CLU_TRI_CAP;
+    auto stage = [&](const int skip) {                 // the live triangles number skip .. skip + CLU_TRI_CAP - 1 in (object, index) order
+      unsigned long long mm = cm;
+      int seen0 = 0;                                   // live triangles before the current object (workgroup-uniform bookkeeping is not needed when everything fits)
+      while (mm) {
+        const uint2 fc = rng[__builtin_ctzll(mm)];
+        mm &= mm - 1ull;
+        for (int t0 = (int)fc.x; t0 < (int)(fc.x + fc.y); t0 += RB) {
+          const int t = t0 + tid;
+          bool live = false;
+          if (t < (int)(fc.x + fc.y)) { const float4 bb = boxes[t]; live = bb.x <= bb.y; }
+          if (one_pass) {
+            if (live) s_tris[atomicAdd(&s_nt, 1)] = *reinterpret_cast<const TriCov*>(base + t);
+          } else {
+            // ordered slots: rank of this live triangle among the workgroup's (ballot per wavefront + the wavefront totals in LDS)
+            __shared__ int s_wc[RB / 64];
+            const unsigned long long bm = __ballot(live);
+            if (lane == 0) s_wc[wave] = __popcll(bm);
+            __syncthreads();
+            int before = seen0;
+#pragma unroll
+            for (int q = 0; q < RB / 64; ++q) { before += q < wave ? s_wc[q] : 0; }
+            int tot = 0;
+#pragma unroll
+            for (int q = 0; q < RB / 64; ++q) tot += s_wc[q];
+            const int rank = before + __popcll(bm & ((1ull << lane) - 1ull));
+            if (live && rank >= skip && rank < skip + CLU_TRI_CAP) s_tris[rank - skip] = *reinterpret_cast<const TriCov*>(base + t);
+            seen0 += tot;
+            __syncthreads();
+          }
+        }
+      }
+      if (!one_pass && tid == 0) s_nt = min(CLU_TRI_CAP, max(0, n_live - skip));
+    };
+    if (one_pass) stage(0);
+    __syncthreads();
+    const int n = (int)s_blk[nb].y;                    // entries of the unit
+    const int n_rounds = (n + 64 * (RB / 64) - 1) / (64 * (RB / 64));
+    for (int rd = 0; rd < n_rounds; ++rd) {            // workgroup-uniform: a round = one 64-entry batch per wavefront
+      const int idx = (rd * (RB / 64) + wave) * 64 + lane;
+      bool have = idx < n;
+      // list item of the entry: the last one whose prefix is <= idx
+      int lo_ = 0, hi_ = nb - 1;
+      while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if ((int)s_blk[mid].y <= idx) lo_ = mid; else hi_ = mid - 1; }
+      const uint2 bl = s_blk[lo_];
+      const int b = (int)(bl.x & 0xFFFFu), li = (int)(bl.x >> 16) + (idx - (int)bl.y);
+      const uint16_t* w_queue = queue + ((size_t)(chunk * n_tiles + (b >> 2)) * 4 + (b & 3)) * QREGION;
+      const uint32_t ent = have ? (uint32_t)w_queue[QREGION - 1 - li] : 0u;     // object-box entries sit at the far end of the region
+      const bool pedge = (ent & QE_PLANE_EDGE) != 0u;
+      const int lp = (int)(ent & 255u);
+      const int tile = b >> 2;
+      int pix = ((tile / tiles_x) * DT_TILE_H + (b & 3) * (WAVE_PIX / WAVE_W) + lp / WAVE_W) * R.W + (tile % tiles_x) * DT_TILE_W + lp % WAVE_W;
+      if (!have) pix = 0;
+      const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
+      const float nxv = l.x, nyv = l.y;
+      const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
+      // mine: inside the box of a member of the cluster (the block's entries of this env may belong to other clusters)
+      bool mine = false;
+      {
+        unsigned long long mm = cm;
+        while (mm) {                                   // workgroup-uniform
+          const ObjBox ob = obox[__builtin_ctzll(mm)];
+          mm &= mm - 1ull;
+          mine |= pcx >= ob.bx0 - ox_mrg && pcx <= ob.bx1 + ox_mrg && pcy >= ob.by0 - ox_mrg && pcy <= ob.by1 + ox_mrg;
+        }
+      }
+      have = have && mine;
+      float zbest[4] = {0.f, 0.f, 0.f, 0.f};
+      int tbest[4] = {-1, -1, -1, -1};
+      float x0 = have ? pcx : 1e30f, x1 = have ? pcx : -1e30f, y0 = have ? pcy : 1e30f, y1 = have ? pcy : -1e30f;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
+        y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
+      }
+      for (int skip = 0; skip < n_live; skip += CLU_TRI_CAP) {   // one pass when the cluster's triangles fit (workgroup-uniform)
+        if (!one_pass) { __syncthreads(); stage(skip); __syncthreads(); }
+        const int nt = s_nt;
+        if (__ballot(have)) {
+          // triangle-parallel cull of the staged set against the batch's pixel box -> selection list
+          int nsel = 0;
+          for (int k0 = 0; k0 < nt; k0 += 64) {
+            const int k = k0 + lane;
+            bool pass = false;
+            if (k < nt) { const float4 bb = *reinterpret_cast<const float4*>(&s_tris[k]); pass = !(bb.x > x1 || bb.y < x0 || bb.z > y1 || bb.w < y0); }
+            const unsigned long long pm = __ballot(pass);
+            if (pass) w_sel[nsel + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)k;
+            nsel += __popcll(pm);
+          }
+          if (nsel > 0)
+            zbuffer_chunk(s_tris, w_scr, nsel, have, lane, pcx, pcy, zbest, tbest,
+#ifdef DT_RO_STATS
+                          reinterpret_cast<int32_t*>(reinterpret_cast<char*>(R.pixtab) + (size_t)R.W * R.H * 64 + 1024 + 768),
+#else
+                          nullptr,
+#endif
+                          w_sel);
+        }
+      }
+#if DT_RO_SKIP_UNCOVERED
+      have = have && (pedge || (tbest[0] & tbest[1] & tbest[2] & tbest[3]) >= 0);
+#endif
+      if (have) {
+        const uint32_t v = shade_msaa<true>(c, m, R, s_tiles, nxv, nyv, base, zbest, tbest);
+        uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
+        const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;     // two stores: an aligned half + one byte
+        uint8_t* p8 = odd ? dst : dst + 2;
+        uint16_t* p16 = reinterpret_cast<uint16_t*>(odd ? dst + 1 : dst);
+        *p8 = (uint8_t)(odd ? v : v >> 16);
+        *p16 = (uint16_t)(odd ? v >> 8 : v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in, int tables) {
@@ -2914,6 +3170,11 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
     const bool v3_obj = quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1;
     if (!DT_OBJ_LAYERS || !(obj && (v3_obj || v3dr)) || !R.objlayer || !R.layers || (R.W & 3) != 0) R.layer_cap = 0;
   }
+  // k_resolve_clu (units per (env, object cluster)) behind the rasters that share its 128 x 2 block / queue layout; DTSIM_RESOLVE_OBJ_OLD=1: k_resolve_obj
+  static const bool clu_off = [] { const char* v = getenv("DTSIM_RESOLVE_OBJ_OLD"); return v && v[0] == '1'; }();
+  const bool use_clu = DT_RESOLVE_CLU && !clu_off && obj && R.units && R.tribox && R.objmask && DT_WAVE_W == 128 &&
+                       ((quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1) || v3dr);
+  if (!use_clu) R.units = nullptr;
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
@@ -2930,12 +3191,13 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
                      v3dr ? envd : nullptr, R.W, R.H);
+  (void)hipMemsetAsync(R.work, 0, 8 * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj / k_resolve_clu (k_obj_setup appends units)
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
     hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams, pos);
   }
-  (void)hipMemsetAsync(R.work, 0, 4 * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj
+
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
   const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
@@ -2986,7 +3248,11 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
     if (!quad) hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
-    if (obj) {
+    if (obj && use_clu) {
+      const size_t n_blk = dt_raster_tiles(R.W, R.H) * 4;
+      const size_t lds5 = lds + (size_t)CLU_TRI_CAP * sizeof(TriCov) + (n_blk + 1) * sizeof(uint2) + (size_t)(RB / 64) * (RO_SCR_BYTES + CLU_TRI_CAP * 2);
+      hipLaunchKernelGGL(k_resolve_clu, dim3(256 * 3), dim3(RB), lds5, s, R, cams, R.queue, pos);
+    } else if (obj) {
       const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
       hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, 1, pos ? envq : (const EnvQ*)nullptr);
     }
