@@ -408,3 +408,41 @@ def test_allgather_frames_through_the_c_abi_one_rank():
     sim.close()
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_sharded_exchange_on_the_device_one_rank():
+    """ShardedSimulator.step_render_gather on the real simulator (world_size 1: no transfer, but the whole produce path -- the render
+    pass bound into the slot's slice through dtsim_bind_frames, dtsim_observe into the slot, slot rotation, flush): every batch handed
+    out for step t equals what a second simulator with the same seed renders / observes at step t."""
+    import torch
+    from dtsim import BatchedSimulator
+    from dtsim.sharding import ShardedSimulator
+    N, W, H, T = 6, 160, 120, 4
+    kw = dict(camera_width=W, camera_height=H, distortion=True, domain_rand=False, seed=11)
+    acts = np.random.default_rng(2).uniform(0.2, 0.8, (T, N, 2)).astype(np.float32)
+    ref = BatchedSimulator("small_loop", N, **kw)
+    want_f, want_o = [], []
+    for t in range(T):
+        ref.step(acts[t]); ref.render()
+        want_f.append(ref.frames_host().copy())
+        want_o.append(torch.as_tensor(ref.observe(60, 80), device="cuda:0").cpu().numpy().copy())
+    ref.close()
+    for what, want, obs in (("frames", want_f, None), ("observe", want_o, (60, 80))):
+        ss = ShardedSimulator.wrap(BatchedSimulator("small_loop", N, **kw), N, 0, 1)
+        got = {}
+        for t in range(T):
+            k, batch = ss.step_render_gather(acts[t], overlap=True, dst=0, local_actions=True, what=what, obs=obs)
+            if t == 0:
+                assert k is None and batch is None
+            else:
+                assert k == t - 1
+                got[k] = batch.cpu().numpy().copy()
+        k, batch = ss.flush_gather(dst=0)
+        assert k == T - 1
+        got[k] = batch.cpu().numpy().copy()
+        for t in range(T):
+            assert np.array_equal(got[t], want[t]), (what, t)
+        # the blocking form delivers the step it just made
+        k, batch = ss.step_render_gather(acts[0], overlap=False, dst=0, local_actions=True, what=what, obs=obs)
+        assert batch is not None and batch.shape[0] == N
+        ss.sim.close()
