@@ -1390,6 +1390,7 @@ __device__ inline PixInv pix_inv_dr(float nx, float ny, bool valid, const DrCam&
 // stored for it is not final: k_resolve_obj leaves a pixel alone when no mesh triangle covers any of its samples and the
 // bit is clear (the raster's one-ray colour is the pixel).  k_raster_v3 / k_raster_v3dr tell; the other rasters always set it.
 #define QE_PLANE_EDGE 0x8000u
+#define QE_ALWAYS_EDGE 0x4000u    // plane-edge entries of k_raster_v3 (front of the region): never a one-ray pixel (resolve_region skips its interior test)
 static_assert(ENVS_PER_BLOCK <= 64, "the env position of a queue entry has six bits");
 #define ITEM_B DT_ITEM_B   // 64-entry batches per k_resolve work item
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
@@ -1914,7 +1915,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   auto phase1 = [&](auto utag, const int r0) __attribute__((always_inline)) -> int {
     constexpr int U = decltype(utag)::value;
     int n_list = 0;                                  // wave-uniform
-    bool have[U], interior[U];
+    bool have[U], interior[U], tagged[U], skip[U];
       int pix[U], el[U], env[U];
       PixTab pt[U];
       float Xu[U], Zu[U];
@@ -1932,7 +1933,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         }
         // the entries were written by this wavefront (workgroup) a moment ago: bypass the (possibly stale) L1 line
         const uint32_t ent = have[u] ? (uint32_t)__builtin_nontemporal_load(w_queue + qoff) : 0u;
-        el[u] = (int)(ent >> 8);
+        el[u] = (int)((ent >> 8) & 63u);
+        // QE_ALWAYS_EDGE (k_raster_v3, round 4): the pixel can never be a one-ray pixel (horizon band, near / far limits): it goes to
+        // the list without the interior test -- and without its loads when the whole batch is such (these entries come in runs)
+        tagged[u] = (ent & QE_ALWAYS_EDGE) != 0u;
+        skip[u] = !__ballot(have[u] && !tagged[u]);    // wave-uniform
         const int lp = (int)(ent & 255u);
         pix[u] = (wave_y0 + ry + lp / WWc) * R.W + tile_x0 + rx + lp % WWc;
       }
@@ -1940,6 +1945,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       uint4 qb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        qa[u] = make_float4(0.f, 0.f, 0.f, 0.f); qb[u] = make_uint4(0u, 0u, 0u, 0u); env[u] = 0;
+        pt[u] = PixTab{0.f, 0.f, 0.f, 0xFFFFu};
+        if (skip[u]) continue;                       // wave-uniform
         pt[u] = pixtab[pix[u]];
         const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
         qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
@@ -1949,6 +1957,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        interior[u] = false; Xu[u] = Zu[u] = 0.f; te_c[u] = make_uint2(0u, 0u);
+        if (skip[u]) continue;                       // wave-uniform
         const float A = qa[u].x, B = qa[u].y, Cx = qa[u].z, Cz = qa[u].w;
         const float Xhi = __uint_as_float(qb[u].x), Zhi = __uint_as_float(qb[u].y);
         Xu[u] = fmaf(pt[u].lf, B, fmaf(pt[u].lr, A, Cx)); Zu[u] = fmaf(pt[u].lf, -A, fmaf(pt[u].lr, B, Cz));
@@ -1960,15 +1970,17 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const float ux = Xu[u] - ox, uz = Zu[u] - oz;        // in [0, S) inside the owner tile
         const float d = fminf(fminf(ux, Sf - ux), fminf(uz, Sf - uz));
         const bool in_range = Xu[u] - 0.5f >= lo && Xu[u] - 0.5f <= Xhi && Zu[u] - 0.5f >= lo && Zu[u] - 0.5f <= Zhi;
-        interior[u] = have[u] && in_range && te_c[u].x >= tex_min && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
+        interior[u] = have[u] && !tagged[u] && in_range && te_c[u].x >= tex_min && pt[u].lit > 0.f && (pt[u].mi & 0xFFFFu) < 0xFFF0u && d > mrg * R.q_per_m;
       }
       uint4 qc[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]);   // always in bounds (record 0 / 1 for non-tiles)
+      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u]) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]); }   // always in bounds (record 0 / 1 for non-tiles)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
-        if (interior[u]) store_rgb(env[u], pix[u], rgb);
+        if (!skip[u]) {                                // wave-uniform
+          const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
+          if (interior[u]) store_rgb(env[u], pix[u], rgb);
+        }
         const bool msaa = have[u] && !interior[u];
         const unsigned long long mm = __ballot(msaa);
         if (msaa) w_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))] = (uint32_t)pix[u] | ((uint32_t)el[u] << 24);
@@ -2028,6 +2040,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         uint32_t aH[3] = {0u, 0u, 0u}, aL[3] = {0u, 0u, 0u};
         int n_sky = 0, n_gnd = 0;
         float gX = 0.f, gZ = 0.f;                      // ground hit (quad coordinates) of the lowest-index ground sample
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t raddr_prev = 0u;
 #pragma unroll
         for (int s = 3; s >= 0; --s) {
           const uint32_t hr = sp.dlr[s >> 1], hf = sp.dlf[s >> 1];
@@ -2048,7 +2062,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
           n_gnd += is_gnd; n_sky += !(is_tile | is_gnd);
           if (is_gnd) { gX = Xg; gZ = Zg; }
           const uint32_t cell = __builtin_amdgcn_perm(zic, xic, sel);
-          const uint4 rec = *reinterpret_cast<const uint4*>(qtex + (is_tile ? tb + (cell << 4) : 0u));
+          // one record per DISTINCT tile among the pixel's samples (round 4: the path is texture-unit heavy, its gathers fully divergent;
+          // the samples of most edge pixels share a tile, or are not on a tile at all): a lane loads only when its address changes
+          const uint32_t raddr = is_tile ? tb + (cell << 4) : 0u;
+          if (s == 3 || raddr != raddr_prev) rec = *reinterpret_cast<const uint4*>(qtex + raddr);
+          raddr_prev = raddr;
           aH[0] = __builtin_amdgcn_udot4(rec.x, wh, aH[0], false); aL[0] = __builtin_amdgcn_udot4(rec.x, wl, aL[0], false);
           aH[1] = __builtin_amdgcn_udot4(rec.y, wh, aH[1], false); aL[1] = __builtin_amdgcn_udot4(rec.y, wl, aL[1], false);
           aH[2] = __builtin_amdgcn_udot4(rec.z, wh, aH[2], false); aL[2] = __builtin_amdgcn_udot4(rec.z, wl, aL[2], false);
