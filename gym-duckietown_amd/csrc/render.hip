@@ -49,7 +49,8 @@
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
 #ifndef DT_ENV_SORT
-#define DT_ENV_SORT 0              // 1: envs in k_env_sort order -- half the L2 fills, 4-5 % slower (dt_launch_render)
+#define DT_ENV_SORT 1              // envs in k_env_sort order: half the L2 fills.  Round 3 switched it off (4 - 5 % slower with that kernel); with round 4's
+                                   // k_raster_v3 (32 x 2 slots, 6 wavefronts per SIMD) it costs nothing (profiles/r04_variants_ab.txt block I): on again
 #endif
 #ifndef DT_RESOLVE_CLU
 #define DT_RESOLVE_CLU 0           // round 4: object-box pixels by k_resolve_clu (one WORKGROUP per (env, object cluster, band of raster tile rows): blocks ->
@@ -3197,12 +3198,9 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
 #if !DT_ENV_SORT
-  // Round 3: the sort is off.  It was introduced (round 2) for L2 locality when the pass waited for its record loads.  With
-  // k_raster_v3 the loads hide behind the vector issue, and the sorted order is SLOWER on the headline workload: 2.00-2.01 ms
-  // per step against 1.87-1.93 in index order on the same box (profiles/r03_variants_ab.txt block H) -- neighbours in the
-  // order look at the same scene, so the slow blocks of a frame pile up in the same workgroups and on one XCD.  What the sort
-  // buys is counted L2 fills (FETCH_SIZE 2.08 -> 0.90 GB raw per pass, with the XCD-affine workgroup map only; the fills come
-  // from the 7 MB record pool, which the 256 MB Infinity Cache holds).  -DDT_ENV_SORT=1 restores it.
+  // (index order: round 3's choice, when the sorted order was 4 - 5 % slower -- neighbours in the order look at the same scene, so the
+  // slow blocks of a frame piled up in the same workgroups and on one XCD.  With round 4's kernel the two orders run at the same
+  // speed and the sorted one halves the L2 fills: FETCH_SIZE 2.15 -> 1.00 GB raw per pass, profiles/r04_variants_ab.txt block I.)
   pos = nullptr;
 #endif
   if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
