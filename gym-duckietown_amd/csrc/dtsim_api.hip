@@ -71,6 +71,7 @@ struct dtsim {
   dtsim_probe* d_qout = nullptr;
   dtsim_agent_info* d_agent = nullptr;
   int render_tables = 0;          // dt_launch_render: which env-invariant tables are valid (camera LUT + maps unchanged)
+  RenderOverlap overlap{};        // render parts (DTSIM_RENDER_PARTS > 1): second stream + ordering events
   int q_cap = 0;
   // render
   uint8_t* frames_own = nullptr;
@@ -271,11 +272,21 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
-      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8) * sizeof(int32_t));   // counts, debug counters, work-list header
+      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8 * DT_MAX_RENDER_PARTS) * sizeof(int32_t));   // counts, debug counters, work-list header (of each render part)
       if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * (DT_ITEMS_PER_WG + DT_ENVS_PER_BLOCK) * sizeof(uint32_t));   // k_resolve's list + k_resolve_obj's (at most one per env of a workgroup)
       if (e == hipSuccess) e = hipMalloc(&h->d_qend, n_wg * 4 * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
     }
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(lut): %s", hipGetErrorString(e)); }
+    {  // render parts: off (1) unless asked for
+      const char* rp = getenv("DTSIM_RENDER_PARTS");
+      const int parts = rp ? std::min(std::max(atoi(rp), 1), DT_MAX_RENDER_PARTS) : 1;
+      if (parts > 1) {
+        e = hipStreamCreateWithFlags(&h->overlap.s2, hipStreamNonBlocking);
+        for (int i = 0; i <= DT_MAX_RENDER_PARTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&h->overlap.ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "render parts (stream / events): %s", hipGetErrorString(e)); }
+        h->overlap.parts = parts;
+      }
+    }
     (void)hipMemset((char*)h->d_pixtab + (size_t)cfg->cam_height * cfg->cam_width * 64, 0, 2048);
     if (!(cfg->flags & DTSIM_F_DISTORTION)) {
       // identity LUT: output pixel == rectilinear pixel
@@ -299,6 +310,8 @@ void dtsim_destroy(dtsim_t* h) {
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
                   h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_units, h->d_objlayer, h->d_layers, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->overlap.s2) { (void)hipStreamSynchronize(h->overlap.s2); (void)hipStreamDestroy(h->overlap.s2); }
+  for (hipEvent_t ev : h->overlap.ev) if (ev) (void)hipEventDestroy(ev);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -896,11 +909,23 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
   R.qmax_tiles = 0;
   for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);
+#ifdef DT_WAVE_SPANS
+  R.spans = (getenv("DTSIM_WAVE_SPANS") && h->d_units) ? reinterpret_cast<unsigned long long*>(h->d_units) : nullptr;
+  if (R.spans) HIPCHK(hipMemsetAsync(R.spans, 0, 2 * 2048 * 4 * 8 * 8, h->stream));
+#endif
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
-    h->render_tables = dt_launch_render(h->stream, h->A, R, h->render_tables);
+    h->render_tables = dt_launch_render(h->stream, h->A, R, h->render_tables, h->overlap.parts > 1 ? &h->overlap : nullptr);
   }
   HIPCHK(hipGetLastError());
+#ifdef DT_WAVE_SPANS
+  if (R.spans) {   // the spans of the last render -> the file DTSIM_WAVE_SPANS names (tools/wave_spans.py reads it)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> sp(2 * 2048 * 4 * 8);
+    HIPCHK(hipMemcpy(sp.data(), R.spans, sp.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(getenv("DTSIM_WAVE_SPANS"), "wb")) { fwrite(sp.data(), 8, sp.size(), f); fclose(f); }
+  }
+#endif
   if (getenv("DTSIM_DEBUG_QUEUE") || getenv("DTSIM_DEBUG_TIMERS")) {   // profiling aid: how many pixels took the exact MSAA path (DEBUG_TIMERS: without the in-kernel counters)
     HIPCHK(hipStreamSynchronize(h->stream));
     {  // phase timers of the DT_Q_TIMING build variant (zero otherwise)

@@ -61,6 +61,9 @@
 #define DT_V3_DR 1                 // domain randomisation on the quad records (render_v3dr.inc); 0: the generic k_raster<DR=1>
 #endif
 #include <type_traits>
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 // Format-converting buffer loads (MTBUF): tbuffer_load_format_d16_xyzw with format 8_8_8_8 / UINT returns the four BYTES of one
 // dword as four u16 in two registers -- exactly the operand pairs of v_dot2_u32_u16.  clang has no builtin for it; the LLVM
@@ -1397,7 +1400,7 @@ static_assert(ENVS_PER_BLOCK <= 64, "the env position of a queue entry has six b
 #define ITEMS_PER_WG DT_ITEMS_PER_WG
 #define GRAB_MAX 16       // work items per cursor atomic, at most
 #ifndef DT_RES_ENVS
-#define DT_RES_ENVS 8
+#define DT_RES_ENVS 1             // round 4: 8 -> 1 (one env per item: the launch ended on its longest octet; C5 - 8 %, profiles/r04_wave_spans.txt)
 #endif
 #define RES_ENVS DT_RES_ENVS  // env positions of a chunk per k_resolve_obj work item
 static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITEMS_PER_WG, "octet items");
@@ -1406,22 +1409,45 @@ static_assert(ENVS_PER_BLOCK % RES_ENVS == 0 && ENVS_PER_BLOCK / RES_ENVS <= ITE
 // env positions of a raster workgroup that queued object-box pixels.
 // groups: bit g = env group g of the chunk (RES_ENVS positions) has object-box entries in some region of the workgroup; the
 // quad-record rasters pass what they queued (round 4: 60 % of the items used to be empty), the others every group.
-__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg, uint32_t groups = ~0u) {
-  const int ng = ENVS_PER_BLOCK / RES_ENVS;
-  groups &= (1u << ng) - 1u;
-  const int ni = __popc(groups);
-  if (ni == 0) return;
-  int pos = atomicAdd(R.work + 2, ni);
-  for (int i = 0; i < ng; ++i) if ((groups >> i) & 1u) R.items2[pos++] = rwg * ITEMS_PER_WG + (uint32_t)i;
+// Round 4: the list has two ends.  Items of env groups that queued a lot (heavy: bit g, a subset of groups) go to the front in push
+// order, the others to the back (from the last slot down); k_resolve_obj walks front to back, so the units of close-up objects -- up to
+// 1 024 pixels against every triangle of the object, 100 - 250 us of one wavefront -- start first instead of wherever their raster
+// workgroup happened to finish (the launch used to end on a third of the wavefronts, profiles/r04_wave_spans.txt).
+// work[2] = front count, work[6] = back count, work[3] = cursor; capacity = one slot per (raster workgroup, env group).
+__device__ inline size_t obj_items_cap(const RenderParams& R) {
+  const int n_tiles = ((R.W + DT_TILE_W - 1) / DT_TILE_W) * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
+  return (size_t)((R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK) * n_tiles * (ENVS_PER_BLOCK / RES_ENVS);
 }
+__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg, uint32_t groups = ~0u, uint32_t heavy = 0u) {
+  const int ng = ENVS_PER_BLOCK / RES_ENVS;
+  if (ng < 32) groups &= (1u << ng) - 1u;
+  heavy &= groups;
+  const uint32_t light = groups & ~heavy;
+  const int nh = __popc(heavy), nl = __popc(light);
+  if (nh) {
+    int pos = atomicAdd(R.work + 2, nh);
+    for (int i = 0; i < ng; ++i) if ((heavy >> i) & 1u) R.items2[pos++] = rwg * ITEMS_PER_WG + (uint32_t)i;
+  }
+  if (nl) {
+    size_t pos = obj_items_cap(R) - 1 - (size_t)atomicAdd(R.work + 6, nl);
+    for (int i = 0; i < ng; ++i) if ((light >> i) & 1u) R.items2[pos--] = rwg * ITEMS_PER_WG + (uint32_t)i;
+  }
+}
+#ifndef DT_RO_HEAVY
+#define DT_RO_HEAVY 128            // entries of one env in one 256-pixel wavefront region from which its unit counts as heavy
+#endif
 // which env groups of the chunk have entries in THIS wavefront's region: qend_v = the region's fill after each env (lane = position)
-__device__ inline uint32_t obj_groups_of(int qend_v, int lane) {
+__device__ inline uint32_t obj_groups_of(int qend_v, int lane, uint32_t* heavy = nullptr) {
   const int up = __shfl_up(qend_v, 1);
-  const bool has = lane < ENVS_PER_BLOCK && qend_v != (lane == 0 ? 0 : up);
-  const unsigned long long m = __ballot(has);
-  uint32_t g = 0u;
+  const int cnt = lane < ENVS_PER_BLOCK ? qend_v - (lane == 0 ? 0 : up) : 0;
+  const unsigned long long m = __ballot(cnt != 0), mh = __ballot(cnt >= DT_RO_HEAVY);
+  uint32_t g = 0u, gh = 0u;
 #pragma unroll
-  for (int i = 0; i < ENVS_PER_BLOCK / RES_ENVS; ++i) g |= ((m >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
+  for (int i = 0; i < ENVS_PER_BLOCK / RES_ENVS; ++i) {
+    g |= ((m >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
+    gh |= ((mh >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
+  }
+  if (heavy) *heavy = gh;
   return g;
 }
 
@@ -2674,17 +2700,30 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES
   uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
   EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * ENVS_PER_BLOCK;                    // wavefront-local
   const int n_items = R.work[0];                     // written by the raster launch
+#ifdef DT_WAVE_SPANS   // experiment: wall-clock span of every persistent wavefront (100 MHz ticks), read back by dtsim_render
+  const unsigned long long span_t0 = wall_clock64(); unsigned long long span_long = 0, span_first = 0, span_first_at = 0, span_sum = 0, span_last = 0; int span_n = 0;
+#endif
   // One atomic buys `grab` items, taken with stride n_grabs through the list: same-address atomics are
   // serialised by the L2 (~0.2 ms per 100 k of them), and the stride keeps the consecutive items of one hot
   // raster workgroup on different wavefronts.  Granularity: ~4 grabs per resident wavefront, <= GRAB_MAX items.
   const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
   const int n_grabs = (n_items + grab - 1) / grab;
+  // Round 4: the first grab of a wavefront is its own index (the launch holds exactly the resident workgroups, resident_blocks()):
+  // 5 000 wavefronts starting on one cursor atomic spent 30 - 60 us each waiting for it (profiles/r04_wave_spans.txt).
+  const int n_waves = (int)gridDim.x * (RB / 64);
+  bool first_grab = true;
   while (true) {
-    int g = 0;
-    if (lane == 0) g = atomicAdd(R.work + 1, 1);
-    g = __builtin_amdgcn_readfirstlane(g);
+    int g = wave * (int)gridDim.x + (int)blockIdx.x;
+    if (!first_grab) {
+      if (lane == 0) g = n_waves + atomicAdd(R.work + 1, 1);
+      g = __builtin_amdgcn_readfirstlane(g);
+    }
+    first_grab = false;
     if (g >= n_grabs) break;
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
+#ifdef DT_WAVE_SPANS
+      const unsigned long long span_i0 = wall_clock64(); ++span_n;
+#endif
       const uint32_t item = R.items[it];
       const int rwg = (int)(item / ITEMS_PER_WG), part = (int)(item % ITEMS_PER_WG);
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
@@ -2729,8 +2768,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES
           dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16);
         }
       }
+#ifdef DT_WAVE_SPANS
+      { const unsigned long long d = wall_clock64() - span_i0; span_long = d > span_long ? d : span_long; span_sum += d; span_last = d; if (span_n == 1) { span_first = d; span_first_at = span_i0 - span_t0; } }
+#endif
     }
   }
+#ifdef DT_WAVE_SPANS
+  if (R.spans && lane == 0) {
+    unsigned long long* o = R.spans + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = span_t0; o[1] = wall_clock64(); o[2] = (unsigned long long)span_n; o[3] = span_long; o[4] = span_first; o[5] = span_first_at; o[6] = span_sum; o[7] = span_last;
+  }
+#endif
 }
 
 // Exact path of the pixels inside mesh-object screen boxes (and, after the generic raster, of every queued pixel).
@@ -2767,14 +2815,24 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
   TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
   uint32_t* w_scr = reinterpret_cast<uint32_t*>(reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + (RB / 64) * TRI_CAP) +
                     wave * (RO_SCR_BYTES / 4);       // z-buffer scratch of the pair schedule
-  const int n_items = R.work[2];                     // written by the raster launch (push_obj_items)
+  const int n_front = R.work[2], n_items = n_front + R.work[6];   // written by the raster launch (push_obj_items): heavy items first
+  const size_t items_cap = obj_items_cap(R);
+  auto item_at = [&](int i) -> uint32_t { return R.items2[i < n_front ? (size_t)i : items_cap - 1 - (size_t)(i - n_front)]; };
+#ifdef DT_WAVE_SPANS
+  const unsigned long long span_t0 = wall_clock64(); unsigned long long span_long = 0, span_first = 0, span_first_at = 0, span_sum = 0, span_last = 0; int span_n = 0;
+#endif
   const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
   const int n_grabs = (n_items + grab - 1) / grab;
   auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };   // position in the render order -> env
+  const int n_waves = (int)gridDim.x * (RB / 64);     // first grab = the wavefront's own index, as in k_resolve
+  bool first_grab = true;
   while (true) {
-    int g = 0;
-    if (lane == 0) g = atomicAdd(R.work + 3, 1);
-    g = __builtin_amdgcn_readfirstlane(g);
+    int g = wave * (int)gridDim.x + (int)blockIdx.x;
+    if (!first_grab) {
+      if (lane == 0) g = n_waves + atomicAdd(R.work + 3, 1);
+      g = __builtin_amdgcn_readfirstlane(g);
+    }
+    first_grab = false;
     if (g >= n_grabs) break;
     // Round 4: the item loop is software-pipelined -- the id of the item after next and the queue fills (qend) of the next
     // item are loaded while the current one is processed: the kernel is a chain of dependent round trips per (tile, env)
@@ -2785,7 +2843,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #pragma unroll
       for (int r = 0; r < 4; ++r) endv_[r] = lane < ENVS_PER_BLOCK ? (int)R.qend[((size_t)rwg_ * 4 + r) * ENVS_PER_BLOCK + lane] : 0;
     };
-    uint32_t item_cur = R.items2[g], item_nxt = g + n_grabs < n_items ? R.items2[g + n_grabs] : 0u;
+    uint32_t item_cur = item_at(g), item_nxt = g + n_grabs < n_items ? item_at(g + n_grabs) : 0u;
     int endv_nxt[4];
     load_qend(item_cur, endv_nxt);
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
@@ -2795,7 +2853,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
       for (int r = 0; r < 4; ++r) endv[r] = endv_nxt[r];
       item_cur = item_nxt;
       if (it + n_grabs < n_items) load_qend(item_cur, endv_nxt);
-      item_nxt = it + 2 * n_grabs < n_items ? R.items2[it + 2 * n_grabs] : 0u;
+      item_nxt = it + 2 * n_grabs < n_items ? item_at(it + 2 * n_grabs) : 0u;
       const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG) * RES_ENVS;
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
@@ -2829,6 +2887,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DT_WAVE_SPANS
+      const unsigned long long span_i0 = wall_clock64(); ++span_n;
+#endif
       for (int p = p0; p < min(p0 + RES_ENVS, ne); ++p) {   // wave-uniform: one (tile, env) unit
         int c_[4], s_[4];
 #pragma unroll
@@ -2958,8 +3019,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next item overwrites w_cams
       __builtin_amdgcn_wave_barrier();
+#ifdef DT_WAVE_SPANS
+      { const unsigned long long d = wall_clock64() - span_i0; span_long = d > span_long ? d : span_long; span_sum += d; span_last = d; if (span_n == 1) { span_first = d; span_first_at = span_i0 - span_t0; } }
+#endif
     }
   }
+#ifdef DT_WAVE_SPANS
+  if (R.spans && lane == 0) {
+    unsigned long long* o = R.spans + ((size_t)(2048 + blockIdx.x) * 4 + wave) * 8;
+    o[0] = span_t0; o[1] = wall_clock64(); o[2] = (unsigned long long)span_n; o[3] = span_long; o[4] = span_first; o[5] = span_first_at; o[6] = span_sum; o[7] = span_last;
+  }
+#endif
 }
 
 // ---- k_resolve_clu (round 4): the object-box pixels of k_raster_v3<OBJ> / k_raster_v3dr<OBJ>, one work unit per (env, CLUSTER of
@@ -3169,7 +3239,88 @@ void k_resolve_clu(RenderParams R, const EnvCam* __restrict__ cams, const uint16
 
 }  // namespace
 
-int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in, int tables) {
+// Workgroups of `kernel` (RB threads, lds bytes of dynamic LDS) the device holds at once: the launch size of the persistent exact-path kernels.
+template <class K> static size_t resident_blocks(K kernel, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, size_t> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({dev, lds});
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, n_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RB, lds) != hipSuccess || per_cu < 1) per_cu = 3;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+  return cache[{dev, lds}] = (size_t)per_cu * (size_t)n_cu;
+}
+
+// One range of chunks through its raster (stream s) and exact-path kernels (stream s_res, after event ev when it is
+// another stream): the whole batch, or one of dt_launch_render's render parts (every array already moved to the range).
+static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t ev, const RenderParams& R, EnvCam* cams, EnvFast* fasts, EnvQ* envq,
+                                  EnvV* envv, EnvD* envd, uint8_t* frames_raster, bool quad, bool v3, bool v3dr, bool obj, bool use_clu, bool has_pos, const int32_t* pos_map) {
+  const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+  const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
+  const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
+  const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
+  const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
+  // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of DT_Q_TILE_GROUP (the last group padded)
+  const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + DT_Q_TILE_GROUP - 1) / DT_Q_TILE_GROUP) * DT_Q_TILE_GROUP * ((n_chunks + 7) / 8) * 8));
+#define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
+  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, frames_raster, R.texels,               \
+                     reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
+  if (quad) {
+    const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
+    PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
+    SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
+#define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, frames_raster, R.qtex, \
+                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
+    const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
+    // k_raster_v3 (render_v3.inc): S = 256 textures, padded grids up to 32 x 24 tiles, up to 4 maps (else k_raster_q)
+    if (v3) {
+      const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
+#define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, frames_raster, R.qtex, \
+                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
+#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1
+      if (obj) LAUNCH_V3(true); else
+#endif
+      LAUNCH_V3(false);
+#undef LAUNCH_V3
+    } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
+    else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
+#undef LAUNCH_Q
+#if DT_V3_DR
+  } else if (v3dr) {
+    const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
+    if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+    else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+#endif
+  } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
+  else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
+#undef LAUNCH_RASTER
+  // exact path.  Quad pipeline: the plane-edge pixels were resolved inside k_raster_q (resolve_region); generic raster:
+  // k_resolve drains them (front of the queue regions).  Pixels inside mesh-object screen boxes (far end of the regions)
+  // are k_resolve_obj's, after either raster.
+  if (!R.no_msaa) {
+    if (s_res != s && (obj || !quad)) { (void)hipEventRecord(ev, s); (void)hipStreamWaitEvent(s_res, ev, 0); }
+    // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
+    // (round 4: EXACTLY the resident workgroups -- every wavefront's first grab is static, a workgroup that waits for a slot would sit on its items)
+    if (!quad) {
+      const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve, lds2)));
+      hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s_res, R, cams, R.queue, R.qcount);
+    }
+    if (obj && use_clu) {
+      const size_t n_blk = dt_raster_tiles(R.W, R.H) * 4;
+      const size_t lds5 = lds + (size_t)CLU_TRI_CAP * sizeof(TriCov) + (n_blk + 1) * sizeof(uint2) + (size_t)(RB / 64) * (RO_SCR_BYTES + CLU_TRI_CAP * 2);
+      hipLaunchKernelGGL(k_resolve_clu, dim3(256 * 3), dim3(RB), lds5, s_res, R, cams, R.queue, pos_map);
+    } else if (obj) {
+      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
+      const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve_obj<DT_RES_NB>, lds4)));
+      hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s_res, R, cams, R.queue, 1, has_pos ? envq : (const EnvQ*)nullptr);
+    }
+  }
+}
+
+int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in, int tables, const RenderOverlap* ov) {
   RenderParams R = R_in;
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
@@ -3215,63 +3366,49 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   }
 
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-  const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
-  const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
-  const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
-  const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
-  // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of DT_Q_TILE_GROUP (the last group padded)
-  const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + DT_Q_TILE_GROUP - 1) / DT_Q_TILE_GROUP) * DT_Q_TILE_GROUP * ((n_chunks + 7) / 8) * 8));
-#define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
-  hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, R.frames, R.texels,               \
-                     reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
-  if (quad) {
-    const size_t ldsq = (size_t)R.n_qtiles * 8 + (size_t)RB * PPT * sizeof(uint32_t);
+  const bool v3 = quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= V3_MAX_ROWS && R.n_maps * V3_MAP_COLS <= V3_TAB_PITCH / 2 &&
+                  (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP != 1));
+  if (quad && !(tables & 1)) {
     PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
-    if (!(tables & 1)) hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
+    hipLaunchKernelGGL(k_pix_setup, dim3((R.W * R.H + 255) / 256), dim3(256), 0, s, R, reinterpret_cast<const float4*>(R.lut), pixtab, samptab);
     tables |= 1;
-#define LAUNCH_Q(OBJ_, S256_) hipLaunchKernelGGL((k_raster_q<OBJ_, S256_>), gridq, dim3(RB), ldsq, s, R, cams, fasts, envq, R.frames, R.qtex, \
-                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
-    const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
-    // k_raster_v3 (render_v3.inc): S = 256 textures, padded grids up to 32 x 24 tiles, up to 4 maps (else k_raster_q)
-    const bool v3 = R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= V3_MAX_ROWS && R.n_maps * V3_MAP_COLS <= V3_TAB_PITCH / 2 &&
-                    (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP != 1));
-    if (v3) {
-      const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
-#define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, R.frames, R.qtex, \
-                                           reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
-#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1
-      if (obj) LAUNCH_V3(true); else
-#endif
-      LAUNCH_V3(false);
-#undef LAUNCH_V3
-    } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
-    else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
-#undef LAUNCH_Q
-#if DT_V3_DR
-  } else if (v3dr) {
-    const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
-    if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
-    else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, R.frames, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
-#endif
-  } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
-  else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
-#undef LAUNCH_RASTER
-  // exact path.  Quad pipeline: the plane-edge pixels were resolved inside k_raster_q (resolve_region); generic raster:
-  // k_resolve drains them (front of the queue regions).  Pixels inside mesh-object screen boxes (far end of the regions)
-  // are k_resolve_obj's, after either raster.
-  if (!R.no_msaa) {
-    // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
-    const dim3 rgrid((unsigned)std::min<size_t>(grid.x, 256 * 6));
-    if (!quad) hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s, R, cams, R.queue, R.qcount);
-    if (obj && use_clu) {
-      const size_t n_blk = dt_raster_tiles(R.W, R.H) * 4;
-      const size_t lds5 = lds + (size_t)CLU_TRI_CAP * sizeof(TriCov) + (n_blk + 1) * sizeof(uint2) + (size_t)(RB / 64) * (RO_SCR_BYTES + CLU_TRI_CAP * 2);
-      hipLaunchKernelGGL(k_resolve_clu, dim3(256 * 3), dim3(RB), lds5, s, R, cams, R.queue, pos);
-    } else if (obj) {
-      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
-      hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s, R, cams, R.queue, 1, pos ? envq : (const EnvQ*)nullptr);
-    }
   }
+  // Render parts (DTSIM_RENDER_PARTS = P > 1): the chunks of the batch in P ranges; the raster of range p + 1 on the
+  // caller's stream runs beside the exact-path kernels of range p on a second stream (they wait on memory, the raster on
+  // the vector ALU and the L1).  Every per-position array is addressed relative to the range's first chunk, so the
+  // kernels are the same; only the paths whose positions are chunk-separable are split: k_raster_v3 in the sorted render
+  // order (env-indexed arrays stay whole) and k_raster_v3dr (position = env: every per-env array moves).
+  int parts = 1;
+  if (ov && ov->parts > 1 && !R.no_msaa && !use_clu && ((v3 && pos) || v3dr) && (obj || !quad)) parts = std::min(std::min(ov->parts, DT_MAX_RENDER_PARTS), n_chunks / 8);
+  if (parts <= 1) { launch_raster_resolve(s, s, nullptr, R, cams, fasts, envq, envv, envd, R.frames, quad, v3, v3dr, obj, use_clu, pos != nullptr, pos); return tables; }
+  static const bool parts_serial = [] { const char* v = getenv("DTSIM_RENDER_PARTS_SERIAL"); return v && v[0] == '1'; }();   // experiment: the split without the overlap
+  const size_t n_tiles = dt_raster_tiles(R.W, R.H), n_blk = n_tiles * 4, npix = (size_t)R.W * R.H;
+  (void)hipMemsetAsync(R.work, 0, 8 * parts * sizeof(int32_t), s);
+  for (int p = 0; p < parts; ++p) {
+    const int c0 = (int)((long long)n_chunks * p / parts), c1 = (int)((long long)n_chunks * (p + 1) / parts);
+    const size_t e0 = (size_t)c0 * ENVS_PER_BLOCK, wg0 = (size_t)c0 * n_tiles;
+    RenderParams Rp = R;
+    Rp.N = std::min(R.N, c1 * ENVS_PER_BLOCK) - (int)e0;
+    Rp.work = R.work + 8 * p;
+    if (R.objmask) Rp.objmask = R.objmask + e0 * n_blk;
+    Rp.queue = R.queue + wg0 * (RB / 64) * QREGION;
+    Rp.qcount = R.qcount + wg0 * (RB / 64);
+    if (R.qend) Rp.qend = R.qend + wg0 * (RB / 64) * ENVS_PER_BLOCK;
+    Rp.items = R.items + wg0 * ITEMS_PER_WG;
+    Rp.items2 = R.items2 + wg0 * ENVS_PER_BLOCK;
+    EnvCam* cams_p = cams; EnvFast* fasts_p = fasts; EnvD* envd_p = envd;
+    EnvQ* envq_p = envq + e0; EnvV* envv_p = envv ? envv + e0 : nullptr;
+    if (!quad) {                                       // position = env
+      cams_p += e0; fasts_p += e0; if (envd) envd_p += e0;
+      Rp.frames = R.frames + e0 * npix * 3;            // (k_raster_v3dr stores by the env id of its EnvD record: it gets the whole array)
+      if (R.stris) Rp.stris = R.stris + e0 * R.max_tris;
+      if (R.tribox) Rp.tribox = R.tribox + e0 * R.max_tris;
+      if (R.objbox) Rp.objbox = R.objbox + e0 * DTSIM_MAX_OBJECTS;
+    }
+    launch_raster_resolve(s, parts_serial ? s : ov->s2, ov->ev[p], Rp, cams_p, fasts_p, envq_p, envv_p, envd_p, R.frames, quad, v3, v3dr, obj, false, pos != nullptr, nullptr);
+  }
+  (void)hipEventRecord(ov->ev[DT_MAX_RENDER_PARTS], ov->s2);
+  (void)hipStreamWaitEvent(s, ov->ev[DT_MAX_RENDER_PARTS], 0);
   return tables;
 }
