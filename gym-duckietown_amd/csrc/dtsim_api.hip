@@ -272,7 +272,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
       if (e == hipSuccess) e = hipMalloc(&h->d_queue, n_wg * 4 * (64 * DT_PPT) * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
-      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + 8 * DT_MAX_RENDER_PARTS) * sizeof(int32_t));   // counts, debug counters, work-list header (of each render part)
+      if (e == hipSuccess) e = hipMalloc(&h->d_qcount, (n_wg * 4 + 8 + DT_WORK_INTS * DT_MAX_RENDER_PARTS) * sizeof(int32_t));   // counts, debug counters, work-list header (of each render part)
       if (e == hipSuccess) e = hipMalloc(&h->d_items, n_wg * (DT_ITEMS_PER_WG + DT_ENVS_PER_BLOCK) * sizeof(uint32_t));   // k_resolve's list + k_resolve_obj's (at most one per env of a workgroup)
       if (e == hipSuccess) e = hipMalloc(&h->d_qend, n_wg * 4 * DT_ENVS_PER_BLOCK * sizeof(uint16_t));
     }
@@ -909,9 +909,12 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.dump = (char*)h->d_pixtab + (size_t)R.W * R.H * 64;
   R.qmax_tiles = 0;
   for (int mi = 0; mi < h->M.n_maps; ++mi) R.qmax_tiles = std::max(R.qmax_tiles, std::max(h->map_w[mi], h->map_h[mi]) + 2 * DT_QRING);
-#ifdef DT_WAVE_SPANS
-  R.spans = (getenv("DTSIM_WAVE_SPANS") && h->d_units) ? reinterpret_cast<unsigned long long*>(h->d_units) : nullptr;
-  if (R.spans) HIPCHK(hipMemsetAsync(R.spans, 0, 2 * 2048 * 4 * 8 * 8, h->stream));
+#ifdef DT_WAVE_SPANS   // experiment: [2][2048][4][8] spans of the exact-path kernels, then [raster workgroups][4 wavefronts][4] stamps of k_raster_v3
+  static unsigned long long* d_spans = nullptr;
+  const size_t n_spans = (size_t)2 * 2048 * 4 * 8 + dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK) * 4 * 4;
+  if (getenv("DTSIM_WAVE_SPANS") && !d_spans) HIPCHK(hipMalloc(&d_spans, n_spans * 8));
+  R.spans = getenv("DTSIM_WAVE_SPANS") ? d_spans : nullptr;
+  if (R.spans) HIPCHK(hipMemsetAsync(R.spans, 0, n_spans * 8, h->stream));
 #endif
   {
     ProfScope ps(h, DTSIM_KERNEL_RENDER);
@@ -921,7 +924,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
 #ifdef DT_WAVE_SPANS
   if (R.spans) {   // the spans of the last render -> the file DTSIM_WAVE_SPANS names (tools/wave_spans.py reads it)
     HIPCHK(hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> sp(2 * 2048 * 4 * 8);
+    std::vector<unsigned long long> sp(n_spans);
     HIPCHK(hipMemcpy(sp.data(), R.spans, sp.size() * 8, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(getenv("DTSIM_WAVE_SPANS"), "wb")) { fwrite(sp.data(), 8, sp.size(), f); fclose(f); }
   }

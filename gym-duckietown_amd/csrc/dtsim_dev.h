@@ -215,7 +215,7 @@ struct RenderParams {
   int32_t* qcount;              // [workgroups][4]
   uint16_t* qend;               // [workgroups][4][DT_ENVS_PER_BLOCK] queue fill of each region after each env of the chunk (mesh-object renders)
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
-  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj ([2] = its heavy items, front of the list; [6] = the others, back), [4], [5] units of k_resolve_clu; zeroed per render (8 per render part)
+  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj ([2] = its heavy items, front of the list; [6] = the others, back), [4], [5] units of k_resolve_clu; zeroed per render (DT_WORK_INTS per render part)
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
   uint32_t* items2;             // [workgroups * DT_ENVS_PER_BLOCK] work items of k_resolve_obj: raster workgroup * DT_ITEMS_PER_WG + env group
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
@@ -255,6 +255,7 @@ struct RenderParams {
 // Render parts (round 4): with parts > 1 the exact-path kernels of one range of chunks run on s2 beside the raster of the
 // next range; ev[p] orders range p across the two streams, ev[DT_MAX_RENDER_PARTS] joins s2 back into the caller's stream.
 #define DT_MAX_RENDER_PARTS 8
+#define DT_WORK_INTS 8           // RenderParams.work: ints per render part
 struct RenderOverlap { int parts; hipStream_t s2; hipEvent_t ev[DT_MAX_RENDER_PARTS + 1]; };
 int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, int tables, const RenderOverlap* ov = nullptr);
 

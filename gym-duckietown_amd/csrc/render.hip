@@ -3251,6 +3251,7 @@ template <class K> static size_t resident_blocks(K kernel, size_t lds) {
   int per_cu = 0, n_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RB, lds) != hipSuccess || per_cu < 1) per_cu = 3;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+  if (getenv("DTSIM_DEBUG_RESIDENT")) fprintf(stderr, "[dtsim] resident_blocks: %d workgroups per CU x %d CUs (%zu B of dynamic LDS)\n", per_cu, n_cu, lds);
   return cache[{dev, lds}] = (size_t)per_cu * (size_t)n_cu;
 }
 
@@ -3358,7 +3359,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
                      v3dr ? envd : nullptr, R.W, R.H);
-  (void)hipMemsetAsync(R.work, 0, 8 * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj / k_resolve_clu (k_obj_setup appends units)
+  (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj / k_resolve_clu (k_obj_setup appends units)
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
@@ -3384,13 +3385,13 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   if (parts <= 1) { launch_raster_resolve(s, s, nullptr, R, cams, fasts, envq, envv, envd, R.frames, quad, v3, v3dr, obj, use_clu, pos != nullptr, pos); return tables; }
   static const bool parts_serial = [] { const char* v = getenv("DTSIM_RENDER_PARTS_SERIAL"); return v && v[0] == '1'; }();   // experiment: the split without the overlap
   const size_t n_tiles = dt_raster_tiles(R.W, R.H), n_blk = n_tiles * 4, npix = (size_t)R.W * R.H;
-  (void)hipMemsetAsync(R.work, 0, 8 * parts * sizeof(int32_t), s);
+  (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * parts * sizeof(int32_t), s);
   for (int p = 0; p < parts; ++p) {
     const int c0 = (int)((long long)n_chunks * p / parts), c1 = (int)((long long)n_chunks * (p + 1) / parts);
     const size_t e0 = (size_t)c0 * ENVS_PER_BLOCK, wg0 = (size_t)c0 * n_tiles;
     RenderParams Rp = R;
     Rp.N = std::min(R.N, c1 * ENVS_PER_BLOCK) - (int)e0;
-    Rp.work = R.work + 8 * p;
+    Rp.work = R.work + DT_WORK_INTS * p;
     if (R.objmask) Rp.objmask = R.objmask + e0 * n_blk;
     Rp.queue = R.queue + wg0 * (RB / 64) * QREGION;
     Rp.qcount = R.qcount + wg0 * (RB / 64);
