@@ -1215,6 +1215,17 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
     else if (hs.cls == CLS_TILE) key[s] = 2u | ((uint32_t)hs.tj << 2) | ((uint32_t)hs.ti << 14);
     else { key[s] = (uint32_t)hs.cls; n_sky += hs.cls == CLS_SKY; n_gnd += hs.cls == CLS_GROUND; }
   }
+#ifdef DT_WAVE_SPANS   // experiment: how many exact-path pixels have all four samples on one primitive (counters behind the span slots)
+  if (!OBJ && R.spans) {
+    unsigned long long* cn = R.spans + 2 * 2048 * 4 * 8 - 8;
+    const bool uni = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+    const unsigned long long all = __ballot(true), ut = __ballot(uni && (key[0] & 3u) == 2u), ug = __ballot(uni && key[0] == 1u), us = __ballot(uni && key[0] == 0u);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(all)) {
+      atomicAdd(cn + 0, (unsigned long long)__popcll(all)); atomicAdd(cn + 1, (unsigned long long)__popcll(ut));
+      atomicAdd(cn + 2, (unsigned long long)__popcll(ug)); atomicAdd(cn + 3, (unsigned long long)__popcll(us));
+    }
+  }
+#endif
   // 2. shading: once per primitive, at the pixel centre, weighted by its sample count.  Sky and the
   //    ground quad are single primitives; tiles / triangles are walked as a list of distinct keys so
   //    that a wavefront runs max-over-lanes(distinct) passes of the expensive code, not one per sample.

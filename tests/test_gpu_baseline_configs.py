@@ -208,3 +208,25 @@ def test_c5_full_size_batch_matches_oracle_directly():
             worst[f] = max(worst[f], s[f])
     print("C5 4096-env batch, %d envs against the oracle: worst" % len(picks), worst)
     sim.close()
+
+
+@pytest.mark.parametrize("cfg", ["c5", "c4"])
+def test_render_parts_give_the_same_frames(cfg, monkeypatch):
+    """DTSIM_RENDER_PARTS (read at dtsim_create): the chunks of the batch in ranges, the exact-path kernels of one range on a second stream
+    beside the raster of the next -- every per-position array addressed relative to the range.  Same frames, bit for bit, as the one-part
+    launch: 512 envs = 16 chunks = two parts of 8 (k_raster_v3<OBJ> in the sorted render order for C5, k_raster_v3dr for C4)."""
+    N = 512
+    kw = dict(c5=dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, extra=dict(map_cycle=True)),
+              c4=dict(maps="loop_pedestrians", dr=True, extra={}))[cfg]
+    out = []
+    for parts in ("1", "2"):
+        monkeypatch.setenv("DTSIM_RENDER_PARTS", parts)
+        sim = BatchedSimulator(kw["maps"], N, camera_width=W, camera_height=H, distortion=True, domain_rand=kw["dr"], seed=5, max_steps=100000,
+                               **kw["extra"])
+        acts = np.random.default_rng(9).uniform(0.2, 0.9, (4, N, 2)).astype(np.float32)
+        sim.step(acts, n_steps=4)
+        sim.render()
+        out.append(sim.frames_host().copy())
+        sim.close()
+    assert out[0].std() > 10.0
+    assert np.array_equal(out[0], out[1])

@@ -15,7 +15,11 @@ for _ in range(6):
     sim.step(rng.uniform(-1, 1, (N, 2)).astype(np.float32))
 for _ in range(3):
     sim.render()
-sp = np.fromfile(os.environ["DTSIM_WAVE_SPANS"], dtype=np.uint64).reshape(2, 2048 * 4, 8)
+raw = np.fromfile(os.environ["DTSIM_WAVE_SPANS"], dtype=np.uint64)
+cn = raw[2 * 2048 * 4 * 8 - 8:2 * 2048 * 4 * 8].astype(np.int64)
+if cn[0]:
+    print("k_resolve pixels: %d; all four samples on one primitive: %.1f %% one tile, %.1f %% ground quad, %.1f %% sky" % (cn[0], 100.0 * cn[1] / cn[0], 100.0 * cn[2] / cn[0], 100.0 * cn[3] / cn[0]))
+sp = raw[:2 * 2048 * 4 * 8].reshape(2, 2048 * 4, 8)
 for k, name in enumerate(("k_resolve", "k_resolve_obj")):
     s = sp[k][sp[k][:, 1] > 0].astype(np.int64)
     if not len(s):
