@@ -1260,6 +1260,7 @@ size_t public_bytes(const dtsim* h, int field) {
     case DTSIM_FIELD_OBJ_PARAMS: return N * DTSIM_MAX_DYNAMIC * 3 * 8;
     case DTSIM_FIELD_OBJ_EXTRA: return N * DTSIM_MAX_DYNAMIC * 5 * 8;
     case DTSIM_FIELD_STATE_BLOB: return h->slab_bytes;
+    case DTSIM_FIELD_RENDER_POS: return N * 4;
     default: {
       FieldDesc d;
       if (!field_desc(const_cast<dtsim*>(h), field, d)) return 0;
@@ -1320,6 +1321,18 @@ int field_xfer(dtsim* h, int field, void* host, size_t bytes, bool to_host) {
       hipError_t e = to_host ? hipMemcpy(host, h->slab, need, hipMemcpyDeviceToHost)
                              : hipMemcpy(h->slab, host, need, hipMemcpyHostToDevice);
       if (e != hipSuccess) return fail(DTSIM_E_HIP, "hipMemcpy blob: %s", hipGetErrorString(e));
+      return DTSIM_OK;
+    }
+    case DTSIM_FIELD_RENDER_POS: {                    // read-only; the identity until a render pass ran in k_env_sort's order
+      if (!to_host) return fail(DTSIM_E_INVALID, "DTSIM_FIELD_RENDER_POS is read-only");
+      int32_t* out = static_cast<int32_t*>(host);
+      if (h->render_tables & 4) {
+        const int32_t* envpos = reinterpret_cast<const int32_t*>((const char*)h->d_envcam + N * (128 + 64 + 64));
+        hipError_t e = hipMemcpy(out, envpos, N * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(DTSIM_E_HIP, "hipMemcpy render order: %s", hipGetErrorString(e));
+      } else {
+        for (size_t i = 0; i < N; ++i) out[i] = (int32_t)i;
+      }
       return DTSIM_OK;
     }
     case DTSIM_FIELD_POS: bases = {A.pos_x, nullptr, A.pos_z}; return xfer_planar(h, bases.data(), 3, 8, host, to_host);

@@ -251,7 +251,8 @@ struct RenderParams {
 #define DT_LAYER_OBJ_PIX 8192   // largest object tile (up to eight passes); larger objects go through the queue
 
 // tables: bit 0 = the per-pixel tables (k_pix_setup), bit 1 = block boxes / object ranges (k_blk_setup) are valid from an
-// earlier launch (they depend on the camera LUT and the maps only); returns the bits that are valid after this launch.
+// earlier launch (they depend on the camera LUT and the maps only); returns the bits that are valid after this launch,
+// plus bit 2 when the pass ran in k_env_sort's render order (RenderParams.envpos holds it: DTSIM_FIELD_RENDER_POS).
 // Render parts (round 4): with parts > 1 the exact-path kernels of one range of chunks run on s2 beside the raster of the
 // next range; ev[p] orders range p across the two streams, ev[DT_MAX_RENDER_PARTS] joins s2 back into the caller's stream.
 #define DT_MAX_RENDER_PARTS 8

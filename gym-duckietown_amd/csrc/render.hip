@@ -3334,6 +3334,7 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
 
 int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in, int tables, const RenderOverlap* ov) {
   RenderParams R = R_in;
+  tables &= 3;                                         // bit 2 (returned): this pass ran in k_env_sort's order (DTSIM_FIELD_RENDER_POS)
   EnvCam* cams = reinterpret_cast<EnvCam*>(R.envcam);
   EnvFast* fasts = reinterpret_cast<EnvFast*>(cams + A.N);
   EnvQ* envq = reinterpret_cast<EnvQ*>(fasts + A.N);
@@ -3366,7 +3367,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   // speed and the sorted one halves the L2 fills: FETCH_SIZE 2.15 -> 1.00 GB raw per pass, profiles/r04_variants_ab.txt block I.)
   pos = nullptr;
 #endif
-  if (pos) hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos);
+  if (pos) { hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos); tables |= 4; }
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
                      v3dr ? envd : nullptr, R.W, R.H);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 8
+ABI_VERSION = 9
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 32, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
@@ -30,7 +30,7 @@ TILE_OTHER = 10
  FIELD_LANE, FIELD_IN_LANE, FIELD_PROX, FIELD_SPEED, FIELD_TIMESTAMP, FIELD_WHEELS, FIELD_MAP_ID,
  FIELD_OBJ_CENTER, FIELD_OBJ_ACTIVE, FIELD_OBJ_YROT, FIELD_OBJ_PARAMS, FIELD_OBJ_VISIBLE,
  FIELD_EPISODE, FIELD_STATE_BLOB, FIELD_OBJ_LIGHT, FIELD_OBJ_Y, FIELD_OBJ_EXTRA, FIELD_CAMERA, FIELD_COLORS,
- FIELD_WHEEL_DIST) = range(27)
+ FIELD_WHEEL_DIST, FIELD_RENDER_POS) = range(28)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
 RENDER_SEGMENT = 1

@@ -524,7 +524,7 @@ class BatchedSimulator:
         _ffi.FIELD_OBJ_VISIBLE: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_EPISODE: ("i4", ()),
         _ffi.FIELD_OBJ_LIGHT: ("u1", (_ffi.MAX_OBJECTS,)), _ffi.FIELD_OBJ_Y: ("f8", (_ffi.MAX_DYNAMIC,)),
         _ffi.FIELD_OBJ_EXTRA: ("f8", (_ffi.MAX_DYNAMIC, 5)), _ffi.FIELD_CAMERA: ("f4", (6,)), _ffi.FIELD_COLORS: ("f4", (16,)),
-        _ffi.FIELD_WHEEL_DIST: ("f8", ()),
+        _ffi.FIELD_WHEEL_DIST: ("f8", ()), _ffi.FIELD_RENDER_POS: ("i4", ()),
     }
 
     def read(self, field: int) -> np.ndarray:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 8
+#define DTSIM_ABI_VERSION 9
 
 /* error codes */
 #define DTSIM_OK 0
@@ -240,7 +240,10 @@ enum {
   DTSIM_FIELD_CAMERA = 24,    /* float  [N][6]  cam_height, cam_angle[0] (rad), cam_fov_y (rad), camera_noise xyz (simulator.py:596-614) */
   DTSIM_FIELD_COLORS = 25,    /* float  [N][16] horizon rgb, ground rgb, light ambient rgb, diffuse rgb, light_pos xyzw (:551-594) */
   DTSIM_FIELD_WHEEL_DIST = 26,/* double [N]     wheel_dist (:597) */
-  DTSIM_FIELD__COUNT = 27
+  DTSIM_FIELD_RENDER_POS = 27,/* int32  [N]     read-only: position of each env in the render order of the last dtsim_render (k_env_sort:
+                               * envs standing on the same tile and facing the same way are neighbours; 32 consecutive positions share a
+                               * raster workgroup, XCD x owns the x-th eighth of the order); the identity when the pass ran in index order */
+  DTSIM_FIELD__COUNT = 28
 };
 
 /* kernels for dtsim_profile_read */

@@ -29,17 +29,24 @@ W, H = 640, 480
 OBJ_TOL = dict(frac_gt1=2e-3, frac_gt2=1e-3, mean=0.03)     # scenes with mesh objects
 
 
-def _stratified_picks(N, n_min, seed):
-    """Env indices of an N-env batch that exercise the raster's work decomposition: envs are rendered in index order, 32 per
-    workgroup chunk, XCD x owning the x-th eighth of the chunks (render_v3.inc: XCD-affine workgroup map)."""
-    picks = [0, 1, 31, 32, 33, 63, 64, N - 1, N - 2, N - 32, N - 33]
-    for x in range(8):                                     # the middle of every XCD's eighth, both sides of a chunk border there
+def _stratified_picks(sim, N, n_min, seed):
+    """Env indices of an N-env batch that exercise the raster's work decomposition.  The decomposition goes by POSITION in the
+    render order of the pass that just ran (DTSIM_FIELD_RENDER_POS: k_env_sort's order on the quad-record paths, the identity
+    elsewhere): 32 consecutive positions share a workgroup chunk, XCD x owns the x-th eighth of the chunks (render_v3.inc:
+    XCD-affine workgroup map).  Picked positions: the first / last of the order, both sides of chunk borders, the middle of
+    every XCD's eighth (a chunk border there), the tail chunk -- mapped back to env indices -- plus envs 0 and N - 1."""
+    pos = sim.read(_ffi.FIELD_RENDER_POS)
+    assert sorted(pos.tolist()) == list(range(N))          # a permutation of the batch
+    env_at = np.argsort(pos, kind="stable")                # position -> env
+    at = [0, 1, 31, 32, 33, 63, 64, N - 1, N - 2, N - 32, N - 33]
+    for x in range(8):
         m = x * (N // 8) + N // 16
-        picks += [m - 1, m]
+        at += [m - 1, m]
+    picks = [int(env_at[p]) for p in at if 0 <= p < N] + [0, N - 1]
     rng = np.random.default_rng(seed)
     while len(set(picks)) < n_min:
         picks.append(int(rng.integers(N)))
-    return sorted(set(int(p) for p in picks if 0 <= p < N))
+    return sorted(set(picks))
 
 
 def _frames_of(sim, picks):
@@ -63,13 +70,16 @@ def test_c3_full_size_batch_matches_oracle_directly():
     ti, tj = np.clip(np.floor(cx / ts), 0, 31).astype(int), np.clip(np.floor(cz / ts), 0, 31).astype(int)
     quad = np.floor(ang * (2.0 / np.pi) + 0.5).astype(int) & 3
     key = (((tj << 5) | ti) << 2) | quad
-    order = np.argsort(key, kind="stable")
     picks = []
     for k in np.unique(key):                               # one env per bin: first, last and every slice of the order
         picks.append(int(np.nonzero(key == k)[0][0]))
     rng = np.random.default_rng(1)
-    picks += [int(order[0]), int(order[-1]), 0, N - 1, 31, 32]
-    picks += [int(order[i]) for i in range(N // 16, N, N // 8)]    # the middle of each XCD's eighth of the order
+    rpos = sim.read(_ffi.FIELD_RENDER_POS)                 # the order the pass actually ran in: bins as recomputed above, ties broken on the device
+    assert sorted(rpos.tolist()) == list(range(N))
+    env_at = np.argsort(rpos)
+    assert (np.diff(key[env_at]) >= 0).mean() > 0.98       # sorted by the key (the device bins in float32: an env on a bin border may move)
+    picks += [int(env_at[0]), int(env_at[-1]), 0, N - 1, int(env_at[31]), int(env_at[32])]
+    picks += [int(env_at[i]) for i in range(N // 16, N, N // 8)]    # the middle of each XCD's eighth of the order
     while len(set(picks)) < 64:
         picks.append(int(rng.integers(N)))
     picks = sorted(set(picks))
@@ -156,7 +166,7 @@ def test_c4_full_size_batch_matches_oracle_directly():
     assert sim.read(_ffi.FIELD_OBJ_ACTIVE).any()
     sim.render()
     sim.sync()
-    picks = _stratified_picks(N, 32, 2)
+    picks = _stratified_picks(sim, N, 32, 2)
     assert len(picks) >= 32
     sub = _frames_of(sim, picks)
     scene = _scene("loop_pedestrians")
@@ -193,7 +203,7 @@ def test_c5_full_size_batch_matches_oracle_directly():
     sim.sync()
     mid = sim.read(_ffi.FIELD_MAP_ID)
     assert set(np.unique(mid)) == {0, 1}
-    picks = _stratified_picks(N, 16, 3)
+    picks = _stratified_picks(sim, N, 16, 3)
     assert len(picks) >= 16 and {int(mid[e]) for e in picks} == {0, 1}
     sub = _frames_of(sim, picks)
     scenes = [_scene(n) for n in names]
