@@ -244,8 +244,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            args.no_gather = True
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # (the exchange legs then stage through pinned host memory)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -441,22 +440,30 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         frames = torch.as_tensor(sim.frames_device(), device=dev)
+        rccl = dist.get_backend() == "nccl"
+        rdev = dev if rccl else "cpu"                   # where the control-plane scalars of this leg live
+        from dtsim.sharding import ShardedSimulator, gather_batch
         try:
-            out = torch.empty((world,) + tuple(frames.shape), dtype=torch.uint8, device=dev)
+            # the all-gather of the frame batch through the product API: on RCCL the library's own collective
+            # (dtsim_allgather_frames, enqueued on the simulator's stream behind the render pass); on gloo (DTSIM_BENCH_ONE_GPU)
+            # staged through host memory
+            ssa = ShardedSimulator.wrap(sim, world * N, rank, world)
             ks = min(K, 3)
             sync_all()
             tg = time.perf_counter()
             for t in range(ks):
                 one_step(Wm + t)
-                sim.sync()
-                dist.all_gather_into_tensor(out, frames)
+                out = ssa.gather_frames()
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
-            tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+            tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
             dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
             gather = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "steps": ks,
-                      "collective": "all_gather_into_tensor(uint8 frames)", "bytes_per_rank_per_step": int(frames.numel())}
-            del out
+                      "collective": ("ShardedSimulator.gather_frames(): dtsim_allgather_frames (ncclAllGather of the uint8 frames on the simulator's stream)"
+                                     if rccl else "ShardedSimulator.gather_frames(): gloo all_gather of the uint8 frames through host memory"),
+                      "bytes_per_rank_per_step": int(frames.numel()), "transport": "rccl" if rccl else "gloo (host staged)",
+                      "checksum_ok": bool(int(out[rank * N:(rank + 1) * N].to(torch.int64).sum().item()) == int(frames.to(torch.int64).sum().item()))}
+            del out, ssa
             # what a learner on rank 0 needs: gather-to-root instead of all-gather, double-buffered so
             # that the exchange of step t overlaps the simulation of step t+1 (the sim runs on its own HIP stream;
             # only the buffer about to be overwritten is waited for)
@@ -472,11 +479,11 @@ def main():
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
                 sim.bind_frames(None)
-                tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+                tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
                 dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
                 gather["to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
                                                 "collective": "ShardedSimulator.step_render_gather(overlap=True): gather(uint8 frames, dst=0), "
-                                                              "two buffers rotating through dtsim_bind_frames, the exchange of step t behind step t+1"}
+                                                              "three buffers rotating through dtsim_bind_frames, the exchange of step t behind step t+1, stream-ordered by events"}
                 del ss
             except Exception as ex:
                 sim.bind_frames(None)
@@ -484,17 +491,20 @@ def main():
             # the same exchange on what learners consume: 160x120 observations made on the device
             # (dtsim_observe, PIL-exact bilinear): 16x fewer bytes over xGMI
             obs = torch.as_tensor(sim.observe(120, 160), device=dev)
-            out = torch.empty((world,) + tuple(obs.shape), dtype=torch.uint8, device=dev)
+            out = torch.empty((world,) + tuple(obs.shape), dtype=torch.uint8, device=dev) if rccl else None
             sync_all()
             tg = time.perf_counter()
             for t in range(ks):
                 one_step(Wm + t)
                 sim.observe(120, 160)
                 sim.sync()
-                dist.all_gather_into_tensor(out, obs)
+                if rccl:
+                    dist.all_gather_into_tensor(out, obs)
+                else:
+                    out = gather_batch(obs.cpu(), world)
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
-            tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+            tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
             dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
             gather["observations"] = {"value": world * N * ks / float(tgt.item()), "unit": "env-steps/s", "shape": [120, 160, 3],
                                       "collective": "all_gather_into_tensor(uint8 160x120 observations from dtsim_observe)",
@@ -512,7 +522,7 @@ def main():
                 ss.flush_gather(dst=0)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
-                tgt = torch.tensor([tg], device=dev, dtype=torch.float64)
+                tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
                 dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
                 gather["observations_to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
                                                              "collective": "ShardedSimulator.step_render_gather(what='observe', obs=(120, 160), overlap=True, dst=0)"}

@@ -44,10 +44,9 @@ def gather_batch(local, world: int, group=None, dst: Optional[int] = None):
             parts = list(out.chunk(world, dim=0))
             dist.all_gather(parts, local.contiguous(), group=group)
         return out
-    rank = dist.get_rank(group)
     parts = None
     out = None
-    if rank == dst:
+    if dist.get_rank() == dst:                           # dst is a GLOBAL rank (torch.distributed.gather)
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         parts = list(out.chunk(world, dim=0))
     dist.gather(local.contiguous(), parts, dst=dst, group=group)
@@ -97,30 +96,134 @@ class ShardedSimulator:
         return frames
 
     def gather_frames(self, dst: Optional[int] = None, group=None):
+        """The frame batches of every rank: [world*n, H, W, 3] on every rank (dst None) or on `dst` only.
+        On RCCL the all-gather is the library's own (`dtsim_allgather_frames`, include/dtsim.h): enqueued on the simulator's stream
+        right behind the render pass, no host synchronisation in between; torch's current stream is ordered behind it by an event.
+        Elsewhere (gloo; gather-to-root) it goes through torch.distributed."""
+        import torch
+        import torch.distributed as dist
+        if dst is None and self._rccl_ready(group):
+            n = self.hi - self.lo
+            out = torch.empty((self.world * n, self.sim.camera_height, self.sim.camera_width, 3), dtype=torch.uint8,
+                              device=f"cuda:{self.sim.device_index}")
+            self._lib_wait_torch(out.device)            # `out` is ready on torch's stream: order the library's stream behind it
+            self.sim.allgather_frames(self._rccl_comm(group), out)
+            self._torch_wait_lib(out.device)
+            return out
+        if self.world > 1 and dist.get_backend(group) == "gloo" and not hasattr(self.sim, "frames_tensor"):
+            return gather_batch(self.local_frames().cpu(), self.world, group, dst)    # gloo moves host memory
         return gather_batch(self.local_frames(), self.world, group, dst)
+
+    # ---- RCCL through the C-ABI (dtsim_allgather_frames) ---------------------------------------------------------
+    def _rccl_ready(self, group) -> bool:
+        import torch.distributed as dist
+        if hasattr(self.sim, "frames_tensor") or not hasattr(self.sim, "allgather_frames"):
+            return False                                 # stand-in simulators of the CPU tests
+        if self.world == 1:
+            return bool(getattr(self, "force_collective", False))
+        return dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def _rccl_comm(self, group) -> int:
+        """An ncclComm_t over the ranks of `group` for the library's all-gather, made once per group: rank 0 of the group draws the
+        unique id (librccl through ctypes), torch.distributed carries it to the others, every rank joins with ITS group rank."""
+        import ctypes as C
+        import torch.distributed as dist
+        comms = self.__dict__.setdefault("_comms", {})
+        if group in comms:
+            return comms[group][0]
+        import torch
+        rccl = C.CDLL(_find_rccl())
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        uid = UniqueId()
+        grank = dist.get_rank(group) if self.world > 1 else 0
+        if grank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if self.world > 1:
+            box = [C.string_at(C.byref(uid), 128)]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        torch.cuda.set_device(self.sim.device_index)
+        if rccl.ncclCommInitRank(C.byref(comm), self.world, uid, grank) != 0:
+            raise RuntimeError("ncclCommInitRank failed")
+        comms[group] = (comm.value, rccl)
+        return comm.value
+
+    def _lib_stream(self, device):
+        """The simulator's HIP stream as a torch stream (dtsim_stream), or None (stand-ins, old torch)."""
+        import torch
+        if not hasattr(self.sim, "stream") or not getattr(device, "type", None) == "cuda":
+            return None
+        ls = self.__dict__.get("_ls")
+        if ls is None:
+            try:
+                ls = self._ls = torch.cuda.ExternalStream(self.sim.stream(), device=device)
+            except Exception:
+                ls = self._ls = False
+        return ls or None
+
+    def _torch_wait_lib(self, device):
+        """Order torch's current stream behind everything enqueued on the simulator's stream so far (no host wait)."""
+        import torch
+        ls = self._lib_stream(device)
+        if ls is None:
+            if hasattr(self.sim, "sync"):
+                self.sim.sync()
+            return
+        ev = torch.cuda.Event()
+        ev.record(ls)
+        torch.cuda.current_stream(device).wait_event(ev)
+
+    def _lib_wait_torch(self, device):
+        """Order the simulator's stream behind torch's current stream (where Work.wait() put the end of a transfer)."""
+        import torch
+        ls = self._lib_stream(device)
+        if ls is None:
+            if getattr(device, "type", None) == "cuda":
+                torch.cuda.current_stream(device).synchronize()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ls.wait_event(ev)
 
     # ---- the learner's exchange, overlapped with the simulation (SURVEY 8e) ---------------------------------------
     # Layout (round 4): per buffer slot ONE preallocated [world*n, ...] tensor on the root; the root's own envs are rendered
     # (or observed) straight into its slice of it, every other rank's batch is received into ITS slice (point-to-point,
     # one transfer per xGMI link into the root) -- no torch.cat, no self-copy, and what the learner gets IS that tensor.
-    def _produce(self, buf, what: str, obs):
-        """This rank's payload of the current step into `buf` (device memory), complete on return (host-level wait on the
-        library's stream: the exchange that reads `buf` is enqueued on another stream).  what = "frames": the render pass
-        writes there directly (dtsim_bind_frames); "observe": render into the library's buffer, dtsim_observe into `buf`."""
+    # Round 5: THREE slots rotate (a batch handed out survives the next call: a learner may keep obs_t next to obs_t+1), and
+    # the ordering between the simulator's stream and the exchange is by EVENTS, not host waits: the simulator can run ahead of
+    # the host while a transfer is in flight.  On gloo (no device transport) the payload is staged through pinned host memory.
+    N_SLOTS = 3
+
+    def _produce(self, slot, what: str, obs):
+        """This rank's payload of the current step into the slot's send buffer.  Device path: enqueued on the simulator's stream;
+        torch's current stream (from which the exchange is issued) is ordered behind it by an event.  what = "frames": the render
+        pass writes there directly (dtsim_bind_frames); "observe": render into the library's buffer, dtsim_observe into the slot."""
+        buf = slot["dev"]
         if what == "frames":
             if hasattr(self.sim, "render_into"):         # stand-in simulators of the CPU tests
                 self.sim.render_into(buf)
                 return
             self.sim.bind_frames(buf.data_ptr())
             self.sim.render()
-            self.sim.sync()
-            return
-        if hasattr(self.sim, "observe_into"):            # stand-in simulators of the CPU tests
+        elif hasattr(self.sim, "observe_into"):          # stand-in simulators of the CPU tests
             self.sim.observe_into(buf, *obs[:2])
             return
-        self.sim.render()
-        self.sim.observe(obs[0], obs[1], out=buf, **(obs[2] if len(obs) > 2 else {}))
-        self.sim.sync()
+        else:
+            self.sim.render()
+            self.sim.observe(obs[0], obs[1], out=buf, **(obs[2] if len(obs) > 2 else {}))
+        if slot["staged"]:                               # gloo: device -> pinned host memory, then the host exchanges it
+            self._torch_wait_lib(buf.device)
+            slot["send"].copy_(buf, non_blocking=True)
+            import torch
+            torch.cuda.current_stream(buf.device).synchronize()
+        else:
+            self._torch_wait_lib(buf.device)
 
     def _payload_shape(self, what: str, obs):
         n = self.hi - self.lo
@@ -136,24 +239,36 @@ class ShardedSimulator:
         return shape, (torch.float32 if kw.get("normalize") else torch.uint8), dev
 
     def _exchange_state(self, what: str, obs, dst: int, group):
+        """Buffers of the overlapped exchange, made once per (payload, root, group).  `dst` is a GLOBAL rank (as in
+        torch.distributed.gather); slices of the root's tensor are in GROUP-rank order."""
         import torch
         import torch.distributed as dist
-        key = (what, tuple(obs[:2]) if obs else None, dst)
+        okw = tuple(sorted((obs[2] if obs and len(obs) > 2 else {}).items()))
+        key = (what, tuple(obs[:2]) if obs else None, okw, dst, group)
         gx = getattr(self, "_gx", None)
         if gx is not None and gx["key"] == key:
             return gx
+        if gx is not None:                               # another payload / root / group: let the old transfers finish first
+            for sl in gx["slots"]:
+                self._wait(sl, reuse=True)
         shape, dtype, dev = self._payload_shape(what, obs)
-        rank = dist.get_rank(group) if self.world > 1 else 0
+        multi = self.world > 1
+        grank = dist.get_rank(group) if multi else 0     # position of this rank's slice
+        is_root = (dist.get_rank() if multi else 0) == dst
+        peers = [dist.get_global_rank(group, r) if (multi and group is not None) else r for r in range(self.world)]
+        staged = bool(multi and dev.type == "cuda" and dist.get_backend(group) == "gloo")
+        xdev = torch.device("cpu") if staged else dev
         n = shape[0]
         slots = []
-        for _ in range(2):
-            if rank == dst:
-                recv = torch.empty((self.world * n,) + tuple(shape[1:]), dtype=dtype, device=dev)
-                send = recv[rank * n:(rank + 1) * n]       # the root produces in place
+        for _ in range(self.N_SLOTS):
+            if is_root:
+                recv = torch.empty((self.world * n,) + tuple(shape[1:]), dtype=dtype, device=xdev, pin_memory=staged)
+                send = recv[grank * n:(grank + 1) * n]     # the root produces in place
             else:
-                recv, send = None, torch.empty(shape, dtype=dtype, device=dev)
-            slots.append({"recv": recv, "send": send, "works": None})
-        gx = self._gx = {"key": key, "slots": slots, "t": 0, "rank": rank, "n": n, "what": what}
+                recv, send = None, torch.empty(shape, dtype=dtype, device=xdev, pin_memory=staged)
+            devbuf = torch.empty(shape, dtype=dtype, device=dev) if staged else send
+            slots.append({"recv": recv, "send": send, "dev": devbuf, "staged": staged, "works": None})
+        gx = self._gx = {"key": key, "slots": slots, "t": 0, "grank": grank, "is_root": is_root, "peers": peers, "n": n, "what": what}
         return gx
 
     def _start_exchange(self, slot, gx, dst: int, group):
@@ -163,19 +278,18 @@ class ShardedSimulator:
         if self.world == 1:
             slot["works"] = []
             return
-        n, rank = gx["n"], gx["rank"]
-        if rank == dst:
-            ops = [dist.P2POp(dist.irecv, slot["recv"][r * n:(r + 1) * n], r, group) for r in range(self.world) if r != dst]
+        n = gx["n"]
+        if gx["is_root"]:
+            ops = [dist.P2POp(dist.irecv, slot["recv"][r * n:(r + 1) * n], peer, group)
+                   for r, peer in enumerate(gx["peers"]) if peer != dst]
         else:
             ops = [dist.P2POp(dist.isend, slot["send"], dst, group)]
         slot["works"] = list(dist.batch_isend_irecv(ops))
-        slot["waited"] = False
 
-    @staticmethod
-    def _wait(slot, host: bool):
-        """Wait for the exchange that uses `slot`.  On RCCL a Work.wait() only orders torch's CURRENT STREAM behind the
-        transfer; the library renders on its own stream, so before a buffer is produced into again the HOST waits
-        (host=True) -- stream-level ordering is enough for handing the tensor to torch consumers (host=False)."""
+    def _wait(self, slot, reuse: bool):
+        """Wait for the exchange that uses `slot`.  Work.wait() orders torch's CURRENT STREAM behind the transfer on RCCL (and blocks
+        the host on gloo): enough for handing the tensor to torch consumers (reuse=False).  Before the slot is produced into again
+        (reuse=True) the SIMULATOR's stream, which is not torch's, is ordered behind that point by an event."""
         works = slot["works"]
         if works is None:
             return
@@ -183,26 +297,28 @@ class ShardedSimulator:
             for w in works:
                 w.wait()
             slot["waited"] = True
-        if host:
-            t = slot["send"]
-            if t.is_cuda:
-                import torch
-                torch.cuda.current_stream(t.device).synchronize()
+        if reuse:
+            t = slot["dev"]
+            if t.is_cuda and not slot["staged"]:
+                self._lib_wait_torch(t.device)
             slot["works"] = None                         # only now: nothing reads or writes the slot's buffers any more
 
     def step_render_gather(self, global_actions, n_steps: int = 1, *, overlap: bool = True, dst: int = 0, group=None,
-                           local_actions: bool = False, what: str = "frames", obs=None):
-        """One learner iteration: step this rank's envs, render them, and gather the batch to rank `dst`.
+                           local_actions: bool = False, what: str = "frames", obs=None, copy: bool = False):
+        """One learner iteration: step this rank's envs, render them, and gather the batch to (global) rank `dst`.
 
         what="frames": the [n, H, W, 3] uint8 frame batch (3.77 GB per rank at the BASELINE size: xGMI-link bound, DESIGN.md 6);
         what="observe", obs=(h, w[, observe() keywords]): the dtsim_observe output of the step instead (57.6 KB per env at
         160 x 120: the exchange the north star's learner can actually keep up with).
         overlap=False: blocking; returns (t, batch) -- batch = [world*n, ...] of THIS step on `dst`, None elsewhere.
-        overlap=True: the gather of step t runs while step t+1 is simulated and rendered.  Two buffer slots
-        rotate; the call returns the batch of step t-1 (the learner runs one step behind the simulator; `flush_gather()`
-        hands out the last one).  The tensor returned on `dst` is the slot's preallocated receive tensor itself (no copy):
-        it stays valid until the next-but-one call.  A slot is produced into again only after the HOST has seen the end of the
-        transfer that read it.  Returns (t-1, batch) or (None, None) on the first call."""
+        overlap=True: the gather of step t runs while step t+1 is simulated and rendered; the call returns the batch
+        of step t-1 (the learner runs one step behind the simulator; `flush_gather()` hands out the last one), or (None, None) on
+        the first call.
+        Lifetime of the returned tensor: it is one of THREE rotating slots' preallocated receive tensor itself (no copy).  It stays
+        valid through the NEXT call and is overwritten by the one after: a learner can hold obs_t while it receives obs_t+1, no
+        longer -- pass copy=True (or clone it) for a replay buffer.  A slot is produced into again only after the simulator's stream
+        has been ordered behind the end of the transfer that read it; consumers must run on torch's current stream (or synchronise
+        with it) -- the ordering of a handed-out batch is stream-level, not host-level."""
         if what not in ("frames", "observe") or (what == "observe" and not obs):
             raise ValueError("what = 'frames' or 'observe' (with obs=(height, width[, keywords]))")
         if local_actions:                                # already this rank's slice (e.g. a device tensor)
@@ -210,36 +326,53 @@ class ShardedSimulator:
         else:
             self.step(global_actions, n_steps)
         gx = self._exchange_state(what, obs, dst, group)
-        if not overlap:
-            t = getattr(self, "_gather_t", 0)
-            self._gather_t = t + 1
-            slot = gx["slots"][0]
-            self._wait(slot, host=True)
-            self._produce(slot["send"], what, obs)
-            self._start_exchange(slot, gx, dst, group)
-            self._wait(slot, host=True)
-            return t, slot["recv"]
-        t, b = gx["t"], gx["t"] % 2
-        slot = gx["slots"][b]
-        self._wait(slot, host=True)                      # the transfer of step t-2 read / wrote this slot
-        self._produce(slot["send"], what, obs)
+        S = self.N_SLOTS
+        t = gx["t"]
+        slot = gx["slots"][t % S]
+        self._wait(slot, reuse=True)                     # the transfer of step t-3 read / wrote this slot
+        self._produce(slot, what, obs)
         self._start_exchange(slot, gx, dst, group)
         gx["t"] = t + 1
+        if not overlap:
+            self._wait(slot, reuse=False)
+            out = slot["recv"]
+            return t, (out.clone() if (copy and out is not None) else out)
         if t == 0:
             return None, None
-        prev = gx["slots"][1 - b]
-        self._wait(prev, host=False)
-        return t - 1, prev["recv"]
+        prev = gx["slots"][(t - 1) % S]
+        self._wait(prev, reuse=False)
+        out = prev["recv"]
+        return t - 1, (out.clone() if (copy and out is not None) else out)
 
     def flush_gather(self, dst: int = 0):
-        """Batch of the last step issued by step_render_gather(overlap=True): (t, batch on `dst` / None)."""
+        """Batch of the last step issued by step_render_gather: (t, batch on `dst` / None); every transfer has ended on return."""
         gx = getattr(self, "_gx", None)
         if gx is None or gx["t"] == 0:
             return None, None
         t = gx["t"] - 1
-        slot = gx["slots"][t % 2]
-        self._wait(slot, host=True)
-        self._wait(gx["slots"][1 - t % 2], host=True)
+        last = gx["slots"][t % self.N_SLOTS]
+        self._wait(last, reuse=False)
+        for sl in gx["slots"]:
+            self._wait(sl, reuse=True)
+        dev = last["dev"].device
+        if getattr(dev, "type", None) == "cuda":
+            import torch
+            torch.cuda.current_stream(dev).synchronize()
         if gx["what"] == "frames" and hasattr(self.sim, "bind_frames"):
+            if hasattr(self.sim, "sync"):
+                self.sim.sync()
             self.sim.bind_frames(None)                   # back to the library's own buffer
-        return t, slot["recv"]
+        return t, last["recv"]
+
+
+def _find_rccl() -> str:
+    """librccl as torch loaded it (so that one RCCL serves both), else the system's."""
+    import os
+    try:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    except Exception:
+        pass
+    return "librccl.so.1"

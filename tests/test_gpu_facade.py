@@ -397,11 +397,13 @@ def test_allgather_frames_through_the_c_abi_one_rank():
     sim.step(np.full((N, 2), 0.4, np.float32))
     sim.render()
     recv = torch.zeros((1, N, 120, 160, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()                             # `recv` must be ready before the library's stream writes it (dtsim.h)
     sim.allgather_frames(comm.value, recv)
     sim.sync()
     assert np.array_equal(recv[0].cpu().numpy(), sim.frames_host())
     obs = sim.observe(60, 80)
     recv2 = torch.zeros((1, N, 60, 80, 3), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
     sim.allgather_frames(comm.value, recv2, send=obs)
     sim.sync()
     assert np.array_equal(recv2[0].cpu().numpy(), torch.as_tensor(obs, device="cuda:0").cpu().numpy())
@@ -425,7 +427,9 @@ def test_sharded_exchange_on_the_device_one_rank():
     for t in range(T):
         ref.step(acts[t]); ref.render()
         want_f.append(ref.frames_host().copy())
-        want_o.append(torch.as_tensor(ref.observe(60, 80), device="cuda:0").cpu().numpy().copy())
+        o = ref.observe(60, 80)
+        ref.sync()                                        # dtsim_observe runs on the library's stream, the copy below on torch's
+        want_o.append(torch.as_tensor(o, device="cuda:0").cpu().numpy().copy())
     ref.close()
     for what, want, obs in (("frames", want_f, None), ("observe", want_o, (60, 80))):
         ss = ShardedSimulator.wrap(BatchedSimulator("small_loop", N, **kw), N, 0, 1)
@@ -446,3 +450,110 @@ def test_sharded_exchange_on_the_device_one_rank():
         k, batch = ss.step_render_gather(acts[0], overlap=False, dst=0, local_actions=True, what=what, obs=obs)
         assert batch is not None and batch.shape[0] == N
         ss.sim.close()
+
+
+def test_sharded_gather_frames_uses_the_library_allgather_one_rank():
+    """ShardedSimulator.gather_frames() on RCCL goes through dtsim_allgather_frames (one exchange implementation on the all-gather
+    path): enqueued on the simulator's stream behind the render pass, torch's stream ordered behind it by an event, no host wait.
+    Exercised here with a 1-rank communicator (force_collective; the N > 1 call is the same one with more ranks -- unmeasured on
+    hardware): the gathered batch is the frame batch, byte for byte, and a held batch survives the next render + gather."""
+    import torch
+    from dtsim import BatchedSimulator
+    from dtsim.sharding import ShardedSimulator
+    N = 6
+    sim = BatchedSimulator("small_loop", N, camera_width=160, camera_height=120, distortion=True, domain_rand=False, seed=3)
+    ss = ShardedSimulator.wrap(sim, N, 0, 1)
+    ss.force_collective = True
+    try:
+        ss._rccl_comm(None)
+    except OSError:
+        pytest.skip("librccl not present")
+    acts = np.random.default_rng(5).uniform(0.2, 0.8, (3, N, 2)).astype(np.float32)
+    kept = []
+    for t in range(3):
+        sim.step(acts[t]); sim.render()
+        out = ss.gather_frames()                          # no sim.sync() in between: the ordering is the streams'
+        assert tuple(out.shape) == (N, 120, 160, 3)
+        kept.append((out, None))
+        host = out.cpu().numpy()                          # torch's stream: behind the library's all-gather by the event
+        assert np.array_equal(host, sim.frames_host()), t
+        kept[-1] = (out, host)
+    for out, host in kept:                                # every batch is its own tensor
+        assert np.array_equal(out.cpu().numpy(), host)
+    sim.close()
+
+
+def _two_rank_worker(rank, world, port, n, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    try:
+        from dtsim import BatchedSimulator
+        from dtsim.sharding import ShardedSimulator
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        total, W, H, T = world * n, 160, 120, 5
+        kw = dict(camera_width=W, camera_height=H, distortion=True, domain_rand=False)
+        ss = ShardedSimulator("small_loop", total, seed=40, device=0, rank=rank, world=world, **kw)
+        acts = np.random.default_rng(2).uniform(0.2, 0.8, (T, total, 2)).astype(np.float32)
+        got = {}
+        for what, obs in (("frames", None), ("observe", (60, 80))):
+            held = None
+            for t in range(T):
+                k, batch = ss.step_render_gather(acts[t:t + 1], overlap=True, dst=0, what=what, obs=obs)
+                if rank == 0 and held is not None:
+                    assert np.array_equal(held[1].numpy() if not held[1].is_cuda else held[1].cpu().numpy(), got[(what, held[0])])   # still intact one call later
+                if batch is not None:
+                    got[(what, k)] = batch.cpu().numpy().copy()
+                    held = (k, batch)
+            k, batch = ss.flush_gather(dst=0)
+            if rank == 0:
+                got[(what, k)] = batch.cpu().numpy().copy()
+            ss.sim.render()                               # (the loop rendered into the slots: the same state into the library's own buffer)
+            allf = ss.gather_frames()                     # all-gather on gloo: host tensors
+            if rank == 0:
+                got[(what, "all")] = allf.cpu().numpy().copy()
+        if rank == 0:
+            np.savez(q, **{f"{a}_{b}": v for (a, b), v in got.items()})
+        ss.sim.close()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_exchange_the_real_batches(tmp_path):
+    """world_size 2 on ONE GPU (gloo moves the payload through pinned host memory: the staged path of dtsim/sharding.py): both ranks run
+    the real simulator on their half of the envs and the overlapped gather-to-root; what rank 0 receives for step t equals what ONE
+    simulator with all the envs renders / observes at step t -- env ranges, per-env seeds, action slices, slot rotation and the bytes.
+    (The RCCL transport itself needs two GPUs: unmeasured on hardware.)"""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from dtsim import BatchedSimulator
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world, n = 2, 5
+    out = str(tmp_path / "root.npz")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = np.load(out)
+    total, T = world * n, 5
+    ref = BatchedSimulator("small_loop", total, camera_width=160, camera_height=120, distortion=True, domain_rand=False, seed=40)
+    acts = np.random.default_rng(2).uniform(0.2, 0.8, (T, total, 2)).astype(np.float32)
+    for what in ("frames", "observe"):
+        for t in range(T):
+            ref.step(acts[t]); ref.render()
+            if what == "frames":
+                want = ref.frames_host()
+            else:
+                o = ref.observe(60, 80)
+                ref.sync()                                # dtsim_observe runs on the library's stream, the copy below on torch's
+                want = torch.as_tensor(o, device="cuda:0").cpu().numpy()
+            assert np.array_equal(got[f"{what}_{t}"], want), (what, t)
+        assert np.array_equal(got[f"{what}_all"], ref.frames_host()), what
+    ref.close()

@@ -107,7 +107,7 @@ def _worker(rank, world, port, total, q):
         ok = ok and bool(torch.equal(allf2, _fake_frames(0, total)))
         rootf = ss.gather_frames(dst=0)
         ok = ok and ((rank == 0 and bool(torch.equal(rootf, _fake_frames(0, total)))) or (rank != 0 and rootf is None))
-        # the learner's loop: gather-to-root of step t overlapped with step t+1, two rotating buffers.
+        # the learner's loop: gather-to-root of step t overlapped with step t+1, three rotating buffers.
         # Every frame delivered must be the frame of ITS step, whole (the stand-in renders in two halves with a pause).
         ss2 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
         a1 = np.zeros((1, total, 2), np.float32)
@@ -126,7 +126,7 @@ def _worker(rank, world, port, total, q):
                 ok = ok and fr is None
             # zero extra copies on the root: what comes back IS the slot's preallocated [world*n, ...] receive tensor, and
             # the root's own envs were rendered straight into its slice of it
-            slot = ss2._gx["slots"][tt % 2]
+            slot = ss2._gx["slots"][tt % sharding.ShardedSimulator.N_SLOTS]
             if rank == 0:
                 ok = ok and fr.data_ptr() == slot["recv"].data_ptr() and tuple(fr.shape) == (total,) + tuple(_fake_frames(0, 1).shape[1:])
                 ok = ok and slot["send"].data_ptr() == slot["recv"][lo:hi].data_ptr()
@@ -157,6 +157,79 @@ def _worker(rank, world, port, total, q):
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_lifetime_and_groups(rank, world, port, total, q):
+    """Round 5 (advisor, round 4): a batch handed out by step_render_gather survives the NEXT call (three slots); a change of the
+    payload drains the old transfers; `dst` is a global rank, also with an explicit group."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = 5000
+        a1 = np.zeros((1, total, 2), np.float32)
+        for overlap in (True, False):
+            ss = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+            held = None                                  # (step, tensor) of the call before
+            for t in range(8):
+                tt, fr = ss.step_render_gather(a1, overlap=overlap, dst=0)
+                if rank == 0 and held is not None:       # obs_t kept next to obs_t+1: still step held[0]'s bytes, whole
+                    assert torch.equal(held[1], _step_frames(0, total, held[0] + 1)), (overlap, t, held[0])
+                    assert fr is None or fr.data_ptr() != held[1].data_ptr()
+                if rank == 0 and fr is not None:
+                    assert torch.equal(fr, _step_frames(0, total, tt + 1)), (overlap, t, tt)
+                held = (tt, fr) if fr is not None else None
+            tt, fr = ss.flush_gather(dst=0)
+            assert tt == 7
+            if rank == 0:
+                assert torch.equal(fr, _step_frames(0, total, 8))
+            # copy=True: a private tensor, not a slot
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=0, copy=True)
+            if rank == 0:
+                assert all(fr.data_ptr() != sl["recv"].data_ptr() for sl in ss._gx["slots"]) and torch.equal(fr, _step_frames(0, total, 9))
+            # another payload on the same object: the pending transfers are drained, new buffers of the new shape
+            for t in range(3):
+                tt, ob = ss.step_render_gather(a1, overlap=True, dst=0, what="observe", obs=(4, 5))
+                if rank == 0 and ob is not None:
+                    assert tuple(ob.shape) == (total, 4, 5, 3)
+                    assert torch.equal(ob, _fake_frames(0, total, 4, 5) + torch.tensor(((tt + 10) * 13 + 4) % 256, dtype=torch.uint8))   # the new exchange counts from 0; 9 steps were made before
+            ss.flush_gather(dst=0)
+            # and back, to the OTHER root
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1)
+            assert (fr is not None) == (rank == 1)
+            if rank == 1:
+                assert torch.equal(fr, _step_frames(0, total, 13))
+        # an explicit group: `dst` stays a GLOBAL rank and the peers of the point-to-point transfers are translated with
+        # dist.get_global_rank (torch sorts the ranks of a new group, so at world_size 2 group rank == global rank: the
+        # translation is the identity here, what is exercised is the group argument on every call of the exchange)
+        g = dist.new_group(ranks=[0, 1])
+        ss = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
+        for t in range(3):
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1, group=g)
+            assert (fr is not None) == (rank == 1)
+            if rank == 1:
+                assert torch.equal(fr, _step_frames(0, total, t + 1)), t
+        assert ss._gx["peers"] == [0, 1] and ss._gx["is_root"] == (rank == 1)
+        q.put((rank, True))
+    except Exception as ex:                              # noqa: BLE001
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_held_batches_payload_changes_and_groups():
+    world, total = 2, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_lifetime_and_groups, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)], res
 
 
 def test_two_rank_gather_and_sharding():
