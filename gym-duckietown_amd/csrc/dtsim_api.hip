@@ -14,6 +14,7 @@
 
 #include "dtsim_dev.h"
 #include <dlfcn.h>
+#include <mutex>
 
 namespace {
 
@@ -94,10 +95,6 @@ struct dtsim {
   TileLds* d_tilerecs = nullptr;
   ScreenTri* d_stris = nullptr;
   ObjBox* d_objbox = nullptr;
-  uint4* d_units = nullptr;     // work units of k_resolve_clu: clusters of objects with overlapping screen boxes, per env (k_obj_setup)
-  int4* d_objlayer = nullptr;   // object layers (render.hip k_obj_setup): per (env, object) tile descriptor ...
-  uint4* d_layers = nullptr;    // ... and the per-env arenas of 32-byte source-pixel records
-  int layer_cap = 0;
   void* d_objmask = nullptr;    // block boxes [tiles*4][4] floats, then object masks [N][tiles*4] u64
   std::vector<uint32_t> h_pool;       // host copy of the RGBA8 pool (quad blocks are built from it at dtsim_set_maps)
   void* d_pixtab = nullptr;           // per-pixel tables of the shared camera (k_pix_setup)
@@ -308,7 +305,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_units, h->d_objlayer, h->d_layers, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->overlap.s2) { (void)hipStreamSynchronize(h->overlap.s2); (void)hipStreamDestroy(h->overlap.s2); }
   for (hipEvent_t ev : h->overlap.ev) if (ev) (void)hipEventDestroy(ev);
@@ -659,10 +656,6 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (h->d_stris) { (void)hipFree(h->d_stris); h->d_stris = nullptr; }
   if (h->d_objbox) { (void)hipFree(h->d_objbox); h->d_objbox = nullptr; }
   if (h->d_objmask) { (void)hipFree(h->d_objmask); h->d_objmask = nullptr; }
-  if (h->d_units) { (void)hipFree(h->d_units); h->d_units = nullptr; }
-  if (h->d_objlayer) { (void)hipFree(h->d_objlayer); h->d_objlayer = nullptr; }
-  if (h->d_layers) { (void)hipFree(h->d_layers); h->d_layers = nullptr; }
-  h->layer_cap = 0;
   h->max_tris = 0;
   for (auto& rm : rmaps) h->max_tris = std::max(h->max_tris, rm.n_tris);
   if (h->max_tris > 0 && (h->cfg.flags & DTSIM_F_RENDER)) {
@@ -670,15 +663,6 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     HIPCHK(hipMalloc(&h->d_objbox, sizeof(ObjBox) * (size_t)h->N * DTSIM_MAX_OBJECTS));
     const size_t n_blk = dt_raster_tiles(h->cfg.cam_width, h->cfg.cam_height) * 4;
     HIPCHK(hipMalloc(&h->d_objmask, n_blk * 16 + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8 + (size_t)h->N * n_blk * 8));
-    HIPCHK(hipMalloc(&h->d_units, sizeof(uint4) * (size_t)h->N * 256));   // (env, object cluster, tile-row band) units: 256 per env on average
-    // object layers: 16384 source pixels per env (512 KB) up to 4096 envs, fewer beyond (at most 2 GB); off with DTSIM_OBJ_LAYERS=0
-    // and for frames wider than 1024 (the rasters keep their source-pixel centres as fp16: exact only below 1024)
-    const char* lay = getenv("DTSIM_OBJ_LAYERS");
-    if (DT_OBJ_LAYERS && !(lay && lay[0] == '0') && h->cfg.cam_width <= 1024 && h->cfg.cam_height <= 1024) {
-      h->layer_cap = h->N <= 4096 ? 16384 : h->N <= 8192 ? 8192 : h->N <= 16384 ? 4096 : 2048;   // 512 KB per env up to 4096 envs, at most 2 GB
-      HIPCHK(hipMalloc(&h->d_objlayer, sizeof(int4) * (size_t)h->N * DTSIM_MAX_OBJECTS));
-      HIPCHK(hipMalloc(&h->d_layers, (size_t)32 * h->layer_cap * h->N));
-    }
   }
   h->n_tilerecs = (int)trecs.size();
   h->tex_w = tex_w ? tex_w : 1; h->tex_h = tex_h ? tex_h : 1;
@@ -889,8 +873,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   R.blockbox = reinterpret_cast<float*>(h->d_objmask);
   R.objrange = h->d_objmask ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(h->d_objmask) + dt_raster_tiles(R.W, R.H) * 4 * 16) : nullptr;
   R.objmask = h->d_objmask ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.objrange) + (size_t)DTSIM_MAX_MAPS * DTSIM_MAX_OBJECTS * 8) : nullptr;
-  R.units = h->d_units; R.units_cap = h->d_units ? h->N * 256 : 0; R.pad4_ = 0;
-  R.objlayer = h->d_objlayer; R.layers = h->d_layers; R.layer_cap = (h->d_layers && !segment) ? h->layer_cap : 0;
+  R.pad4_ = 0;
   R.queue = h->d_queue; R.qcount = h->d_qcount;
   R.dbg = nullptr;
   const size_t n_wg_ = dt_raster_tiles(R.W, R.H) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);
@@ -972,8 +955,6 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     int32_t dbg[8];
     HIPCHK(hipMemcpy(dbg, h->d_qcount + n_wg * 4, sizeof dbg, hipMemcpyDeviceToHost));
     unsigned long long pairs; memcpy(&pairs, dbg + 6, 8);
-    fprintf(stderr, "[dtsim] object layers: %d objects layered, %d live objects not layered, %d layer pixels rasterised; rasters composited %d box pixels from layers, "
-                    "sent %d on as ambiguous\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4]);
     fprintf(stderr, "[dtsim] resolve mesh pass: %d (batch,env) pairs, %d objects streamed, %d z-buffer calls (%d triangle-parallel), "
                     "%d triangles staged, %d pixels, %llu pixel x triangle tests\n", dbg[0], dbg[1], dbg[4], dbg[5], dbg[2], dbg[3], pairs);
     fprintf(stderr, "[dtsim] exact-path pixels: %lld of %zu (%.2f%%), max per wavefront region %lld\n", tot, npix * h->N,
@@ -999,18 +980,21 @@ typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_
 typedef const char* (*nccl_errstr_fn)(int);
 nccl_allgather_fn g_nccl_allgather = nullptr;
 nccl_errstr_fn g_nccl_errstr = nullptr;
-bool g_nccl_tried = false;
+std::once_flag g_nccl_once;
+std::string g_nccl_why;                               // why the library / symbol could not be had (kept: dlerror() is one-shot)
 void resolve_rccl() {
-  if (g_nccl_tried) return;
-  g_nccl_tried = true;
-  void* lib = nullptr;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);      // (the process's own copy when torch already loaded it)
-    if (lib) break;
-  }
-  if (!lib) return;
-  g_nccl_allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
-  g_nccl_errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(lib, "ncclGetErrorString"));
+  std::call_once(g_nccl_once, [] {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);    // (the process's own copy when torch already loaded it)
+      if (lib) break;
+      if (const char* e = dlerror()) g_nccl_why = e;
+    }
+    if (!lib) return;
+    g_nccl_allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(lib, "ncclAllGather"));
+    g_nccl_errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_nccl_allgather) { const char* e = dlerror(); g_nccl_why = e ? e : "ncclAllGather not exported"; }
+  });
 }
 }  // namespace
 
@@ -1023,10 +1007,8 @@ int dtsim_allgather_frames(dtsim_t* h, void* nccl_comm, void* recv, const void* 
   }
   if (send_bytes == 0) return fail(DTSIM_E_INVALID, "empty send buffer");
   resolve_rccl();
-  if (!g_nccl_allgather) {
-    const char* why = dlerror();
-    return fail(DTSIM_E_STATE, "librccl.so (ncclAllGather) could not be loaded: %s", why ? why : "library or symbol not found");
-  }
+  if (!g_nccl_allgather)
+    return fail(DTSIM_E_STATE, "librccl.so (ncclAllGather) could not be loaded: %s", g_nccl_why.empty() ? "library or symbol not found" : g_nccl_why.c_str());
   HIPCHK(hipSetDevice(h->cfg.device));
   const int rc = g_nccl_allgather(send, recv, send_bytes, /*ncclUint8*/ 1, nccl_comm, h->stream);
   if (rc != 0) return fail(DTSIM_E_HIP, "ncclAllGather: %s", g_nccl_errstr ? g_nccl_errstr(rc) : "error");

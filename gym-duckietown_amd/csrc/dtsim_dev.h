@@ -215,7 +215,7 @@ struct RenderParams {
   int32_t* qcount;              // [workgroups][4]
   uint16_t* qend;               // [workgroups][4][DT_ENVS_PER_BLOCK] queue fill of each region after each env of the chunk (mesh-object renders)
   int32_t* dbg;                 // optional debug counters (DTSIM_DEBUG_QUEUE), else null
-  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj ([2] = its heavy items, front of the list; [6] = the others, back), [4], [5] units of k_resolve_clu; zeroed per render (DT_WORK_INTS per render part)
+  int32_t* work;                // [0] number of work items (raster appends), [1] resolve cursor, [2], [3] the same for k_resolve_obj ([2] = its heavy items, front of the list; [6] = the others, back); zeroed per render (DT_WORK_INTS per render part)
   uint32_t* items;              // [workgroups * DT_ITEMS_PER_WG] work items: raster workgroup * DT_ITEMS_PER_WG + part
   uint32_t* items2;             // [workgroups * DT_ENVS_PER_BLOCK] work items of k_resolve_obj: raster workgroup * DT_ITEMS_PER_WG + env group
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
@@ -231,25 +231,9 @@ struct RenderParams {
   void* envv;                   // [N + 1] EnvV (render.hip): k_raster_v3's per-env constants in render order
   void* envd;                   // [N] EnvD (render_v3dr.inc, 192 B): k_raster_v3dr's per-env constants (domain randomisation)
   int32_t q3_rows;              // k_raster_v3 (render_v3.inc): rows of its LDS tile table (largest padded grid height); 0: k_raster_q is used
-  int32_t layer_cap;            // object layers (round 4): source pixels per env in `layers`; 0 = off
-  int32_t units_cap, pad4_;     // capacity of `units`
-  // Object layers: k_obj_setup rasterises every mesh object whose screen box is small and meets no other object's into a
-  // per-(env, object) tile of the RECTILINEAR image -- per pixel four MSAA samples {r, g, b (1/256 of an 8-bit step), flag} --
-  // and the quad-record rasters composite those samples over their own plane colour, instead of queueing the pixel for
-  // k_resolve_obj.  objlayer[env][object] = {first pixel of its tile in the env's arena or -1, x0, y0, tile width}.
-  uint4* units;                 // [N * DTSIM_MAX_OBJECTS] work units of k_resolve_clu (round 4): {env, member objects (64-bit mask: a cluster of
-                                // objects whose screen boxes overlap), 0}, appended by k_obj_setup; count = work[4], cursor = work[5]
-  int4* objlayer;               // [N][DTSIM_MAX_OBJECTS]
-  uint4* layers;                // [N][layer_cap][2]: 32 bytes per source pixel
+  int32_t pad4_;
   unsigned long long* spans;    // DT_WAVE_SPANS build variant only (else null): [2][2048 workgroups][4 wavefronts]{start, end, items, longest / first item, start of the first, sum, last item} in 100 MHz ticks
 };
-#ifndef DT_OBJ_LAYERS
-#define DT_OBJ_LAYERS 0         // built, parity-green, measured a NET LOSS on C4 / C5 (profiles/r04_variants_ab.txt block G): off.  1 compiles the layer
-                                // stage into k_obj_setup and the composite into k_raster_v3 / k_raster_v3dr (then DTSIM_OBJ_LAYERS=0 disables at run time)
-#endif
-#define DT_LAYER_MAX_PIX 1024   // source pixels per rasterisation pass: the z-keys of a pass live in 32 KB of LDS
-#define DT_LAYER_OBJ_PIX 8192   // largest object tile (up to eight passes); larger objects go through the queue
-
 // tables: bit 0 = the per-pixel tables (k_pix_setup), bit 1 = block boxes / object ranges (k_blk_setup) are valid from an
 // earlier launch (they depend on the camera LUT and the maps only); returns the bits that are valid after this launch,
 // plus bit 2 when the pass ran in k_env_sort's render order (RenderParams.envpos holds it: DTSIM_FIELD_RENDER_POS).

@@ -32,7 +32,11 @@
 //                 and writes, per (env, block), the mask of the objects whose box meets the block.
 //   k_raster_q<OBJ,S256> (shared camera, square power-of-two tile textures): quad-record one-ray path +
 //                 the exact path of plane-edge pixels inside the same wavefronts (resolve_region).
-//   k_resolve:    exact 4-sample resolve of the plane-edge pixels the generic k_raster queued (front of the queue
+//   k_raster_v3<OBJ> (render_v3.inc; 256 x 256 tile textures, the BASELINE configurations): k_raster_q on an instruction diet -- the
+//                 headline kernel; k_raster_v3dr<OBJ> (render_v3dr.inc): domain randomisation on the same records (per-env homography).
+//   k_env_sort:   render order of the envs for the quad-record paths (tile under the camera, heading quadrant): an XCD's L2 serves one
+//                 region of the map; DTSIM_FIELD_RENDER_POS reads the order back.
+//   k_resolve:    exact 4-sample resolve of the plane-edge pixels the generic k_raster / k_raster_v3dr queued (front of the queue
 //                 regions): persistent wavefronts pull work items (8 queue batches of one raster workgroup), 64 entries
 //                 at a time -- coverage per sample, shading once per distinct primitive at the pixel centre --
 //                 and patch the 3 bytes of each pixel; stream-ordered after the raster.
@@ -44,40 +48,24 @@
 //
 // Roofline: algorithmic bytes per env-step = W*H*3 (921 600 B at 640x480), written once (+ the ~1.3 % edge
 // pixels a second time); LUT / textures / tables are shared by all envs and stay in registers / LDS / L2.
-// Measured (profiles/): the pass is VALU-issue bound -- 44 vector instructions per pixel (round 1: 64.8)
-// with the vector ALUs 75-78 % busy -- at 24 % of the HBM roofline; float32 / integer-filter shading, uint8 output.
+// Measured (profiles/): the pass is co-limited by vector issue and the texture path -- 36.9 vector instructions per pixel
+// (round 1: 64.8), vector ALUs 74 % and texture unit 73 % busy -- at 25 - 26 % of the HBM roofline; float32 / integer-filter shading, uint8 output.
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
-#ifndef DT_ENV_SORT
-#define DT_ENV_SORT 1              // envs in k_env_sort order: half the L2 fills.  Round 3 switched it off (4 - 5 % slower with that kernel); with round 4's
-                                   // k_raster_v3 (32 x 2 slots, 6 wavefronts per SIMD) it costs nothing (profiles/r04_variants_ab.txt block I): on again
-#endif
-#ifndef DT_RESOLVE_CLU
-#define DT_RESOLVE_CLU 0           // round 4: object-box pixels by k_resolve_clu (one WORKGROUP per (env, object cluster, band of raster tile rows): blocks ->
-                                   // entry ranges, triangles staged once, per-batch cull) instead of k_resolve_obj.  Built, parity-green (48 GPU tests), and no
-                                   // faster: 0.83 ms against 0.85 on C5, 1.06 against 0.79 on C4 (profiles/r04_variants_ab.txt block G): off
-#endif
-#ifndef DT_V3_DR
-#define DT_V3_DR 1                 // domain randomisation on the quad records (render_v3dr.inc); 0: the generic k_raster<DR=1>
-#endif
 #include <type_traits>
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <tuple>
 
-// Format-converting buffer loads (MTBUF): tbuffer_load_format_d16_xyzw with format 8_8_8_8 / UINT returns the four BYTES of one
-// dword as four u16 in two registers -- exactly the operand pairs of v_dot2_u32_u16.  clang has no builtin for it; the LLVM
-// intrinsic is reached by name (its immediates must be literals after inlining).  Checked on the part by tools/ubench/fmt_load.hip.
+// Buffer stores through a raw descriptor (k_raster_v3 / k_raster_v3dr frame rows): clang has no builtin with a scalar-base form, the LLVM
+// intrinsics are reached by name (their immediates must be literals after inlining).
 typedef int v3_i32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 v3_h16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t v3_u32x3 __attribute__((ext_vector_type(3)));
-__device__ v3_h16x4 v3_tbuf_load_d16x4(v3_i32x4 rsrc, int voffset, int soffset, int format, int aux) __asm("llvm.amdgcn.raw.tbuffer.load.v4f16");
-__device__ int v3_buf_load_i32(v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 __device__ void v3_buf_store_v3i32(v3_u32x3 data, v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v3i32");
 typedef uint32_t v3_u32x4 __attribute__((ext_vector_type(4)));
 __device__ void v3_buf_store_v4i32(v3_u32x4 data, v3_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
-#define V3_FMT_8888_UINT 74        // dfmt 10 (8_8_8_8) | nfmt 4 (UINT) << 4
-#define V3_RSRC_W3 0x00027000      // raw buffer descriptor word 3 (the MTBUF instruction carries its own format)
+#define V3_RSRC_W3 0x00027000      // raw buffer descriptor word 3
 __device__ inline v3_i32x4 v3_rsrc(const void* p, uint32_t bytes) {
   v3_i32x4 r;
   r.x = (int)(uint32_t)reinterpret_cast<uintptr_t>(p); r.y = (int)((reinterpret_cast<uintptr_t>(p) >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = V3_RSRC_W3;
@@ -494,190 +482,6 @@ __device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
   return n0 + b * (n1 - n0);
 }
 
-#if DT_OBJ_LAYERS
-// ---- object layers (round 4) ---------------------------------------------------------------------------------------
-// objects.py:123-148 / objmesh.py:360-375 (mesh draw), graphics.py:172-251 (4x MSAA), for the common case of a SMALL object
-// whose screen box meets no other object's: instead of sending every pixel of the box through the queue to k_resolve_obj
-// (a chain of dependent loads per (raster tile, env) unit: profiles/r04_resolve_obj.txt), the object is rasterised HERE,
-// triangle-major, into a tile of the rectilinear image: z-keys of the four samples of each source pixel in LDS (ds_max_u64:
-// LESS depth test with the draw-order tie break, the arithmetic of zbuffer_chunk), then per covered pixel the winners are
-// shaded at the pixel centre (the mesh branch of shade_msaa) and written as four {r, g, b, flag} samples -- colours in 1/256 of
-// an 8-bit step; flag 1 = covered and in front of the tile plane along its ray (so in front of every plane primitive), 2 =
-// covered but not certainly in front: the rasters send such pixels through the queue as before.  The quad-record rasters
-// composite the flag-1 samples over their own plane colour (render_v3.inc / render_v3dr.inc push_obj).
-__device__ inline void obj_layers(const RenderParams& R, const EnvCam& c, const RenderMapDev& m, const int e, const int tid,
-                                  const ScreenTri* __restrict__ out, const float (*s_oboxf)[4]) {
-  __shared__ unsigned long long s_keys[DT_LAYER_MAX_PIX * 4];   // z-keys of the pass's sub-tile: [pixel][sample]
-  __shared__ float s_tri[256][12];                     // the chunk's triangles: sx[3], sy[3], iw[3], inv_area, index, -
-  __shared__ int s_tbox[256];                          // clipped pixel box of each: ix0 | iy0 << 12 | width << 24 (width <= 255 per pass: wider boxes are split by the pass)
-  __shared__ int s_pref[257];                          // exclusive scan of the boxes' ROW counts
-  __shared__ int s_lay[DTSIM_MAX_OBJECTS][5];          // first pixel in the env's arena (-1: no layer), x0, y0, w, h
-  if (tid < DTSIM_MAX_OBJECTS) {
-    int off = -1, x0 = 0, y0 = 0, w = 0, hh = 0;
-    if (tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1]) {
-      // every source pixel whose centre the rasters' box test (box +- the fp16 margin) can accept: box +- 1 px, clipped
-      x0 = max(0, (int)floorf(s_oboxf[tid][0] - 1.f)); y0 = max(0, (int)floorf(s_oboxf[tid][2] - 1.f));
-      const int x1 = min(R.W - 1, (int)ceilf(s_oboxf[tid][1] + 1.f)), y1 = min(R.H - 1, (int)ceilf(s_oboxf[tid][3] + 1.f));
-      w = x1 - x0 + 1; hh = y1 - y0 + 1;
-      off = (w > 0 && hh > 0 && w <= 255 && w * hh <= DT_LAYER_OBJ_PIX) ? 0 : -1;
-    }
-    s_lay[tid][0] = off; s_lay[tid][1] = x0; s_lay[tid][2] = y0; s_lay[tid][3] = w; s_lay[tid][4] = hh;
-  }
-  __syncthreads();
-  if (tid == 0) {                                      // arena offsets, in object order
-    int acc = 0;
-    for (int o = 0; o < m.n_obj; ++o) {
-      if (s_lay[o][0] < 0) continue;
-      const int area = s_lay[o][3] * s_lay[o][4];
-      if (acc + area <= R.layer_cap) { s_lay[o][0] = acc; acc += area; } else s_lay[o][0] = -1;
-    }
-  }
-  __syncthreads();
-  if (tid < DTSIM_MAX_OBJECTS) R.objlayer[(size_t)e * DTSIM_MAX_OBJECTS + tid] = make_int4(s_lay[tid][0], s_lay[tid][1], s_lay[tid][2], s_lay[tid][3]);
-  if (R.dbg && tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1]) {   // DTSIM_DEBUG_QUEUE: layered / live-but-not-layered objects, layer pixels
-    atomicAdd(R.dbg + (s_lay[tid][0] >= 0 ? 0 : 1), 1);
-    if (s_lay[tid][0] >= 0) atomicAdd(R.dbg + 2, s_lay[tid][3] * s_lay[tid][4]);
-  }
-  const uint2* rng = R.objrange + (size_t)c.map_id * DTSIM_MAX_OBJECTS;
-  const float4* boxes = R.tribox + (size_t)e * R.max_tris;
-  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
-  const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int o = 0; o < m.n_obj; ++o) {                  // workgroup-uniform
-    const int off = s_lay[o][0];
-    if (off < 0) continue;
-    const int x0 = s_lay[o][1], oy0 = s_lay[o][2], w = s_lay[o][3], ohh = s_lay[o][4];
-    const uint2 fc = rng[o];
-    const int rows_pp = max(1, DT_LAYER_MAX_PIX / w);  // rows of the object's tile per pass (the keys of a pass fit the LDS buffer)
-    for (int r0 = 0; r0 < ohh; r0 += rows_pp) {        // ---- one pass: sub-tile rows [y0, y0 + hh)
-      const int y0 = oy0 + r0, hh = min(rows_pp, ohh - r0), npx = w * hh;
-      for (int i = tid; i < npx * 4; i += 256) s_keys[i] = 0ull;
-      for (int t0 = (int)fc.x; t0 < (int)(fc.x + fc.y); t0 += 256) {   // the object's triangles, 256 at a time
-        __syncthreads();                               // keys zeroed / the previous chunk's pairs done
-        // (1) this lane's triangle: clipped pixel box -> LDS, with its set-up; rows -> scan
-        int rows = 0;
-        {
-          const int t = t0 + tid;
-          int ix0 = 0, iy0 = 0, bw = 0;
-          if (t < (int)(fc.x + fc.y)) {
-            const float4 bb = boxes[t];                // bx0, bx1, by0, by1 (inverted for culled triangles)
-            if (bb.x <= bb.y) {
-              ix0 = max(x0, (int)ceilf(bb.x - 0.5f)); iy0 = max(y0, (int)ceilf(bb.z - 0.5f));
-              const int ix1 = min(x0 + w - 1, (int)floorf(bb.y - 0.5f)), iy1 = min(y0 + hh - 1, (int)floorf(bb.w - 0.5f));
-              bw = max(0, ix1 - ix0 + 1); rows = bw > 0 ? max(0, iy1 - iy0 + 1) : 0;
-              if (rows > 0) {
-                const ScreenTri& st = out[t];
-                float* d = s_tri[tid];
-                d[0] = st.sx[0]; d[1] = st.sx[1]; d[2] = st.sx[2]; d[3] = st.sy[0]; d[4] = st.sy[1]; d[5] = st.sy[2];
-                d[6] = st.iw[0]; d[7] = st.iw[1]; d[8] = st.iw[2]; d[9] = st.inv_area; d[10] = __int_as_float(st.index);
-              }
-            }
-          }
-          s_tbox[tid] = ix0 | (iy0 << 12) | (bw << 24);
-        }
-        // exclusive scan of `rows` over the 256 lanes (wave scan + the four wave totals)
-        int inc = rows;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
-        __shared__ int s_wtot[4];
-        if (lane == 63) s_wtot[wave] = inc;
-        __syncthreads();
-        int wbase = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wbase += q < wave ? s_wtot[q] : 0;
-        s_pref[tid] = wbase + inc - rows;
-        if (tid == 255) s_pref[256] = wbase + inc;
-        __syncthreads();
-        const int n_rows = s_pref[256];
-        // (2) (triangle, row) pairs spread over the 256 lanes; a lane walks its row's columns
-        for (int pr = tid; pr < n_rows; pr += 256) {
-          int lo_ = 0, hi_ = 255;                      // last triangle with pref <= pr
-#pragma unroll
-          for (int it = 0; it < 8; ++it) { const int mid = (lo_ + hi_ + 1) >> 1; if (s_pref[mid] <= pr) lo_ = mid; else hi_ = mid - 1; }
-          const int tl = lo_;
-          const int tb = s_tbox[tl];
-          const int ix0 = tb & 4095, iy = ((tb >> 12) & 4095) + (pr - s_pref[tl]), bw = (int)((uint32_t)tb >> 24);
-          const float* d = s_tri[tl];
-          const float ia = d[9];
-          const float d0 = d[6] - d[8], d1 = d[7] - d[8];
-          const uint32_t rix = 0x7fffffffu - (uint32_t)__float_as_int(d[10]);
-          const float qy = (float)iy + 0.5f;
-          const float e0y = d[3] - qy, e1y = d[4] - qy, e2y = d[5] - qy;
-          unsigned long long* kp = s_keys + ((iy - y0) * w + (ix0 - x0)) * 4;
-          for (int ix = ix0; ix < ix0 + bw; ++ix, kp += 4) {   // the arithmetic of zbuffer_chunk's drain, term for term
-            const float qx = (float)ix + 0.5f;
-            const float e0x = d[0] - qx, e1x = d[1] - qx, e2x = d[2] - qx;
-            const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
-            const float g0x = (e1y - e2y) * ia, g0y = (e2x - e1x) * ia, g1x = (e2y - e0y) * ia, g1y = (e0x - e2x) * ia;
-            const float wc = fmaf(b1c, d1, fmaf(b0c, d0, d[8]));
-            const float gwx = fmaf(g1x, d1, g0x * d0), gwy = fmaf(g1y, d1, g0y * d0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float b0 = fmaf(g0y, oy[q], fmaf(g0x, ox[q], b0c));
-              const float b1 = fmaf(g1y, oy[q], fmaf(g1x, ox[q], b1c));
-              const float b2 = 1.f - b0 - b1;
-              const float wq = fmaf(gwy, oy[q], fmaf(gwx, ox[q], wc));
-              const bool in = fminf(fminf(b0, b1), b2) >= 0.f && wq <= 1.f / NEAR_Z && wq >= 1.f / FAR_Z;
-              if (in) atomicMax(kp + q, ((unsigned long long)__float_as_uint(wq) << 32) | rix);
-            }
-          }
-        }
-      }
-      __syncthreads();
-      // (3) resolve the pass's pixels: winners shaded at the pixel centre -> four {r, g, b, flag} samples
-      uint4* arena = R.layers + ((size_t)e * R.layer_cap + off + (size_t)r0 * w) * 2;
-      for (int p = tid; p < npx; p += 256) {
-        unsigned long long k[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = s_keys[p * 4 + q];
-        uint32_t rec[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        if ((k[0] | k[1] | k[2] | k[3]) != 0ull) {
-          const int py = p / w;
-          const float pcx = (float)(x0 + p - py * w) + 0.5f, pcy = (float)(y0 + py) + 0.5f;
-          const float nx = pcx * sxn - 1.f, ny = 1.f - pcy * syn;
-          int prev_t = -1;
-          uint32_t prev_rg = 0u, prev_b = 0u;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (k[q] == 0ull) continue;
-            const float wq = __uint_as_float((uint32_t)(k[q] >> 32));
-            const int ti = (int)(0x7fffffffu - (uint32_t)k[q]);
-            // in front of the tile plane along the sample's ray?  (then in front of the ground quad and the sky as well)
-            const Ray rs = make_ray(nx + ox[q] * sxn, ny - oy[q] * syn, c.tx, c.ty, c.sth, c.cth);
-            const bool front = !(rs.yla < 0.f) || 1.f / wq < c.Cy * frcp(-rs.yla);
-            if (ti != prev_t) {                        // shade the winner at the PIXEL CENTRE (shade_msaa's mesh branch)
-              const ScreenTri& st = out[ti];
-              const float b0 = ((st.sx[1] - pcx) * (st.sy[2] - pcy) - (st.sx[2] - pcx) * (st.sy[1] - pcy)) * st.inv_area;
-              const float b1 = ((st.sx[2] - pcx) * (st.sy[0] - pcy) - (st.sx[0] - pcx) * (st.sy[2] - pcy)) * st.inv_area;
-              const float b2 = 1.f - b0 - b1;
-              const float inv = 1.f / (b0 * st.iw[0] + b1 * st.iw[1] + b2 * st.iw[2]);
-              float tx[3] = {1.f, 1.f, 1.f};
-              if (st.tex >= 0) {
-                const float u = (b0 * st.uw[0] + b1 * st.uw[1] + b2 * st.uw[2]) * inv;
-                const float v = (b0 * st.vw[0] + b1 * st.vw[1] + b2 * st.vw[2]) * inv;
-                mesh_texel(R, st.tex, u == u ? u : 0.f, v == v ? v : 0.f, tx);
-              }
-              uint32_t c16[3];
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) {
-                const float v = (b0 * st.cw[0][ch] + b1 * st.cw[1][ch] + b2 * st.cw[2][ch]) * inv;
-                c16[ch] = (uint32_t)(fminf(fmaxf(v == v ? v : 0.f, 0.f), 255.f) * tx[ch] * 256.f + 0.5f);
-              }
-              prev_t = ti; prev_rg = c16[0] | (c16[1] << 16); prev_b = c16[2];
-            }
-            rec[2 * q] = prev_rg; rec[2 * q + 1] = prev_b | ((front ? 1u : 2u) << 16);
-          }
-        }
-        arena[(size_t)p * 2] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-        arena[(size_t)p * 2 + 1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
-      }
-      __syncthreads();
-    }
-  }
-}
-
-#endif  // DT_OBJ_LAYERS
 
 __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
   const int e = blockIdx.x;
@@ -790,35 +594,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     s_oboxf[tid][0] = ob.bx0; s_oboxf[tid][1] = ob.bx1; s_oboxf[tid][2] = ob.by0; s_oboxf[tid][3] = ob.by1;   // empty when not live
   }
   __syncthreads();
-#if DT_OBJ_LAYERS
-  if (R.layer_cap > 0) obj_layers(R, c, m, e, tid, out, s_oboxf);
-#endif
-  __shared__ int s_lab[DTSIM_MAX_OBJECTS];             // cluster label of each object (-1: not live)
-  __shared__ uint32_t s_band[DTSIM_MAX_OBJECTS];      // per cluster root: the bands of raster tile rows its members' boxes meet
-  if (R.units) {
-    // Work units of k_resolve_clu: clusters of live objects whose screen boxes (+ 1.5 px: the rasters' box margin) overlap,
-    // transitively -- every queued object-box pixel of the env lies in the boxes of exactly one cluster.  Label propagation
-    // by one wavefront (lane = object, labels in LDS; a wavefront's DS operations execute in order).
-    if (tid < DTSIM_MAX_OBJECTS) {
-      s_band[tid] = 0u;
-      const bool live = tid < m.n_obj && s_oboxf[tid][0] <= s_oboxf[tid][1];
-      s_lab[tid] = live ? tid : -1;
-      for (int it = 0; it < m.n_obj; ++it) {           // wave-uniform bound
-        int l = s_lab[tid];
-        if (l >= 0)
-          for (int p = 0; p < m.n_obj; ++p) {
-            const int lp = s_lab[p];
-            if (lp >= 0 && lp < l &&
-                !(s_oboxf[p][1] + 1.5f < s_oboxf[tid][0] - 1.5f || s_oboxf[p][0] - 1.5f > s_oboxf[tid][1] + 1.5f ||
-                  s_oboxf[p][3] + 1.5f < s_oboxf[tid][2] - 1.5f || s_oboxf[p][2] - 1.5f > s_oboxf[tid][3] + 1.5f)) l = lp;
-          }
-        const bool ch = l != s_lab[tid];
-        if (!__ballot(ch)) break;
-        s_lab[tid] = l;
-      }
-    }
-    __syncthreads();                                   // labels complete before the block loop below reads them
-  }
   if (R.objmask) {
     // which objects' screen boxes meet each raster wavefront block (source-pixel boxes of the blocks: k_blk_setup): the
     // raster reads one 8-byte mask per (env, block) instead of walking the env's object boxes
@@ -830,24 +605,6 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
       for (int o = 0; o < m.n_obj; ++o)
         if (!(bb.y < s_oboxf[o][0] || bb.x > s_oboxf[o][1] || bb.w < s_oboxf[o][2] || bb.z > s_oboxf[o][3])) mk |= 1ull << o;
       R.objmask[(size_t)(pos ? pos[e] : e) * n_blk + b] = mk;   // indexed by position in the render order
-      if (R.units && mk) {                             // the band of this block's tile row, for the clusters of the objects it meets
-        const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, tiles_y = (R.H + DT_TILE_H - 1) / DT_TILE_H;
-        const int band = ((b >> 2) / tiles_x) / max(2, (tiles_y + 31) / 32);
-        unsigned long long t = mk;
-        while (t) { const int o = __builtin_ctzll(t); t &= t - 1ull; atomicOr(&s_band[s_lab[o]], 1u << band); }
-      }
-    }
-    __syncthreads();
-    if (R.units && tid < m.n_obj && s_lab[tid] == tid) {   // cluster root: one unit per band its members' boxes meet
-      unsigned long long mk = 0ull;
-      for (int p = 0; p < m.n_obj; ++p) if (s_lab[p] == tid) mk |= 1ull << p;
-      uint32_t bands = s_band[tid];
-      const int nbd = __popc(bands);
-      if (nbd) {
-        int ui = atomicAdd(R.work + 4, nbd);
-        if (ui + nbd > R.units_cap) bands = 0u;        // (never with the capacity dtsim_set_maps allocates: 256 units per env on average)
-        while (bands) { const int bd = __builtin_ctz(bands); bands &= bands - 1u; R.units[ui++] = make_uint4((uint32_t)e, (uint32_t)mk, (uint32_t)(mk >> 32), (uint32_t)bd); }
-      }
     }
   }
 }
@@ -970,19 +727,12 @@ __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, floa
 //                     the per-sample winners are reduced across the wavefront (a handful of pixels of a
 //                     small / distant object, where the pixel-parallel loop would idle most lanes).
 // Depth func LESS with the draw-order tie break, identical in both schedules.
-#ifndef DT_RO_BATCH_CULL
-#define DT_RO_BATCH_CULL 0     // per-batch triangle cull ahead of the per-pixel box tests: measured no gain (profiles/r03_variants_ab.txt, block F)
-#endif
-#ifndef DT_RO_PAIRS
-#define DT_RO_PAIRS 1          // pixel-parallel schedule as a balanced (pixel, triangle) pair list (below)
-#endif
 #ifndef RO_PAIR_CAP
 #define RO_PAIR_CAP 256                                  // pair slots per wavefront (16-bit entries)
 #endif
-#define RO_SCR_BYTES (DT_RO_PAIRS ? 64 * 4 * 8 + RO_PAIR_CAP * 2 : 0)   // per wavefront: sample keys + the pair list
-// sel (round 4, k_resolve_clu): the staged triangles to test are w_tris[sel[0 .. fill)] (a per-batch cull of a larger staged set)
+#define RO_SCR_BYTES (64 * 4 * 8 + RO_PAIR_CAP * 2)       // per wavefront: sample keys + the pair list
 __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int fill, bool mine, int lane, float pcx, float pcy,
-                                     float wbest[4], int tbest[4], int32_t* dbg, const uint16_t* sel = nullptr) {
+                                     float wbest[4], int tbest[4], int32_t* dbg) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1002,7 +752,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
       const float qx = __shfl(pcx, src), qy = __shfl(pcy, src);
       float wb[4] = {0.f, 0.f, 0.f, 0.f};
       int tb[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-      for (int k = lane; k < fill; k += 64) test_tri(w_tris[sel ? (int)sel[k] : k], qx, qy, wb, tb);   // tb starts at "no triangle" = +inf: ties keep the lower index
+      for (int k = lane; k < fill; k += 64) test_tri(w_tris[k], qx, qy, wb, tb);   // tb starts at "no triangle" = +inf: ties keep the lower index
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         float wmax = wb[s];
@@ -1022,7 +772,6 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
     // its own mask: the wavefront runs max-over-lanes(candidates) passes of the 4-sample test, with a different
     // triangle per lane.
     static_assert(TRI_CAP <= 128 && TRI_CAP % 32 == 0, "up to four 32-bit candidate masks");
-#if DT_RO_PAIRS
     // Round 3: balanced.  Walking per-lane candidate masks costs max-over-lanes passes of the 4-sample test -- measured
     // 18 passes per call where the (pixel, triangle) pairs would fill 5.8 (profiles/r03_variants_ab.txt block G): the
     // pixels of a batch straddle the dense middle of an object and the empty corners of its box.  Instead (1) the box
@@ -1079,7 +828,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     for (int jj = 0; jj < fill; ++jj) {                // wave-uniform
-      const int j = sel ? (int)sel[jj] : jj;
+      const int j = jj;
       const float4 bb = *reinterpret_cast<const float4*>(&w_tris[j]);              // bx0, bx1, by0, by1
       // four compares straight into scalar masks, ANDed on the scalar unit (as one bool expression the compiler builds the
       // conjunction out of 0 / 1 integers: 17 vector instructions instead of 4)
@@ -1106,86 +855,6 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
 #ifdef DT_RO_STATS
     if (dbg && lane == 0) { atomicAdd(dbg + 8, n_pairs); atomicAdd(dbg + 9, n_pass); atomicAdd(dbg + 10, (n_pairs + 63) >> 6); }
 #endif
-#else
-    uint32_t cand[4] = {0u, 0u, 0u, 0u};
-#if DT_RO_BATCH_CULL
-    // (0) The 64 pixels of a batch are a short piece of one or two frame rows (queue order), while the staged triangles
-    // were culled against the whole unit: first drop, triangle-parallel, the staged triangles whose box misses the
-    // batch's own pixel box -- two triangles per lane, the survivors as scalar bit masks -- so that step (1) only walks
-    // the few triangles that can touch this batch.
-    float bx0 = mine ? pcx : 1e30f, bx1 = mine ? pcx : -1e30f, by0 = mine ? pcy : 1e30f, by1 = mine ? pcy : -1e30f;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      bx0 = fminf(bx0, __shfl_xor(bx0, d)); bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
-      by0 = fminf(by0, __shfl_xor(by0, d)); by1 = fmaxf(by1, __shfl_xor(by1, d));
-    }
-    uint32_t live[4] = {0u, 0u, 0u, 0u};             // wave-uniform: staged triangle j of chunk c can touch the batch
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h * 64 >= fill) break;                     // wave-uniform
-      const int k = h * 64 + lane;
-      bool hit = false;
-      if (k < fill) {
-        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[k]);            // bx0, bx1, by0, by1
-        hit = !(bb.x > bx1 || bb.y < bx0 || bb.z > by1 || bb.w < by0);
-      }
-      const unsigned long long hm = __ballot(hit);
-      live[2 * h] = (uint32_t)hm; live[2 * h + 1] = (uint32_t)(hm >> 32);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint32_t lv = live[c];                         // scalar
-      uint32_t mk = 0u;
-      while (lv) {                                   // wave-uniform: only the triangles that meet the batch's box
-        const int j = __builtin_ctz(lv);
-        lv &= lv - 1u;
-        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[c * 32 + j]);
-        const bool in = (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
-        mk |= in ? (1u << j) : 0u;
-      }
-      cand[c] = mine ? mk : 0u;
-    }
-#else
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c * 32 >= fill) break;                     // wave-uniform
-      const int nk = min(32, fill - c * 32);
-      uint32_t mk = 0u;
-      for (int j = 0; j < nk; ++j) {
-        const float4 bb = *reinterpret_cast<const float4*>(&w_tris[c * 32 + j]);   // bx0, bx1, by0, by1
-        const bool in = (pcx >= bb.x) & (pcx <= bb.y) & (pcy >= bb.z) & (pcy <= bb.w);
-        mk |= in ? (1u << j) : 0u;
-      }
-      cand[c] = mine ? mk : 0u;
-    }
-#endif
-#ifdef DT_RO_STATS
-    if (dbg) {                                       // candidate statistics of the pixel-parallel z-buffer (build variant)
-      int nc = __popc(cand[0]) + __popc(cand[1]) + __popc(cand[2]) + __popc(cand[3]);
-      int sum = nc, mx = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { int m = __popc(cand[c]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
-        mx += m; }
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-      if (lane == 0) { atomicAdd(dbg + 8, sum); atomicAdd(dbg + 9, mx); atomicAdd(dbg + 10, (sum + 63) >> 6); }
-    }
-#endif
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c * 32 >= fill) break;
-      uint32_t mk = cand[c];
-      while (__ballot(mk != 0u)) {                   // wave-uniform trip count
-        if (mk) {
-          const int j = __builtin_ctz(mk);
-          mk &= mk - 1u;
-          test_tri_inside(w_tris[c * 32 + j], pcx, pcy, wbest, tbest);
-        }
-      }
-    }
-#endif  // DT_RO_PAIRS
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1863,29 +1532,6 @@ __device__ inline void quad_filter3(const uint4& q, float ax, float az, float I,
   for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
 }
 
-// Object layers (k_obj_setup / obj_layers): composite the four samples of one source pixel (two 16-byte halves a, b) over the
-// pixel's own 8-bit plane colour rgb = 0x00BBGGRR -- covered samples (flag 1) replace the plane colour, (sum + 2) / 4 with
-// the layer colours in 1/256 of a step; amb: some sample is covered but not certainly in front of the planes (flag 2): the
-// pixel takes the queue instead.  An uncovered pixel keeps its colour bit for bit.
-__device__ inline uint32_t layer_composite(const uint4 a, const uint4 b, const uint32_t rgb, bool& amb) {
-  const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
-  uint32_t sr = 0u, sg = 0u, sb = 0u, ncov = 0u;
-  amb = false;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t f = hi[q] >> 16;
-    const bool cov = f == 1u;
-    amb |= f == 2u;
-    sr += cov ? (lo[q] & 0xFFFFu) : 0u; sg += cov ? (lo[q] >> 16) : 0u; sb += cov ? (hi[q] & 0xFFFFu) : 0u;
-    ncov += cov ? 1u : 0u;
-  }
-  if (ncov == 0u) return rgb;
-  const uint32_t np = 4u - ncov;
-  const uint32_t r = (sr + np * ((rgb & 255u) << 8) + 512u) >> 10, g = (sg + np * (((rgb >> 8) & 255u) << 8) + 512u) >> 10,
-                 bl = (sb + np * (((rgb >> 16) & 255u) << 8) + 512u) >> 10;
-  return min(r, 255u) | (min(g, 255u) << 8) | (min(bl, 255u) << 16);
-}
-
 #define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
 // V3: the LDS tile table layout of k_raster_v3 (render_v3.inc: block offset at (tz << 10 | tx << 2) + the map's column
 // offset EnvQ.pad[0], the cell selector 512 bytes behind it) and its wavefront block shape; (tile_x0, wave_y0) is the
@@ -2220,14 +1866,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 #ifndef DT_Q_WAVES
 #define DT_Q_WAVES 5                                 // wavefronts per SIMD the register allocation is held to (96 VGPRs)
 #endif
-#ifndef DT_Q_PIPE
-#define DT_Q_PIPE 0
-#endif
 #ifndef DT_Q_TILE_GROUP
 #define DT_Q_TILE_GROUP 10
-#endif
-#ifndef DT_Q_SCHED_BARRIER
-#define DT_Q_SCHED_BARRIER 1
 #endif
 #ifndef DT_Q_PRIO
 #define DT_Q_PRIO 3                                  // s_setprio level while a wavefront issues its quad loads (0: off)
@@ -2439,7 +2079,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         else local = (((zi & SM) << LS) | (xi & SM)) & te.y;                   // te.y: cell mask
 #ifdef DT_Q_NO_LOAD
         st.q[k] = make_uint4(tb + local, tb ^ local, local, 0x00000080u);
-#elif defined(DT_Q_HOT_LOAD)
+#elif 0
         st.q[k] = *reinterpret_cast<const uint4*>(qtex + (tb + ((local & 0x3FFu) << 4)));   // ablation: L1-resident taps
 #else
         st.q[k] = *reinterpret_cast<const uint4*>(qtex + (tb + (local << 4)));
@@ -2456,7 +2096,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     uint32_t* d = reinterpret_cast<uint32_t*>(st_base + (size_t)env * st_stride);
 #if defined(DT_Q_NO_STORE)
     if (o.a == 0x12345678u) *d = 1u;
-#elif defined(DT_Q_PLAIN_STORE)
+#elif 0
     *reinterpret_cast<U3*>(d) = o;
 #else
     // non-temporal: the frame is written once and not read back by this pass; keep the taps in L2
@@ -2488,9 +2128,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     const uint32_t hor_v = hor_rgb;
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
-#if DT_Q_SCHED_BARRIER
       if (j) __builtin_amdgcn_sched_barrier(0);      // one pixel pair at a time: fewer live temporaries
-#endif
       // bilinear weights with the lit factor folded in, two pixels per packed op
       const f2 I2 = lit2[j];
       const f2 axI = ax2[j] * I2, azI = az2[j] * I2;
@@ -2588,30 +2226,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     }
     return out;
   };
-#if DT_Q_PIPE
-  {  // two stages: loads of env e+1 in flight while env e is filtered and stored
-    QStage sa, sb;
-    EnvQ fa = envq[e0], fb = envq[min(e0 + 1, e1 - 1)];
-    issue(fa, sa);
-    for (int e = e0; e < e1; e += 2) {
-      const uint32_t hor_a = fa.hor_rgb, hor_b = fb.hor_rgb, env_a = fa.env, env_b = fb.env;
-      issue(fb, sb);                                 // env e+1 (a harmless repeat of the last env past the end)
-      fa = envq[min(e + 2, e1 - 1)];
-      const U3 oa = finish(e, env_a, hor_a, sa, objmask_of(e));
-      store(env_a, oa);
-      if (e + 1 < e1) {
-        issue(fa, sa);                               // env e+2
-        fb = envq[min(e + 3, e1 - 1)];
-        const U3 ob = finish(e + 1, env_b, hor_b, sb, objmask_of(e + 1));
-        store(env_b, ob);
-      }
-    }
-  }
-#else
-#ifdef DT_Q_TIMING
-#define TSTAMP() __builtin_readcyclecounter()
-  unsigned long long t_issue = 0, t_lds = 0, t_mem = 0, t_filt = 0, t_tail = 0, t_n = 0;
-#endif
   {  // one stage, deferred store: the 12 bytes of env e-1 are held in registers and stored right after the loads of
      // env e have been issued, so that waiting for those loads never waits for a store of the same iteration.
      // No branch between the loads and the store (first env peeled).
@@ -2624,33 +2238,14 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
     if (OBJ) qend_v = qo;
     for (int e = e0 + 1; e < e1; ++e) {
       env_prev = env; hor = f.hor_rgb; env = f.env;
-#ifdef DT_Q_TIMING
-      const unsigned long long t0 = TSTAMP();
-#endif
       issue(f, sa);
       store(env_prev, held);
       f = envq[min(e + 1, e1 - 1)];                  // next env's constants: the scalar load has the whole filter to land
-#ifdef DT_Q_TIMING
-      const unsigned long long t1 = TSTAMP();
-      __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0): all four quad records (and the store) have landed
-      const unsigned long long t2 = TSTAMP();
-#endif
       held = finish(e, env, hor, sa, objmask_of(e));
       if (OBJ) qend_v = lane >= e - e0 ? qo : qend_v;
-#ifdef DT_Q_TIMING
-      const unsigned long long t3 = TSTAMP();
-      t_issue += t1 - t0; t_mem += t2 - t1; t_filt += t3 - t2; t_n += 1;
-#endif
     }
     store(env, held);
-#ifdef DT_Q_TIMING
-    if (lane == 0) {
-      unsigned long long* tc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(R.dump) + 1024);
-      atomicAdd(tc + 0, t_issue); atomicAdd(tc + 1, t_mem); atomicAdd(tc + 2, t_filt); atomicAdd(tc + 3, t_n);
-    }
-#endif
   }
-#endif
   if (lane == 0) qcount[rwg * (RB / 64) + wave] = OBJ ? qo : qn;
 #ifdef DT_Q_ABL_NORESOLVE
   if (qn < 0) {
@@ -2678,16 +2273,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 }
 
 #include "render_v3.inc"
-#if DT_V3_DR && !(DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1)   // experimental block shapes / lane maps of k_raster_v3: the generic kernels keep domain randomisation
-#undef DT_V3_DR
-#define DT_V3_DR 0
-#endif
-#if DT_V3_DR
 #include "render_v3dr.inc"
-#else
-struct EnvD { float v[48]; };
-__device__ inline void fill_envd_at(EnvD*, int, const EnvCam&, const EnvQ&, const RenderMapDev&, float, int, int) {}
-#endif
 
 // Exact 4-sample resolve of the queued edge pixels, stream-ordered after k_raster so the byte patches
 // land after the fast-path stores.  Persistent wavefronts pull work items (ITEM_B consecutive 64-entry
@@ -2800,9 +2386,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RES_WAVES
 // (qend), so a unit's entries are four contiguous ranges; a work item covers RES_ENVS consecutive env positions of a chunk.
 #ifndef DT_RES_NB
 #define DT_RES_NB 2
-#endif
-#ifndef DT_RO_SKIP_UNCOVERED
-#define DT_RO_SKIP_UNCOVERED 1     // uncovered object-box pixels keep the raster's colour (queue-entry bit QE_PLANE_EDGE)
 #endif
 #ifndef DT_RO_WAVES
 #define DT_RO_WAVES 4              // wavefronts per SIMD the kernel is compiled for (142 VGPRs at 3; 4 caps it at 128)
@@ -3011,11 +2594,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             if (j > 0 && g0 + j * 64 >= n_p) break;                  // wave-uniform
-#if DT_RO_SKIP_UNCOVERED
             // a pixel no mesh triangle covers, and that is no plane edge either, already holds its colour (the raster's)
             have[j] = have[j] && (pedge[j] || (tbest[j][0] & tbest[j][1] & tbest[j][2] & tbest[j][3]) >= 0);   // all four < 0  <=>  the AND is negative
             if (!__ballot(have[j])) continue;                        // wave-uniform: nothing of this batch needs shading
-#endif
             if (have[j]) {
 #ifdef DT_RO_NOSHADE
               const uint32_t v = (uint32_t)tbest[j][0] ^ (uint32_t)tbest[j][1] ^ (uint32_t)tbest[j][2] ^ (uint32_t)tbest[j][3];
@@ -3043,233 +2624,29 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #endif
 }
 
-// ---- k_resolve_clu (round 4): the object-box pixels of k_raster_v3<OBJ> / k_raster_v3dr<OBJ>, one work unit per (env, CLUSTER of
-// objects whose screen boxes overlap) instead of one per (raster tile, env) -------------------------------------------------
-// Reference: objects.py:123-148, objmesh.py:360-375 (mesh draw), graphics.py:172-251 (4x MSAA): as k_resolve_obj, same z-buffer
-// (zbuffer_chunk) and shading (shade_msaa<true>).  Why: k_resolve_obj is a chain of dependent round trips per unit (vector ALUs
-// 56 % busy, 61 % of the wavefront time in s_waitcnt) over ~ 70 k units of ~ 100 pixels per launch, each re-streaming and
-// re-culling its objects' triangles; there are only ~ 0.8 live objects per env (profiles/r04_variants_ab.txt block G).  Here a
-// WORKGROUP takes an (env, cluster, band of raster tile rows) unit from the list k_obj_setup wrote (bands bound a unit's size: a
-// close-up object is split over several workgroups): (a) the band's raster blocks whose object mask meets the
-// cluster and that hold entries of this env -> a list in LDS with the prefix sums of their entry counts (the entries of one env in
-// one region are contiguous: qend); (b) the cluster's live triangles staged ONCE in LDS; (c) the four wavefronts take 64-entry
-// batches of the concatenated ranges: entry -> pixel -> source position, "mine" = inside a member's box (the raster's test; clusters
-// are > 3 px apart), triangle-parallel cull of the staged set against the batch's pixel box -> selection list -> the pair-list
-// z-buffer on the selection -> shade -> store.  Clusters with more live triangles than CLU_TRI_CAP re-stage per round (slow, rare).
-#ifndef CLU_TRI_CAP
-#define CLU_TRI_CAP 384
-#endif
-static_assert(CLU_TRI_CAP <= 1024, "pair entries carry the staged slot in 10 bits");
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES, DT_RO_WAVES)))
-void k_resolve_clu(RenderParams R, const EnvCam* __restrict__ cams, const uint16_t* __restrict__ queue, const int32_t* __restrict__ pos) {
-  extern __shared__ uint32_t s_mem[];
-  TileLds* s_tiles = reinterpret_cast<TileLds*>(s_mem);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int npix = R.W * R.H;
-  const int tiles_x = (R.W + DT_TILE_W - 1) / DT_TILE_W, n_tiles = tiles_x * ((R.H + DT_TILE_H - 1) / DT_TILE_H), n_blk = n_tiles * 4;
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(R.tile_recs);
-    for (int i = tid; i < R.n_tile_recs * (int)(sizeof(TileLds) / 4); i += RB) s_mem[i] = src[i];
-  }
-  TriCov* s_tris = reinterpret_cast<TriCov*>(s_mem + R.n_tile_recs * (sizeof(TileLds) / 4));          // [CLU_TRI_CAP]
-  uint2* s_blk = reinterpret_cast<uint2*>(s_tris + CLU_TRI_CAP);                                       // [n_blk + 1]: {block | first entry << 16, prefix of the counts}
-  uint32_t* w_scr = reinterpret_cast<uint32_t*>(s_blk + n_blk + 1) + wave * ((RO_SCR_BYTES + CLU_TRI_CAP * 2) / 4);   // per wavefront: z-buffer scratch, then the selection list
-  uint16_t* w_sel = reinterpret_cast<uint16_t*>(w_scr + RO_SCR_BYTES / 4);
-  __shared__ int s_unit, s_nb, s_nt, s_live;
-  const int n_units = min(R.work[4], R.units_cap);
-  const float ox_mrg = 1.0f;                           // membership margin: the rasters' box margin is <= 0.95 px, clusters are > 3 px apart
-  while (true) {
-    __syncthreads();                                   // the previous unit is done with the LDS lists (and the tile records are in)
-    if (tid == 0) { s_unit = atomicAdd(R.work + 5, 1); s_nb = 0; s_nt = 0; s_live = 0; }
-    __syncthreads();
-    const int u = s_unit;
-    if (u >= n_units) break;
-    const uint4 un = R.units[u];
-    const int e = (int)un.x;
-    const unsigned long long cm = ((unsigned long long)un.z << 32) | un.y;
-    const EnvCam c = cams[e];
-    const MapU m = map_u(R.maps[c.map_id]);
-    const ScreenTri* base = R.stris + (size_t)e * R.max_tris;
-    const float4* boxes = R.tribox + (size_t)e * R.max_tris;
-    const uint2* rng = R.objrange + (size_t)c.map_id * DTSIM_MAX_OBJECTS;
-    const ObjBox* obox = R.objbox + (size_t)e * DTSIM_MAX_OBJECTS;
-    const int p = pos ? pos[e] : e, chunk = p / ENVS_PER_BLOCK, pp = p % ENVS_PER_BLOCK;
-    // (a) blocks with entries of this env whose object mask meets the cluster
-    const unsigned long long* masks = R.objmask + (size_t)p * n_blk;
-    const int band_rows = max(2, ((n_tiles / tiles_x) + 31) / 32);
-    const int b_lo = (int)un.w * band_rows * tiles_x * 4, b_hi = min(n_blk, b_lo + band_rows * tiles_x * 4);   // the unit's band of raster tile rows
-    for (int b = b_lo + tid; b < b_hi; b += RB) {
-      if (!(masks[b] & cm)) continue;
-      const uint16_t* qe = R.qend + ((size_t)(chunk * n_tiles + (b >> 2)) * 4 + (b & 3)) * ENVS_PER_BLOCK;
-      const int end = (int)qe[pp], start = pp ? (int)qe[pp - 1] : 0;
-      if (end > start) s_blk[atomicAdd(&s_nb, 1)] = make_uint2((uint32_t)b | ((uint32_t)start << 16), (uint32_t)(end - start));
-    }
-    // live triangles of the cluster (boxes only): does the set fit the staging area?
-    {
-      unsigned long long mm = cm;
-      int cnt = 0;
-      while (mm) {
-        const uint2 fc = rng[__builtin_ctzll(mm)];
-        mm &= mm - 1ull;
-        for (int t = (int)fc.x + tid; t < (int)(fc.x + fc.y); t += RB) { const float4 bb = boxes[t]; cnt += bb.x <= bb.y ? 1 : 0; }
-      }
-      if (cnt) atomicAdd(&s_live, cnt);
-    }
-    __syncthreads();
-    const int nb = s_nb, n_live = s_live;
-    if (nb == 0 || n_live == 0) continue;              // nothing queued for this cluster (workgroup-uniform)
-    // counts -> exclusive prefix sums, by wavefront 0 (64 list items per step)
-    if (wave == 0) {
-      int carry = 0;
-      for (int i0 = 0; i0 < nb; i0 += 64) {
-        const int i = i0 + lane;
-        const int cnt = i < nb ? (int)s_blk[i].y : 0;
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
-        if (i < nb) s_blk[i].y = (uint32_t)(carry + inc - cnt);
-        carry += __shfl(inc, 63);
-      }
-      if (lane == 0) s_blk[nb] = make_uint2(0u, (uint32_t)carry);
-    }
-    // (b) stage the cluster's live triangles (coverage halves), all of them when they fit
-    const bool one_pass = n_live <= CLU_TRI_CAP;
-    auto stage = [&](const int skip) {                 // the live triangles number skip .. skip + CLU_TRI_CAP - 1 in (object, index) order
-      unsigned long long mm = cm;
-      int seen0 = 0;                                   // live triangles before the current object (workgroup-uniform bookkeeping is not needed when everything fits)
-      while (mm) {
-        const uint2 fc = rng[__builtin_ctzll(mm)];
-        mm &= mm - 1ull;
-        for (int t0 = (int)fc.x; t0 < (int)(fc.x + fc.y); t0 += RB) {
-          const int t = t0 + tid;
-          bool live = false;
-          if (t < (int)(fc.x + fc.y)) { const float4 bb = boxes[t]; live = bb.x <= bb.y; }
-          if (one_pass) {
-            if (live) s_tris[atomicAdd(&s_nt, 1)] = *reinterpret_cast<const TriCov*>(base + t);
-          } else {
-            // ordered slots: rank of this live triangle among the workgroup's (ballot per wavefront + the wavefront totals in LDS)
-            __shared__ int s_wc[RB / 64];
-            const unsigned long long bm = __ballot(live);
-            if (lane == 0) s_wc[wave] = __popcll(bm);
-            __syncthreads();
-            int before = seen0;
-#pragma unroll
-            for (int q = 0; q < RB / 64; ++q) { before += q < wave ? s_wc[q] : 0; }
-            int tot = 0;
-#pragma unroll
-            for (int q = 0; q < RB / 64; ++q) tot += s_wc[q];
-            const int rank = before + __popcll(bm & ((1ull << lane) - 1ull));
-            if (live && rank >= skip && rank < skip + CLU_TRI_CAP) s_tris[rank - skip] = *reinterpret_cast<const TriCov*>(base + t);
-            seen0 += tot;
-            __syncthreads();
-          }
-        }
-      }
-      if (!one_pass && tid == 0) s_nt = min(CLU_TRI_CAP, max(0, n_live - skip));
-    };
-    if (one_pass) stage(0);
-    __syncthreads();
-    const int n = (int)s_blk[nb].y;                    // entries of the unit
-    const int n_rounds = (n + 64 * (RB / 64) - 1) / (64 * (RB / 64));
-    for (int rd = 0; rd < n_rounds; ++rd) {            // workgroup-uniform: a round = one 64-entry batch per wavefront
-      const int idx = (rd * (RB / 64) + wave) * 64 + lane;
-      bool have = idx < n;
-      // list item of the entry: the last one whose prefix is <= idx
-      int lo_ = 0, hi_ = nb - 1;
-      while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if ((int)s_blk[mid].y <= idx) lo_ = mid; else hi_ = mid - 1; }
-      const uint2 bl = s_blk[lo_];
-      const int b = (int)(bl.x & 0xFFFFu), li = (int)(bl.x >> 16) + (idx - (int)bl.y);
-      const uint16_t* w_queue = queue + ((size_t)(chunk * n_tiles + (b >> 2)) * 4 + (b & 3)) * QREGION;
-      const uint32_t ent = have ? (uint32_t)w_queue[QREGION - 1 - li] : 0u;     // object-box entries sit at the far end of the region
-      const bool pedge = (ent & QE_PLANE_EDGE) != 0u;
-      const int lp = (int)(ent & 255u);
-      const int tile = b >> 2;
-      int pix = ((tile / tiles_x) * DT_TILE_H + (b & 3) * (WAVE_PIX / WAVE_W) + lp / WAVE_W) * R.W + (tile % tiles_x) * DT_TILE_W + lp % WAVE_W;
-      if (!have) pix = 0;
-      const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
-      const float nxv = l.x, nyv = l.y;
-      const float pcx = (l.x + 1.f) * 0.5f * (float)R.W, pcy = (1.f - l.y) * 0.5f * (float)R.H;
-      // mine: inside the box of a member of the cluster (the block's entries of this env may belong to other clusters)
-      bool mine = false;
-      {
-        unsigned long long mm = cm;
-        while (mm) {                                   // workgroup-uniform
-          const ObjBox ob = obox[__builtin_ctzll(mm)];
-          mm &= mm - 1ull;
-          mine |= pcx >= ob.bx0 - ox_mrg && pcx <= ob.bx1 + ox_mrg && pcy >= ob.by0 - ox_mrg && pcy <= ob.by1 + ox_mrg;
-        }
-      }
-      have = have && mine;
-      float zbest[4] = {0.f, 0.f, 0.f, 0.f};
-      int tbest[4] = {-1, -1, -1, -1};
-      float x0 = have ? pcx : 1e30f, x1 = have ? pcx : -1e30f, y0 = have ? pcy : 1e30f, y1 = have ? pcy : -1e30f;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) {
-        x0 = fminf(x0, __shfl_xor(x0, d)); x1 = fmaxf(x1, __shfl_xor(x1, d));
-        y0 = fminf(y0, __shfl_xor(y0, d)); y1 = fmaxf(y1, __shfl_xor(y1, d));
-      }
-      for (int skip = 0; skip < n_live; skip += CLU_TRI_CAP) {   // one pass when the cluster's triangles fit (workgroup-uniform)
-        if (!one_pass) { __syncthreads(); stage(skip); __syncthreads(); }
-        const int nt = s_nt;
-        if (__ballot(have)) {
-          // triangle-parallel cull of the staged set against the batch's pixel box -> selection list
-          int nsel = 0;
-          for (int k0 = 0; k0 < nt; k0 += 64) {
-            const int k = k0 + lane;
-            bool pass = false;
-            if (k < nt) { const float4 bb = *reinterpret_cast<const float4*>(&s_tris[k]); pass = !(bb.x > x1 || bb.y < x0 || bb.z > y1 || bb.w < y0); }
-            const unsigned long long pm = __ballot(pass);
-            if (pass) w_sel[nsel + __popcll(pm & ((1ull << lane) - 1ull))] = (uint16_t)k;
-            nsel += __popcll(pm);
-          }
-          if (nsel > 0)
-            zbuffer_chunk(s_tris, w_scr, nsel, have, lane, pcx, pcy, zbest, tbest,
-#ifdef DT_RO_STATS
-                          reinterpret_cast<int32_t*>(reinterpret_cast<char*>(R.pixtab) + (size_t)R.W * R.H * 64 + 1024 + 768),
-#else
-                          nullptr,
-#endif
-                          w_sel);
-        }
-      }
-#if DT_RO_SKIP_UNCOVERED
-      have = have && (pedge || (tbest[0] & tbest[1] & tbest[2] & tbest[3]) >= 0);
-#endif
-      if (have) {
-        const uint32_t v = shade_msaa<true>(c, m, R, s_tiles, nxv, nyv, base, zbest, tbest);
-        uint8_t* dst = R.frames + ((size_t)e * npix + pix) * 3;
-        const bool odd = (reinterpret_cast<uintptr_t>(dst) & 1u) != 0u;     // two stores: an aligned half + one byte
-        uint8_t* p8 = odd ? dst : dst + 2;
-        uint16_t* p16 = reinterpret_cast<uint16_t*>(odd ? dst + 1 : dst);
-        *p8 = (uint8_t)(odd ? v : v >> 16);
-        *p16 = (uint16_t)(odd ? v >> 8 : v);
-      }
-    }
-  }
-}
-
 }  // namespace
 
 // Workgroups of `kernel` (RB threads, lds bytes of dynamic LDS) the device holds at once: the launch size of the persistent exact-path kernels.
 template <class K> static size_t resident_blocks(K kernel, size_t lds) {
   static std::mutex mu;
-  static std::map<std::pair<int, size_t>, size_t> cache;
+  static std::map<std::tuple<int, size_t, const void*>, size_t> cache;   // (the template is instantiated per function-pointer TYPE: two kernels of one signature share it)
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({dev, lds});
+  const auto key = std::make_tuple(dev, lds, reinterpret_cast<const void*>(kernel));
+  auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   int per_cu = 0, n_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RB, lds) != hipSuccess || per_cu < 1) per_cu = 3;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
   if (getenv("DTSIM_DEBUG_RESIDENT")) fprintf(stderr, "[dtsim] resident_blocks: %d workgroups per CU x %d CUs (%zu B of dynamic LDS)\n", per_cu, n_cu, lds);
-  return cache[{dev, lds}] = (size_t)per_cu * (size_t)n_cu;
+  return cache[key] = (size_t)per_cu * (size_t)n_cu;
 }
 
 // One range of chunks through its raster (stream s) and exact-path kernels (stream s_res, after event ev when it is
 // another stream): the whole batch, or one of dt_launch_render's render parts (every array already moved to the range).
 static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t ev, const RenderParams& R, EnvCam* cams, EnvFast* fasts, EnvQ* envq,
-                                  EnvV* envv, EnvD* envd, uint8_t* frames_raster, bool quad, bool v3, bool v3dr, bool obj, bool use_clu, bool has_pos, const int32_t* pos_map) {
+                                  EnvV* envv, EnvD* envd, uint8_t* frames_raster, bool quad, bool v3, bool v3dr, bool obj, bool has_pos) {
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const size_t lds = (size_t)R.n_tile_recs * sizeof(TileLds);
   const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
@@ -3292,20 +2669,16 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
       const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
 #define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, frames_raster, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
-#if DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1
       if (obj) LAUNCH_V3(true); else
-#endif
       LAUNCH_V3(false);
 #undef LAUNCH_V3
     } else if (obj) { if (s256) LAUNCH_Q(true, true); else LAUNCH_Q(true, false); }
     else { if (s256) LAUNCH_Q(false, true); else LAUNCH_Q(false, false); }
 #undef LAUNCH_Q
-#if DT_V3_DR
   } else if (v3dr) {
     const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
     if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
     else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
-#endif
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
@@ -3320,11 +2693,7 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
       const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve, lds2)));
       hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s_res, R, cams, R.queue, R.qcount);
     }
-    if (obj && use_clu) {
-      const size_t n_blk = dt_raster_tiles(R.W, R.H) * 4;
-      const size_t lds5 = lds + (size_t)CLU_TRI_CAP * sizeof(TriCov) + (n_blk + 1) * sizeof(uint2) + (size_t)(RB / 64) * (RO_SCR_BYTES + CLU_TRI_CAP * 2);
-      hipLaunchKernelGGL(k_resolve_clu, dim3(256 * 3), dim3(RB), lds5, s_res, R, cams, R.queue, pos_map);
-    } else if (obj) {
+    if (obj) {
       const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
       const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve_obj<DT_RES_NB>, lds4)));
       hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s_res, R, cams, R.queue, 1, has_pos ? envq : (const EnvQ*)nullptr);
@@ -3342,36 +2711,20 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   EnvD* envd = reinterpret_cast<EnvD*>(R.envd);
   // domain randomisation on the quad records (k_raster_v3dr): same table / texture conditions as k_raster_v3
   const bool v3dr = R.qtex && R.envd && R.domain_rand && !R.segment && !R.no_msaa && (R.W & 3) == 0 && R.qlog2 == 8 && R.q3_rows > 0 &&
-                    R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_DR;
+                    R.q3_rows <= 24 && R.n_maps * 32 <= 128;
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
   // (S = 256 tables carry the v_perm cell selector of the S256 kernels, which need a padded grid under 256 tiles)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
                     !(R.qlog2 == 8 && R.qmax_tiles >= 256);
   const bool obj = R.max_tris > 0;
-  // object layers are read by k_raster_v3<OBJ> / k_raster_v3dr<OBJ> only: off for every other raster (they queue every box pixel)
-  {
-    const bool v3_obj = quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1;
-    if (!DT_OBJ_LAYERS || !(obj && (v3_obj || v3dr)) || !R.objlayer || !R.layers || (R.W & 3) != 0) R.layer_cap = 0;
-  }
-  // k_resolve_clu (units per (env, object cluster)) behind the rasters that share its 128 x 2 block / queue layout; DTSIM_RESOLVE_OBJ_OLD=1: k_resolve_obj
-  static const bool clu_off = [] { const char* v = getenv("DTSIM_RESOLVE_OBJ_OLD"); return v && v[0] == '1'; }();
-  const bool use_clu = DT_RESOLVE_CLU && !clu_off && obj && R.units && R.tribox && R.objmask && DT_WAVE_W == 128 &&
-                       ((quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= 24 && R.n_maps * 32 <= 128 && DT_V3_WW == DT_WAVE_W && DT_V3_MAP != 1) || v3dr);
-  if (!use_clu) R.units = nullptr;
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
   int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
-#if !DT_ENV_SORT
-  // (index order: round 3's choice, when the sorted order was 4 - 5 % slower -- neighbours in the order look at the same scene, so the
-  // slow blocks of a frame piled up in the same workgroups and on one XCD.  With round 4's kernel the two orders run at the same
-  // speed and the sorted one halves the L2 fills: FETCH_SIZE 2.15 -> 1.00 GB raw per pass, profiles/r04_variants_ab.txt block I.)
-  pos = nullptr;
-#endif
   if (pos) { hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos); tables |= 4; }
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
                      v3dr ? envd : nullptr, R.W, R.H);
-  (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj / k_resolve_clu (k_obj_setup appends units)
+  (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * sizeof(int32_t), s);            // work-item counts + cursors of k_resolve / k_resolve_obj
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
@@ -3380,7 +2733,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
 
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
   const bool v3 = quad && R.qlog2 == 8 && R.q3_rows > 0 && R.q3_rows <= V3_MAX_ROWS && R.n_maps * V3_MAP_COLS <= V3_TAB_PITCH / 2 &&
-                  (!obj || (DT_V3_WW == WAVE_W && DT_V3_MAP != 1));
+                  true;
   if (quad && !(tables & 1)) {
     PixTab* pixtab = reinterpret_cast<PixTab*>(R.pixtab);
     SampTab* samptab = reinterpret_cast<SampTab*>(pixtab + (size_t)R.W * R.H);
@@ -3393,8 +2746,8 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   // kernels are the same; only the paths whose positions are chunk-separable are split: k_raster_v3 in the sorted render
   // order (env-indexed arrays stay whole) and k_raster_v3dr (position = env: every per-env array moves).
   int parts = 1;
-  if (ov && ov->parts > 1 && !R.no_msaa && !use_clu && ((v3 && pos) || v3dr) && (obj || !quad)) parts = std::min(std::min(ov->parts, DT_MAX_RENDER_PARTS), n_chunks / 8);
-  if (parts <= 1) { launch_raster_resolve(s, s, nullptr, R, cams, fasts, envq, envv, envd, R.frames, quad, v3, v3dr, obj, use_clu, pos != nullptr, pos); return tables; }
+  if (ov && ov->parts > 1 && !R.no_msaa && ((v3 && pos) || v3dr) && (obj || !quad)) parts = std::min(std::min(ov->parts, DT_MAX_RENDER_PARTS), n_chunks / 8);
+  if (parts <= 1) { launch_raster_resolve(s, s, nullptr, R, cams, fasts, envq, envv, envd, R.frames, quad, v3, v3dr, obj, pos != nullptr); return tables; }
   static const bool parts_serial = [] { const char* v = getenv("DTSIM_RENDER_PARTS_SERIAL"); return v && v[0] == '1'; }();   // experiment: the split without the overlap
   const size_t n_tiles = dt_raster_tiles(R.W, R.H), n_blk = n_tiles * 4, npix = (size_t)R.W * R.H;
   (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * parts * sizeof(int32_t), s);
@@ -3419,7 +2772,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
       if (R.tribox) Rp.tribox = R.tribox + e0 * R.max_tris;
       if (R.objbox) Rp.objbox = R.objbox + e0 * DTSIM_MAX_OBJECTS;
     }
-    launch_raster_resolve(s, parts_serial ? s : ov->s2, ov->ev[p], Rp, cams_p, fasts_p, envq_p, envv_p, envd_p, R.frames, quad, v3, v3dr, obj, false, pos != nullptr, nullptr);
+    launch_raster_resolve(s, parts_serial ? s : ov->s2, ov->ev[p], Rp, cams_p, fasts_p, envq_p, envv_p, envd_p, R.frames, quad, v3, v3dr, obj, pos != nullptr);
   }
   (void)hipEventRecord(ov->ev[DT_MAX_RENDER_PARTS], ov->s2);
   (void)hipStreamWaitEvent(s, ov->ev[DT_MAX_RENDER_PARTS], 0);

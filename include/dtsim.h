@@ -352,7 +352,11 @@ int dtsim_bind_frames(dtsim_t* h, void* devptr);
  * librccl.so is resolved with dlopen at the first call -- the library has no link-time dependency on it, and the
  * call fails with DTSIM_E_STATE where it is absent.  `send` = NULL gathers the frame batch; otherwise `send` /
  * `send_bytes` name another device buffer of this rank to gather instead (e.g. the dtsim_observe output: 57.6 KB per
- * env at 160 x 120 instead of 921.6 KB).  The host-side exchange of dtsim/sharding.py (torch.distributed) does not use it. */
+ * env at 160 x 120 instead of 921.6 KB).  ORDERING: the collective is ordered behind earlier work on the HANDLE's stream only.
+ * `recv` (and a caller-owned `send`) must be ready on that stream when the call is made -- a buffer another stream is still
+ * filling or zeroing must be synchronised first (host wait, or an event the handle's stream waits on: dtsim_stream()); readers on
+ * another stream wait for the handle's stream likewise.  dtsim/sharding.py: ShardedSimulator.gather_frames() uses this entry point
+ * on RCCL jobs (events both ways, no host wait). */
 int dtsim_allgather_frames(dtsim_t* h, void* nccl_comm, void* recv, const void* send, size_t send_bytes);
 
 /* Learner-side observation of the rendered frame batch, on the device (what the reference's learners do
