@@ -137,7 +137,7 @@ struct alignas(16) EnvQ {
   uint32_t sky[3];             // the horizon colour as the three dwords of four consecutive pixels (RGBR GBRG BRGB)
   uint32_t reach;              // cells from the camera to the border of the padded grid: hits closer than that need no clamp
   uint32_t env;                // the env (frame index) at this position of the render order (k_env_sort)
-  uint32_t pad[2];
+  uint32_t pad[2];             // [0]: k_raster_v3's LDS column offset of the map, [1]: quad cells per metre (float bits)
 };
 static_assert(sizeof(EnvQ) == 64, "EnvQ is 64 bytes");
 // k_raster_v3's per-env constants, in render order: the transform as PAIRS (the scalar operand of a v_pk_fma_f32 is two
@@ -332,7 +332,7 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
       const float r = fminf(fminf(q.Cx, xmax - q.Cx), fminf(q.Cz, zmax - q.Cz)) - 2.f;
       q.reach = r > 0.f ? (uint32_t)fminf(r, 1.0e9f) : 0u;      // NaN / outside the padded grid -> 0: always clamp
     }
-    q.env = (uint32_t)e; q.pad[1] = 0u;
+    q.env = (uint32_t)e; q.pad[1] = __float_as_uint(m.inv_tile_size * S);   // quad cells per metre of the env's map (the exact path's ground-quad test)
     q.pad[0] = (uint32_t)c.map_id * (32u * 4u);     // k_raster_v3: byte offset of the map's columns inside an LDS table row (V3_MAP_COLS entries)
     envq[pos ? pos[e] : e] = q;
     if (envv) {
@@ -342,7 +342,7 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
       envv[pos ? pos[e] : e] = v;
       if (e == A.N - 1) envv[A.N] = v;               // the entry past the end (prefetched, never used)
     }
-    if (envd) fill_envd_at(envd, e, c, q, m, S, H, W);   // domain randomisation on the quad records (index = env: no sort there)
+    if (envd) fill_envd_at(envd, pos ? pos[e] : e, c, q, m, S, H, W);   // domain randomisation on the quad records (index = position in the render order)
   }
 }
 
@@ -1437,7 +1437,7 @@ struct alignas(16) PixTab { float lr, lf, lit; uint32_t mi; };
 // places it to 5e-4 of that footprint; for pixels whose centre ray misses the planes the offsets are the hits
 // themselves).  flags: bit s = sample s hits the tile plane within [near, far], bit 4+s = it hits the ground plane
 // within [near, far] (ground hit = kg * tile-plane hit).
-struct alignas(16) SampTab { uint32_t dlr[2], dlf[2]; uint32_t flags; uint32_t pad[3]; };
+struct alignas(16) SampTab { uint32_t dlr[2], dlf[2]; uint32_t flags; uint32_t pad[3]; };   // pad: lr, lf, lit of the PixTab (float bits)
 static_assert(sizeof(PixTab) == 16 && sizeof(SampTab) == 32, "table records");
 
 __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixTab* __restrict__ pixtab, SampTab* __restrict__ samptab) {
@@ -1481,7 +1481,7 @@ __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixT
     sp.dlr[j] = (uint32_t)__half_as_ushort(__float2half_rn(dlr[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(dlr[2 * j + 1])) << 16);
     sp.dlf[j] = (uint32_t)__half_as_ushort(__float2half_rn(dlf[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(dlf[2 * j + 1])) << 16);
   }
-  sp.pad[0] = sp.pad[1] = sp.pad[2] = 0u;
+  sp.pad[0] = __float_as_uint(t.lr); sp.pad[1] = __float_as_uint(t.lf); sp.pad[2] = __float_as_uint(t.lit);   // the PixTab's hit and lit factor once more: phase 2 of the exact path reads ONE table
   samptab[pix] = sp;
 }
 
@@ -1636,8 +1636,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
         qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
         qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
-        if (V3) qb[u].z = fq->pad[0];
-        env[u] = (int)fq->env;
+        const uint4 qd = *reinterpret_cast<const uint4*>(&fq->reach);   // reach, env, pad[0], pad[1] (one 16-byte piece: the path is bound by its vector-memory instruction count)
+        if (V3) qb[u].z = qd.z;
+        env[u] = (int)qd.y;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1688,8 +1689,10 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       const bool have = l0 + lane < n_list;
       const uint32_t le = have ? w_list[l0 + lane] : 0u;
       const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
-      const PixTab pt = pixtab[pix];
       const SampTab sp = samptab[pix];
+      PixTab pt;
+      if constexpr (V3) { pt.lr = __uint_as_float(sp.pad[0]); pt.lf = __uint_as_float(sp.pad[1]); pt.lit = __uint_as_float(sp.pad[2]); pt.mi = 0u; }   // (one table, two 16-byte loads)
+      else pt = pixtab[pix];
       const EnvQ* fq = envq + min(e0 + el, R.N - 1);
       if constexpr (V3) {
         // k_raster_v3's version (round 3): no list of distinct primitives.  The colour of a pixel is the sum over its four
@@ -1698,14 +1701,16 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         // tile: the blocks share one cell grid; a sample that is not on a tile reads the all-zero record 0) to one
         // accumulator per channel -- 6 v_dot4 per sample, exact -- and sky / ground samples add their colour once per
         // count.  Tile look-ups go by v_perm like the env loop's; the +-50 m ground-quad test is made in quad coordinates.
+        // the env's constants as three 16-byte pieces (round 5: the exact path is bound by the NUMBER of vector-memory instructions it issues)
         const float4 qa = *reinterpret_cast<const float4*>(&fq->A);
-        const float A = qa.x, B = qa.y, Cx = qa.z, Cz = qa.w, Xhi = fq->Xhi, Zhi = fq->Zhi;
-        const uint32_t tab = fq->pad[0];
-        const int e = (int)fq->env;
-        const EnvCam* c = cams + e;
-        const float wCy = c->Cy;
+        const uint4 qb = *reinterpret_cast<const uint4*>(&fq->Xhi), qd = *reinterpret_cast<const uint4*>(&fq->reach);
+        const float A = qa.x, B = qa.y, Cx = qa.z, Cz = qa.w, Xhi = __uint_as_float(qb.x), Zhi = __uint_as_float(qb.y);
+        const uint32_t tab = qd.z;
+        const int e = (int)qd.y;
+        const float4* c4 = reinterpret_cast<const float4*>(cams + e);   // EnvCam as 16-byte pieces: [2] = {ty, hor[3]}, [3] = {gnd[3], base0}, [4] = {base1, base2, dif0, dif1}, [5] = {dif2, L..}, [6] = {L3, gndl[0..2]}, [7] = {gndl3, ..}
+        const float wCy = default_cam((float)R.W / (float)R.H).Cy;      // shared camera: the same height for every env (what k_cam_setup wrote)
         const float kg = (wCy - GROUND_Y) / wCy;
-        const float qpm = R.maps[c->map_id].inv_tile_size * Sf;            // quad cells per metre of the env's map
+        const float qpm = __uint_as_float(qd.w);                           // quad cells per metre of the env's map
         const float goff = (float)DT_QRING * Sf + 0.5f, ghalf = GROUND_HALF * qpm;   // world 0 and 50 m in padded quad coordinates
         const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
         const uint32_t xic = (uint32_t)flr_i32(Xu), zic = (uint32_t)flr_i32(Zu);
@@ -1756,16 +1761,22 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
           aH[2] = __builtin_amdgcn_udot4(rec.z, wh, aH[2], false); aL[2] = __builtin_amdgcn_udot4(rec.z, wl, aL[2], false);
         }
         float acc[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] = fmaf((float)n_sky, c->hor[k], (float)((aH[k] << 8) + aL[k]) * (1.f / 65535.f));
+        float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (__ballot(n_sky > 0)) hc = c4[2];           // wave-uniform: the horizon colour only where some sample sees the sky
+        acc[0] = fmaf((float)n_sky, hc.y, (float)((aH[0] << 8) + aL[0]) * (1.f / 65535.f));
+        acc[1] = fmaf((float)n_sky, hc.z, (float)((aH[1] << 8) + aL[1]) * (1.f / 65535.f));
+        acc[2] = fmaf((float)n_sky, hc.w, (float)((aH[2] << 8) + aL[2]) * (1.f / 65535.f));
         if (__ballot(n_gnd > 0)) {                     // wave-uniform: shade the ground quad (lit at its corners, bilinear)
           if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) { gX = fmaf(kg, Xu - Cx, Cx); gZ = fmaf(kg, Zu - Cz, Cz); }   // the centre ray hits the planes
           const float hs = 0.5f / ghalf;
           const float a_ = fminf(fmaxf(fmaf(gX - goff, hs, 0.5f), 0.f), 1.f), b_ = fminf(fmaxf(fmaf(gZ - goff, hs, 0.5f), 0.f), 1.f);
-          const float n0 = c->gndl[0] + a_ * (c->gndl[1] - c->gndl[0]), n1 = c->gndl[2] + a_ * (c->gndl[3] - c->gndl[2]);
+          const float4 q3 = c4[3], q4 = c4[4], q5 = c4[5], q6 = c4[6], q7 = c4[7];
+          const float n0 = q6.y + a_ * (q6.z - q6.y), n1 = q6.w + a_ * (q7.x - q6.w);
           const float ndl = n0 + b_ * (n1 - n0);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) acc[k] += (float)n_gnd * (c->gnd[k] * fminf(c->base[k] + c->dif[k] * ndl, 1.f));
+          const float ng = (float)n_gnd;
+          acc[0] += ng * (q3.x * fminf(q3.w + q4.z * ndl, 1.f));
+          acc[1] += ng * (q3.y * fminf(q4.x + q4.w * ndl, 1.f));
+          acc[2] += ng * (q3.z * fminf(q4.y + q5.x * ndl, 1.f));
         }
         const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
         if (have) store_rgb(e, pix, pack_rgb(o));
@@ -2677,8 +2688,8 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
 #undef LAUNCH_Q
   } else if (v3dr) {
     const size_t ldsd = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * RQ_LIST * 4;
-    if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
-    else hipLaunchKernelGGL((k_raster_v3dr<false>), grid, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+    if (obj) hipLaunchKernelGGL((k_raster_v3dr<true>), gridq, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+    else hipLaunchKernelGGL((k_raster_v3dr<false>), gridq, dim3(RB), ldsd, s, R, cams, envd, frames_raster, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
   } else if (R.domain_rand || R.segment) { if (obj) LAUNCH_RASTER(true, true); else LAUNCH_RASTER(true, false); }   // per-env EnvCam path
   else { if (obj) LAUNCH_RASTER(false, true); else LAUNCH_RASTER(false, false); }
 #undef LAUNCH_RASTER
@@ -2689,7 +2700,11 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
     if (s_res != s && (obj || !quad)) { (void)hipEventRecord(ev, s); (void)hipStreamWaitEvent(s_res, ev, 0); }
     // persistent wavefronts pulling work items: enough workgroups to fill every CU at the kernel's occupancy
     // (round 4: EXACTLY the resident workgroups -- every wavefront's first grab is static, a workgroup that waits for a slot would sit on its items)
-    if (!quad) {
+    if (v3dr) {                                        // plane-edge pixels of k_raster_v3dr: on the quad records, through the env's homography
+      const size_t ldsr = (size_t)R.q3_rows * V3_TAB_PITCH * 4;
+      const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve_dr, ldsr)));
+      hipLaunchKernelGGL(k_resolve_dr, rgrid, dim3(RB), ldsr, s_res, R, cams, envd, R.qtex, reinterpret_cast<const float4*>(R.lut), R.qtiles, R.queue, R.qcount);
+    } else if (!quad) {
       const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve, lds2)));
       hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s_res, R, cams, R.queue, R.qcount);
     }
@@ -2719,7 +2734,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   const bool obj = R.max_tris > 0;
   // render order (k_env_sort): the quad pipeline indexes by position (EnvQ, object masks, queue entries); env ids come
   // from EnvQ.env
-  int32_t* pos = (quad && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
+  int32_t* pos = ((quad || v3dr) && R.envpos && A.N > ENVS_PER_BLOCK) ? R.envpos : nullptr;   // one chunk: the order does not matter
   if (pos) { hipLaunchKernelGGL(k_env_sort, dim3(1), dim3(1024), 0, s, A, R.maps, pos); tables |= 4; }
   hipLaunchKernelGGL(k_cam_setup, dim3((A.N + 63) / 64), dim3(64), 0, s, A, R.domain_rand, R.segment,
                      (float)R.W / (float)R.H, cams, fasts, R.maps, (quad || v3dr) ? envq : nullptr, R.qlog2, pos, quad ? envv : nullptr,
@@ -2743,13 +2758,12 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   // Render parts (DTSIM_RENDER_PARTS = P > 1): the chunks of the batch in P ranges; the raster of range p + 1 on the
   // caller's stream runs beside the exact-path kernels of range p on a second stream (they wait on memory, the raster on
   // the vector ALU and the L1).  Every per-position array is addressed relative to the range's first chunk, so the
-  // kernels are the same; only the paths whose positions are chunk-separable are split: k_raster_v3 in the sorted render
-  // order (env-indexed arrays stay whole) and k_raster_v3dr (position = env: every per-env array moves).
+  // kernels are the same; only the quad-record paths in the sorted render order are split (k_raster_v3, k_raster_v3dr).
   int parts = 1;
-  if (ov && ov->parts > 1 && !R.no_msaa && ((v3 && pos) || v3dr) && (obj || !quad)) parts = std::min(std::min(ov->parts, DT_MAX_RENDER_PARTS), n_chunks / 8);
+  if (ov && ov->parts > 1 && !R.no_msaa && (v3 || v3dr) && pos && (obj || !quad)) parts = std::min(std::min(ov->parts, DT_MAX_RENDER_PARTS), n_chunks / 8);
   if (parts <= 1) { launch_raster_resolve(s, s, nullptr, R, cams, fasts, envq, envv, envd, R.frames, quad, v3, v3dr, obj, pos != nullptr); return tables; }
   static const bool parts_serial = [] { const char* v = getenv("DTSIM_RENDER_PARTS_SERIAL"); return v && v[0] == '1'; }();   // experiment: the split without the overlap
-  const size_t n_tiles = dt_raster_tiles(R.W, R.H), n_blk = n_tiles * 4, npix = (size_t)R.W * R.H;
+  const size_t n_tiles = dt_raster_tiles(R.W, R.H), n_blk = n_tiles * 4;
   (void)hipMemsetAsync(R.work, 0, DT_WORK_INTS * parts * sizeof(int32_t), s);
   for (int p = 0; p < parts; ++p) {
     const int c0 = (int)((long long)n_chunks * p / parts), c1 = (int)((long long)n_chunks * (p + 1) / parts);
@@ -2763,16 +2777,10 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
     if (R.qend) Rp.qend = R.qend + wg0 * (RB / 64) * ENVS_PER_BLOCK;
     Rp.items = R.items + wg0 * ITEMS_PER_WG;
     Rp.items2 = R.items2 + wg0 * ENVS_PER_BLOCK;
-    EnvCam* cams_p = cams; EnvFast* fasts_p = fasts; EnvD* envd_p = envd;
-    EnvQ* envq_p = envq + e0; EnvV* envv_p = envv ? envv + e0 : nullptr;
-    if (!quad) {                                       // position = env
-      cams_p += e0; fasts_p += e0; if (envd) envd_p += e0;
-      Rp.frames = R.frames + e0 * npix * 3;            // (k_raster_v3dr stores by the env id of its EnvD record: it gets the whole array)
-      if (R.stris) Rp.stris = R.stris + e0 * R.max_tris;
-      if (R.tribox) Rp.tribox = R.tribox + e0 * R.max_tris;
-      if (R.objbox) Rp.objbox = R.objbox + e0 * DTSIM_MAX_OBJECTS;
-    }
-    launch_raster_resolve(s, parts_serial ? s : ov->s2, ov->ev[p], Rp, cams_p, fasts_p, envq_p, envv_p, envd_p, R.frames, quad, v3, v3dr, obj, pos != nullptr);
+    // per-POSITION arrays move to the range (EnvQ / EnvV / EnvD in render order, masks, queues, items above); per-ENV arrays (EnvCam, frames,
+    // screen triangles, object boxes) stay whole: the kernels reach them through the env id of the position's record
+    EnvQ* envq_p = envq + e0; EnvV* envv_p = envv ? envv + e0 : nullptr; EnvD* envd_p = envd ? envd + e0 : nullptr;
+    launch_raster_resolve(s, parts_serial ? s : ov->s2, ov->ev[p], Rp, cams, fasts, envq_p, envv_p, envd_p, R.frames, quad, v3, v3dr, obj, true);
   }
   (void)hipEventRecord(ov->ev[DT_MAX_RENDER_PARTS], ov->s2);
   (void)hipStreamWaitEvent(s, ov->ev[DT_MAX_RENDER_PARTS], 0);
