@@ -71,6 +71,9 @@ struct dtsim {
   double* d_qpose = nullptr;
   dtsim_probe* d_qout = nullptr;
   dtsim_agent_info* d_agent = nullptr;
+  bool rendered = false;          // a render pass has written the per-env cameras (dtsim_draw_lines needs them)
+  float* d_lines = nullptr;       // dtsim_draw_lines: device copy of the caller's segments
+  int lines_cap = 0;
   int render_tables = 0;          // dt_launch_render: which env-invariant tables are valid (camera LUT + maps unchanged)
   RenderOverlap overlap{};        // render parts (DTSIM_RENDER_PARTS > 1): second stream + ordering events
   int q_cap = 0;
@@ -305,7 +308,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab, h->d_lines};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->overlap.s2) { (void)hipStreamSynchronize(h->overlap.s2); (void)hipStreamDestroy(h->overlap.s2); }
   for (hipEvent_t ev : h->overlap.ev) if (ev) (void)hipEventDestroy(ev);
@@ -904,6 +907,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     h->render_tables = dt_launch_render(h->stream, h->A, R, h->render_tables, h->overlap.parts > 1 ? &h->overlap : nullptr);
   }
   HIPCHK(hipGetLastError());
+  h->rendered = true;
 #ifdef DT_WAVE_SPANS
   if (R.spans) {   // the spans of the last render -> the file DTSIM_WAVE_SPANS names (tools/wave_spans.py reads it)
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -960,6 +964,39 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     fprintf(stderr, "[dtsim] exact-path pixels: %lld of %zu (%.2f%%), max per wavefront region %lld\n", tot, npix * h->N,
             100.0 * tot / (double)(npix * h->N), mx);
   }
+  return DTSIM_OK;
+}
+
+int dtsim_draw_lines(dtsim_t* h, const float* lines, const int32_t* env_idx, int n) {
+  if (!h || (n > 0 && !lines)) return fail(DTSIM_E_INVALID, "null argument");
+  if (n < 0) return fail(DTSIM_E_INVALID, "n = %d", n);
+  if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  if (!h->have_maps || !h->have_reset || !h->have_lut || !h->rendered) return fail(DTSIM_E_STATE, "dtsim_draw_lines before the first dtsim_render (the pass writes the cameras the lines go through)");
+  if (n == 0) return DTSIM_OK;
+  for (int i = 0; i < n; ++i) {
+    const int e = env_idx ? env_idx[i] : 0;
+    if (e < 0 || e >= h->N) return fail(DTSIM_E_INVALID, "env_idx[%d] = %d out of range [0, %d)", i, e, h->N);
+    if (env_idx && i && env_idx[i] < env_idx[i - 1]) return fail(DTSIM_E_INVALID, "env_idx must be non-decreasing (segments grouped by env)");
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->lines_cap < n) {
+    if (h->d_lines) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; }
+    h->lines_cap = std::max(n, 1024);
+    HIPCHK(hipMalloc(&h->d_lines, sizeof(float) * 9 * (size_t)h->lines_cap));
+  }
+  HIPCHK(hipMemcpyAsync(h->d_lines, lines, sizeof(float) * 9 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  RenderParams R{};
+  R.N = h->N; R.W = h->cfg.cam_width; R.H = h->cfg.cam_height; R.frames = h->frames; R.lut = h->d_lut; R.envcam = h->d_envcam;
+  int i0 = 0;
+  while (i0 < n) {                                    // one launch per env that has segments
+    const int e = env_idx ? env_idx[i0] : 0;
+    int i1 = i0;
+    while (i1 < n && (env_idx ? env_idx[i1] : 0) == e) ++i1;
+    dt_launch_overlay_lines(h->stream, R, h->d_lines, i0, i1 - i0, e);
+    i0 = i1;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));           // `lines` is pageable host memory: the copy must have left it
   return DTSIM_OK;
 }
 

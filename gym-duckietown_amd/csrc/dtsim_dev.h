@@ -243,6 +243,9 @@ struct RenderParams {
 #define DT_WORK_INTS 8           // RenderParams.work: ints per render part
 struct RenderOverlap { int parts; hipStream_t s2; hipEvent_t ev[DT_MAX_RENDER_PARTS + 1]; };
 int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, int tables, const RenderOverlap* ov = nullptr);
+// GL_LINE overlays (draw_curve / draw_bbox) as a post-pass on the resolved frame of `env`: d_lines = [..][9] world-space segments + colour
+// (device memory), `count` of them from `first` on; uses the EnvCam the last render wrote.
+void dt_launch_overlay_lines(hipStream_t s, const RenderParams& R, const float* d_lines, int first, int count, int env);
 
 #ifndef DT_OBS_STAGE_ROWS
 #define DT_OBS_STAGE_ROWS 8

@@ -2635,7 +2635,115 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #endif
 }
 
+
+// ---- k_overlay_lines: the reference's GL_LINE overlays as a post-pass on the resolved frames --------------------------------------
+// draw_curve (simulator.py:1886-1904, graphics.py:336-349: the lane curves of every drivable tile, 19 segments each, the one most aligned
+// with the heading red, the others blue) and draw_bbox (simulator.py:1907-1918, objects.py:131-146: the collision rectangles of the
+// objects and of the agent at y = 0.01, red).  The host states the segments in WORLD space (dtsim_draw_lines); here every segment is
+// taken through the env's camera (EnvCam: shared or domain-randomised), clipped at the near plane, and rasterised as GL rasterises a
+// 1-pixel line under multisampling: the rectangle of width 1 px around the projected segment, coverage per MSAA sample.  The pass works on
+// the RESOLVED frame, per OUTPUT pixel (its source pixel comes from the LUT, so the fisheye remap is honoured): a pixel with n of its four
+// samples covered becomes ((4 - n) frame + sum of the covering lines' colours) / 4 -- what the multisample resolve gives when the line is
+// the nearest thing in the pixel.  Documented deviations from the GL state machine: lines are not depth-tested against
+// mesh objects (they lie 1 cm above the tile plane: in front of tiles and ground always); their colour is the glColor lit as a surface
+// with normal +y (GL_COLOR_MATERIAL, the normal the tile draw leaves behind), the texel of whatever texture is still bound is not applied;
+// where two lines cover one sample the first in the list wins (depth func LESS on equal depths).
+struct OvSeg { float ax, ay, bx, by, inv_len2, r, g, b; };     // projected segment in source-pixel space, lit colour 0..255
+__global__ __launch_bounds__(256) void k_overlay_lines(RenderParams R, const EnvCam* __restrict__ cams, const float* __restrict__ lines,
+                                                       const int first, const int count, const int env) {
+  __shared__ OvSeg s_seg[256];
+  const int tid = threadIdx.x;
+  const int pix = blockIdx.x * 256 + tid;
+  const EnvCam c = cams[env];
+  float sxp = 0.f, syp = 0.f;
+  bool live = false;
+  if (pix < R.W * R.H) {
+    const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
+    live = l.z != 0.f;
+    sxp = (l.x + 1.f) * 0.5f * (float)R.W; syp = (1.f - l.y) * 0.5f * (float)R.H;       // centre of the source pixel
+  }
+  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  float acc[3] = {0.f, 0.f, 0.f};
+  uint32_t covered = 0u;
+  for (int base = 0; base < count; base += 256) {
+    __syncthreads();
+    {                                                  // stage up to 256 projected segments
+      OvSeg sg; sg.ax = sg.ay = sg.bx = sg.by = 0.f; sg.inv_len2 = -1.f; sg.r = sg.g = sg.b = 0.f;
+      if (base + tid < count) {
+        const float* L = lines + (size_t)(first + base + tid) * 9;
+        float pe[2][3], lit[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const float rx = L[3 * v] - c.Cx, ry = L[3 * v + 1] - c.Cy, rz = L[3 * v + 2] - c.Cz;
+          const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
+          pe[v][0] = xla; pe[v][1] = ry * c.cth - zla * c.sth; pe[v][2] = ry * c.sth + zla * c.cth;      // eye space, -z forward
+        }
+        float w0 = -pe[0][2], w1 = -pe[1][2];
+        const float wn = NEAR_Z * 1.0001f;
+        bool ok = !(w0 < wn && w1 < wn);
+        if (ok && (w0 < wn || w1 < wn)) {              // clip the end behind the near plane
+          const int vb = w0 < wn ? 0 : 1, vf = 1 - vb;
+          const float t = (wn - (-pe[vb][2])) / ((-pe[vf][2]) - (-pe[vb][2]));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pe[vb][k] += t * (pe[vf][k] - pe[vb][k]);
+          w0 = -pe[0][2]; w1 = -pe[1][2];
+        }
+        if (ok) {
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {                // lit as a surface with world normal +y: eye-space normal (0, cth, sth)
+            float ndl;
+            if (c.L[3] == 0.f) ndl = c.cth * c.L[1] + c.sth * c.L[2];
+            else {
+              const float lx = c.L[0] - pe[v][0], ly = c.L[1] - pe[v][1], lz = c.L[2] - pe[v][2];
+              ndl = (c.cth * ly + c.sth * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+            }
+            lit[v] = fmaxf(ndl, 0.f);
+          }
+          const float ndl = 0.5f * (lit[0] + lit[1]);  // one colour per segment: the light at its middle
+          sg.ax = (pe[0][0] / w0 / c.tx + 1.f) * 0.5f * (float)R.W; sg.ay = (1.f - pe[0][1] / w0 / c.ty) * 0.5f * (float)R.H;
+          sg.bx = (pe[1][0] / w1 / c.tx + 1.f) * 0.5f * (float)R.W; sg.by = (1.f - pe[1][1] / w1 / c.ty) * 0.5f * (float)R.H;
+          const float dx = sg.bx - sg.ax, dy = sg.by - sg.ay, l2 = dx * dx + dy * dy;
+          sg.inv_len2 = l2 > 1e-12f ? 1.f / l2 : -1.f;
+          sg.r = 255.f * fminf(L[6] * (c.base[0] + c.dif[0] * ndl), 1.f);
+          sg.g = 255.f * fminf(L[7] * (c.base[1] + c.dif[1] * ndl), 1.f);
+          sg.b = 255.f * fminf(L[8] * (c.base[2] + c.dif[2] * ndl), 1.f);
+        }
+      }
+      s_seg[tid] = sg;
+    }
+    __syncthreads();
+    if (!live) continue;
+    const int n = min(256, count - base);
+    for (int i = 0; i < n; ++i) {
+      const OvSeg sg = s_seg[i];
+      if (sg.inv_len2 < 0.f) continue;
+      if (sxp < fminf(sg.ax, sg.bx) - 1.f || sxp > fmaxf(sg.ax, sg.bx) + 1.f || syp < fminf(sg.ay, sg.by) - 1.f || syp > fmaxf(sg.ay, sg.by) + 1.f) continue;
+      const float dx = sg.bx - sg.ax, dy = sg.by - sg.ay;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float qx = sxp + ox[q] - sg.ax, qy = syp + oy[q] - sg.ay;
+        const float u = (qx * dx + qy * dy) * sg.inv_len2;                       // along the segment, 0..1
+        const float cr = qx * dy - qy * dx;                                      // |cross| = distance x length
+        const bool in = u >= 0.f && u <= 1.f && cr * cr * sg.inv_len2 <= 0.25f;   // within half a pixel of the line
+        if (in && !((covered >> q) & 1u)) { covered |= 1u << q; acc[0] += sg.r; acc[1] += sg.g; acc[2] += sg.b; }
+      }
+    }
+  }
+  if (live && covered) {
+    const float nf = (float)(4 - __popc(covered));
+    uint8_t* dst = R.frames + ((size_t)env * R.W * R.H + pix) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst[k] = (uint8_t)(fminf(fmaxf(0.25f * (nf * (float)dst[k] + acc[k]), 0.f), 255.f) + 0.5f);
+  }
+}
+
 }  // namespace
+
+void dt_launch_overlay_lines(hipStream_t s, const RenderParams& R, const float* d_lines, int first, int count, int env) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_overlay_lines, dim3((unsigned)((R.W * R.H + 255) / 256)), dim3(256), 0, s, R, reinterpret_cast<const EnvCam*>(R.envcam), d_lines, first, count, env);
+}
 
 // Workgroups of `kernel` (RB threads, lds bytes of dynamic LDS) the device holds at once: the launch size of the persistent exact-path kernels.
 template <class K> static size_t resident_blocks(K kernel, size_t lds) {

@@ -41,7 +41,7 @@ EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_step_ex", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_allgather_frames", "dtsim_observe", "dtsim_observe_cubic", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read_agent", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_draw_lines", "dtsim_allgather_frames", "dtsim_observe", "dtsim_observe_cubic", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read_agent", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -182,6 +182,7 @@ def load(path: str | None = None):
         "dtsim_frames_bytes": (sz, [vp]),
         "dtsim_bind_frames": (ci, [vp, vp]),
         "dtsim_allgather_frames": (ci, [vp, vp, vp, vp, C.c_size_t]),
+        "dtsim_draw_lines": (ci, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), ci]),
         "dtsim_set_reset_sampler": (ci, [vp, C.POINTER(ResetSampler)]),
         "dtsim_reset_done": (ci, [vp]),
         "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),

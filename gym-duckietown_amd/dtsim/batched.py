@@ -446,6 +446,22 @@ class BatchedSimulator:
         ptr = self._lib.dtsim_frames_devptr(self._h)
         return DeviceArray(ptr, (self.num_envs, self.camera_height, self.camera_width, 3), "|u1", self)
 
+    def draw_lines(self, lines, env_idx=None):
+        """GL_LINE overlays (the reference's draw_curve / draw_bbox) as a post-pass on the frames of the last render():
+        lines [n, 9] = world-space segment (ax, ay, az, bx, by, bz) + colour (r, g, b in 0..1); env_idx [n] (non-decreasing) or None =
+        env 0.  dtsim_draw_lines (include/dtsim.h)."""
+        a = np.ascontiguousarray(np.asarray(lines, dtype=np.float32).reshape(-1, 9))
+        n = a.shape[0]
+        if n == 0:
+            return
+        ip = None
+        if env_idx is not None:
+            ei = np.ascontiguousarray(np.asarray(env_idx, dtype=np.int32).reshape(-1))
+            if ei.shape[0] != n:
+                raise ValueError("env_idx needs one entry per segment")
+            ip = ei.ctypes.data_as(C.POINTER(C.c_int32))
+        _ffi.check(self._lib, self._lib.dtsim_draw_lines(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), ip, int(n)))
+
     def bind_frames(self, devptr: Optional[int]):
         _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
 

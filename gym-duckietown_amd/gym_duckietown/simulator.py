@@ -12,8 +12,9 @@ It is an N=1 view of dtsim.BatchedSimulator: every number comes from the GPU ker
 `render(mode)` returns the 800x600 window image of every mode (agent camera, `free_cam`, `top_down`) from a second
 handle that copies the state; `segment=True` is the segmentation render.
 
-Not provided (out of scope): the pyglet window itself (nothing is displayed), the `draw_bbox` /
-`draw_curve` line overlays, LEDs, `camera_rand`'s carnivalmirror calibration sampling.
+`draw_curve` / `draw_bbox` (round 5): the GL_LINE overlays as a post-pass on the resolved frame (`dtsim_draw_lines`; draw_bbox also switches
+to the reference's debugging camera 0.8 m above the robot).  Not provided (out of scope): the pyglet window itself (nothing
+is displayed), LEDs, `camera_rand`'s carnivalmirror calibration sampling.
 """
 from __future__ import annotations
 
@@ -104,9 +105,9 @@ class Simulator(_EnvBase):
                  camera_rand: bool = False, randomize_maps_on_reset: bool = False, num_tris_distractors: int = 12,
                  color_ground: Sequence[float] = (0.15, 0.15, 0.15), color_sky: Sequence[float] = BLUE_SKY,
                  style: str = "photos", enable_leds: bool = False, device: int = 0, **env_kwargs):
-        if draw_curve or draw_bbox or enable_leds or camera_rand:
-            raise NotImplementedError("draw_curve / draw_bbox / enable_leds / camera_rand "
-                                      "are outside the hot path this backend implements")
+        if enable_leds or camera_rand:
+            raise NotImplementedError("enable_leds (additively blended gluSpheres) / camera_rand (carnivalmirror calibration sampling) "
+                                      "are outside the path this backend implements")
         self.enable_leds = enable_leds
         self.seed_value = seed
         self.num_tris_distractors = num_tris_distractors
@@ -353,9 +354,69 @@ class Simulator(_EnvBase):
         return obs, d.reward, d.done, misc
 
     def render_obs(self, segment: bool = False) -> np.ndarray:
-        """simulator.py:1953-1972; `segment=True` is the segmentation render (:1730-1737, 1753, 1808, 1879)."""
+        """simulator.py:1953-1972; `segment=True` is the segmentation render (:1730-1737, 1753, 1808, 1879).
+        draw_curve / draw_bbox (:1776-1778, 1886-1918): the GL_LINE overlays are a post-pass on the resolved frame
+        (dtsim_draw_lines); with draw_bbox the view is the reference's debugging camera 0.8 m above the robot, looking down."""
+        if self.draw_bbox:
+            v = self._viewer(False, (self.camera_width, self.camera_height))
+            self._sync_viewer(v, top_down=False, bbox=True)
+            v.render(segment=bool(segment))
+            v.draw_lines(self._overlay_lines())
+            return v.frames_host()[0]
         self._sim.render(segment=bool(segment))
+        if self.draw_curve:
+            self._sim.draw_lines(self._overlay_lines())
         return self._sim.frames_host()[0]
+
+    # ---------------------------------------------------------------- GL_LINE overlays --
+    def _overlay_lines(self) -> np.ndarray:
+        """World-space segments [n, 9] of the reference's line overlays, in its draw order.
+        draw_curve (simulator.py:1886-1904): per drivable tile (row-major) the curve whose chord has the largest dot product with the
+        heading first, red, then the tile's other curves, blue -- bezier_draw (graphics.py:336-349): 20 points, 19 segments, at the
+        height of the control points.  draw_bbox (:1907-1918, objects.py:131-139): the collision rectangle of every visible object,
+        then the agent's, at y = 0.01, red."""
+        out = []
+        ang = float(self.cur_angle)
+        if self.draw_curve:
+            dir_vec = get_dir_vec(ang)
+            ts = np.arange(20, dtype=np.float64) / 19.0
+            for tile in self.grid:
+                if tile is None or not tile["drivable"]:
+                    continue
+                curves = np.asarray(tile["curves"], dtype=np.float64)
+                heads = curves[:, -1, :] - curves[:, 0, :]
+                heads = heads / np.linalg.norm(heads).reshape(1, -1)           # (the reference's scalar norm: the argmax is unaffected)
+                best = int(np.argmax(np.dot(heads, dir_vec)))
+                for idx in [best] + [i for i in range(len(curves)) if i != best]:
+                    cps = curves[idx]
+                    pts = np.stack([bezier_point(cps, t) for t in ts])
+                    col = (1.0, 0.0, 0.0) if idx == best else (0.0, 0.0, 1.0)
+                    for a, b in zip(pts[:-1], pts[1:]):
+                        out.append([*a, *b, *col])
+        if self.draw_bbox:
+            vis = self._sim.read(_ffi.FIELD_OBJ_VISIBLE)[0]
+            cen, yrot = self._sim.read(_ffi.FIELD_OBJ_CENTER)[0], self._sim.read(_ffi.FIELD_OBJ_YROT)[0]
+            loops = []
+            for k, o in enumerate(self.objects):
+                if not vis[k]:
+                    continue
+                c = np.asarray(o.corners, dtype=np.float64).reshape(4, 2)
+                if o.dyn_slot >= 0:
+                    now = np.array([cen[o.dyn_slot, 0], cen[o.dyn_slot, 1]])
+                    if o.dyn_kind == 1:                                    # DuckieObj: the rectangle moves with the centre (objects.py:400-403)
+                        c = c + (now - np.array([o.pos[0], o.pos[2]]))
+                    else:                                                  # DuckiebotObj / CheckerboardObj: regenerated at the new pose (collision.py:64-79)
+                        th = math.radians(float(yrot[o.dyn_slot]))
+                        mn, mx, sc = o.min_coords, o.max_coords, o.scale
+                        raw = [(mn[0] * sc, mn[2] * sc), (mx[0] * sc, mn[2] * sc), (mx[0] * sc, mx[2] * sc), (mn[0] * sc, mx[2] * sc)]
+                        c = np.array([[now[0] + x * math.cos(th) + z * math.sin(th), now[1] - x * math.sin(th) + z * math.cos(th)] for x, z in raw])
+                loops.append(c)
+            loops.append(get_agent_corners(self.cur_pos, ang))
+            for c in loops:
+                for i in range(4):
+                    a, b = c[i], c[(i + 1) % 4]
+                    out.append([a[0], 0.01, a[1], b[0], 0.01, b[1], 1.0, 0.0, 0.0])
+        return np.asarray(out, dtype=np.float32).reshape(-1, 9)
 
     def render(self, mode: str = "human", close: bool = False, segment: bool = False):
         """simulator.py:1974-2053: the WINDOW_WIDTH x WINDOW_HEIGHT view of the current state -- the agent camera
@@ -366,17 +427,21 @@ class Simulator(_EnvBase):
         if close:
             return
         v = self._viewer(self.distortion and mode != "free_cam")
-        self._sync_viewer(v, top_down=(mode == "top_down"))
+        self._sync_viewer(v, top_down=(mode == "top_down"), bbox=self.draw_bbox and mode != "top_down")
         v.render(segment=bool(segment))
+        if self.draw_curve or self.draw_bbox:
+            v.draw_lines(self._overlay_lines())
         return v.frames_host()[0]
 
     # ------------------------------------------------------------------ viewer --
-    def _viewer(self, distortion: bool):
+    def _viewer(self, distortion: bool, size=None):
         """A second one-env handle at the window size that renders copies of this env's state: same map and assets,
         per-env camera enabled (so a top-down pose can be given to it), plus one extra non-static duckiebot that
         stands for `self.mesh` in the top-down view (hidden otherwise)."""
         import copy
-        v = self._viewers.get(bool(distortion)) if hasattr(self, "_viewers") else None
+        size = (WINDOW_WIDTH, WINDOW_HEIGHT) if size is None else (int(size[0]), int(size[1]))
+        vkey = (bool(distortion), size)
+        v = self._viewers.get(vkey) if hasattr(self, "_viewers") else None
         if v is not None:
             return v
         if not hasattr(self, "_viewers"):
@@ -395,14 +460,14 @@ class Simulator(_EnvBase):
                 marker["height"] = 0.12                               # the stand-in meshes are unit-height blobs
             objs.append(marker)
         md["objects"] = objs
-        v = BatchedSimulator(self._sim._ctor_map_names[self._map_idx], 1, map_data=md, camera_width=WINDOW_WIDTH, camera_height=WINDOW_HEIGHT,
+        v = BatchedSimulator(self._sim._ctor_map_names[self._map_idx], 1, map_data=md, camera_width=size[0], camera_height=size[1],
                              distortion=bool(distortion), domain_rand=True, seed=0, max_steps=self.max_steps,
                              frame_rate=self.frame_rate, device=self._sim._device, style=self.style,
                              asset_root=self._sim.library.root, do_reset=False)
-        self._viewers[bool(distortion)] = v
+        self._viewers[vkey] = v
         return v
 
-    def _sync_viewer(self, v, top_down: bool):
+    def _sync_viewer(self, v, top_down: bool, bbox: bool = False):
         import ctypes as C
         st = (_ffi.InitState * 1)()
         C.memmove(st, C.byref(self._sim.init_states[0]), C.sizeof(_ffi.InitState))
@@ -420,6 +485,12 @@ class Simulator(_EnvBase):
             s0.cam_height = h_from_floor
             s0.cam_angle_deg = math.degrees(math.atan2(h_from_floor, 0.01))
             s0.camera_noise[:] = [0.0, 0.0, 0.0]
+        elif bbox:                                                    # draw_bbox (:1776-1778): y += 0.8, glRotatef(90, 1, 0, 0), no forward offset
+            d = get_dir_vec(float(ang))
+            s0.pos[:] = [float(pos[0]) - CAMERA_FORWARD_DIST * d[0], 0.0, float(pos[2]) - CAMERA_FORWARD_DIST * d[2]]
+            s0.angle = float(ang)
+            s0.cam_height = 0.8
+            s0.cam_angle_deg = 90.0
         else:
             s0.pos[:] = [float(pos[0]), 0.0, float(pos[2])]
             s0.angle = float(ang)
@@ -556,6 +627,12 @@ class Simulator(_EnvBase):
 
 
 # ---- module-level helpers of the reference (simulator.py:2056-2116) ------------------
+def bezier_point(cps, t):
+    """graphics.py:286-295: cubic Bezier point of the control points [4, 3] at t."""
+    cps = np.asarray(cps, dtype=np.float64)
+    return (1 - t) ** 3 * cps[0] + 3 * t * (1 - t) ** 2 * cps[1] + 3 * t ** 2 * (1 - t) * cps[2] + t ** 3 * cps[3]
+
+
 def get_dir_vec(cur_angle: float) -> np.ndarray:
     return np.array([math.cos(cur_angle), 0, -math.sin(cur_angle)])
 

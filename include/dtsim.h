@@ -339,6 +339,13 @@ int dtsim_set_segment_assets(dtsim_t* h, const dtsim_texture* textures, int n_te
 enum { DTSIM_RENDER_SEGMENT = 1u };
 /* dtsim_render with flags (DTSIM_RENDER_*); dtsim_render(h) == dtsim_render_ex(h, 0). */
 int dtsim_render_ex(dtsim_t* h, uint32_t flags);
+/* GL_LINE overlays of the reference -- draw_curve (simulator.py:1886-1904, graphics.py:336-349) and draw_bbox (simulator.py:1907-1918,
+ * objects.py:131-146) -- as a post-pass on the frames the last dtsim_render made: `lines` = [n][9] floats, world-space segment
+ * (ax, ay, az, bx, by, bz) + colour (r, g, b in 0..1, the glColor3f of the line); env_idx[i] = the env segment i is drawn into (NULL: all
+ * into env 0; must be non-decreasing).  Each segment goes through the env's camera, is clipped at the near plane and rasterised as a
+ * 1-pixel line under 4x multisampling (coverage per sample, first line wins a sample); the colour is the glColor lit as a surface with
+ * normal +y.  Lines are not depth-tested against mesh objects (they lie above the tile plane).  Synchronous (host segments). */
+int dtsim_draw_lines(dtsim_t* h, const float* lines, const int32_t* env_idx, int n);
 void* dtsim_frames_devptr(dtsim_t* h);
 size_t dtsim_frames_bytes(const dtsim_t* h);
 /* Render into caller-owned device memory instead (e.g. a torch tensor that is the

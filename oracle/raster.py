@@ -364,9 +364,64 @@ def distort(img_u8, rmapx, rmapy):
     return out
 
 
-def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None):
-    """Simulator.render_obs (simulator.py:1953-1972): uint8 [H,W,3]."""
+def overlay_lines(img_u8, cam, lines):
+    """The GL_LINE overlays of the reference on the RESOLVED rectilinear image (uint8 [H,W,3]): draw_curve (simulator.py:1886-1904,
+    graphics.py:336-349) and draw_bbox (simulator.py:1907-1918, objects.py:131-146).  `lines`: [n, 9] world-space segments
+    (ax, ay, az, bx, by, bz) + glColor (r, g, b in 0..1).  One documented interpretation (the GL state at those draw calls is whatever
+    the previous call left behind -- PARITY UNPINNED): a segment is clipped at the near plane, projected, and covers the MSAA samples
+    within half a pixel of it (the 1-px line rectangle of multisample rasterisation); its colour is the glColor lit as a surface with
+    normal +y at the segment's middle (GL_COLOR_MATERIAL); the first line in the list wins a sample; a pixel with n covered samples
+    becomes ((4 - n) pixel + sum of the covering colours) / 4, rounded -- no depth test against meshes.  What the HIP post-pass
+    k_overlay_lines does, in float64."""
+    H, W = img_u8.shape[:2]
+    out = img_u8.astype(np.float64)
+    cov = np.zeros((H, W, 4), bool)
+    acc = np.zeros((H, W, 3))
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64) + 0.5, np.arange(H, dtype=np.float64) + 0.5)
+    n_eye = np.array([0.0, cam.cth, cam.sth])
+    for L in np.asarray(lines, dtype=np.float64).reshape(-1, 9):
+        pe = cam.to_eye(np.stack([L[0:3], L[3:6]]))
+        w = -pe[:, 2]
+        wn = NEAR * 1.0001
+        if w[0] < wn and w[1] < wn:
+            continue
+        if w[0] < wn or w[1] < wn:
+            vb = 0 if w[0] < wn else 1
+            vf = 1 - vb
+            t = (wn - w[vb]) / (w[vf] - w[vb])
+            pe[vb] = pe[vb] + t * (pe[vf] - pe[vb])
+            w = -pe[:, 2]
+        ndl = 0.5 * (cam.ndl(pe[0], n_eye) + cam.ndl(pe[1], n_eye))
+        col = 255.0 * np.minimum(L[6:9] * (cam.base + cam.dif * ndl), 1.0)
+        ax, ay = (pe[0, 0] / w[0] / cam.tx + 1) * 0.5 * W, (1 - pe[0, 1] / w[0] / cam.ty) * 0.5 * H
+        bx, by = (pe[1, 0] / w[1] / cam.tx + 1) * 0.5 * W, (1 - pe[1, 1] / w[1] / cam.ty) * 0.5 * H
+        dx, dy = bx - ax, by - ay
+        l2 = dx * dx + dy * dy
+        if l2 <= 1e-12:
+            continue
+        x0, x1 = max(int(math.floor(min(ax, bx) - 1.5)), 0), min(int(math.ceil(max(ax, bx) + 1.5)), W - 1)
+        y0, y1 = max(int(math.floor(min(ay, by) - 1.5)), 0), min(int(math.ceil(max(ay, by) + 1.5)), H - 1)
+        if x0 > x1 or y0 > y1:
+            continue
+        px, py = cols[y0:y1 + 1, x0:x1 + 1], rows[y0:y1 + 1, x0:x1 + 1]
+        for q, (ox, oy) in enumerate(SAMPLE_OFFSETS):
+            qx, qy = px + ox - ax, py + oy - ay
+            u = (qx * dx + qy * dy) / l2
+            cr = qx * dy - qy * dx
+            inside = (u >= 0) & (u <= 1) & (cr * cr / l2 <= 0.25) & ~cov[y0:y1 + 1, x0:x1 + 1, q]
+            cov[y0:y1 + 1, x0:x1 + 1, q] |= inside
+            acc[y0:y1 + 1, x0:x1 + 1] += inside[..., None] * col
+    n = cov.sum(axis=-1)
+    hit = n > 0
+    out[hit] = 0.25 * ((4 - n[hit])[:, None] * out[hit] + acc[hit])
+    return to_u8(out)
+
+
+def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None, lines=None):
+    """Simulator.render_obs (simulator.py:1953-1972): uint8 [H,W,3]; `lines`: draw_curve / draw_bbox overlays (overlay_lines)."""
     img = to_u8(render_rectilinear(cam, scene, lighting, obj_states))
+    if lines is not None and len(lines):
+        img = overlay_lines(img, cam, lines)
     if rmap is not None:
         img = distort(img, rmap[0], rmap[1])
     return img
