@@ -483,7 +483,10 @@ __device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
 }
 
 
-__global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
+#ifndef DT_OBJSETUP_T
+#define DT_OBJSETUP_T 256           // threads of a k_obj_setup workgroup (one workgroup per env)
+#endif
+__global__ __launch_bounds__(DT_OBJSETUP_T) void k_obj_setup(SimArrays A, RenderParams R, const EnvCam* __restrict__ cams, const int32_t* __restrict__ pos) {
   const int e = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t N = A.N;
@@ -497,16 +500,64 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     s_obox[tid][0] = s_obox[tid][2] = 0x7fffffff;    // min slots
     s_obox[tid][1] = s_obox[tid][3] = (int)0x80000000;   // max slots
   }
-  __syncthreads();
-  int obj = 0, obj_first = 0;              // walk the object list as t grows (t is monotone per thread)
-  for (int t = tid; t < m.n_tris; t += 256) {
-    ObjInstDev oi = R.objs[m.obj_off + obj];
-    int nt = oi.mesh_id >= 0 ? R.meshes[oi.mesh_id].n_tris : 0;
-    while (t >= obj_first + nt) {
-      obj_first += nt; ++obj;
-      oi = R.objs[m.obj_off + obj];
-      nt = oi.mesh_id >= 0 ? R.meshes[oi.mesh_id].n_tris : 0;
+  // Round 5: object-level frustum cull first.  An env sees ~ 1 of its map's objects (profiles/r04_variants_ab.txt block G: 0.8 live objects per
+  // env); an object whose model-space box, taken through the instance and the camera, lies wholly outside one frustum plane (or is invisible)
+  // contributes no triangle: its triangles are neither loaded nor transformed nor written -- nothing reads them, the object's screen box
+  // stays empty and so it appears in no block mask (k_resolve_obj streams the triangles of masked objects only).
+  __shared__ uint8_t s_objlive[DTSIM_MAX_OBJECTS];
+  __shared__ int s_nt[DTSIM_MAX_OBJECTS], s_first[DTSIM_MAX_OBJECTS + 1];   // triangles of each object, and before it (the walks below read LDS, not dependent global loads)
+  if (tid < DTSIM_MAX_OBJECTS) {
+    bool livef = false;
+    s_nt[tid] = 0;
+    if (tid < m.n_obj) {
+      const ObjInstDev oi = R.objs[m.obj_off + tid];
+      s_nt[tid] = oi.mesh_id >= 0 ? R.meshes[oi.mesh_id].n_tris : 0;
+      if (oi.mesh_id >= 0 && A.ob_visible[(size_t)tid * N + e] != 0) {
+        const MeshDev md = R.meshes[oi.mesh_id];
+        float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
+        if (oi.dyn_slot >= 0) {
+          px = (float)A.ob_cx[(size_t)oi.dyn_slot * N + e]; pz = (float)A.ob_cz[(size_t)oi.dyn_slot * N + e];
+          py += (float)A.ob_cy[(size_t)oi.dyn_slot * N + e];
+          yrot = (float)A.ob_yrot[(size_t)oi.dyn_slot * N + e];
+        }
+        const float ang = yrot * 0.017453292519943295f;
+        const float co = cosf(ang), so = sinf(ang);
+        uint32_t all_out = 0x1Fu;                       // bit set while every corner so far is outside that plane: near, left, right, bottom, top
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float mx = ((k & 1) ? md.mx[0] : md.mn[0]) * oi.scale, my = ((k & 2) ? md.mx[1] : md.mn[1]) * oi.scale, mz = ((k & 4) ? md.mx[2] : md.mn[2]) * oi.scale;
+          const float rx = (mx * co + mz * so + px) - c.Cx, ry = (my + py) - c.Cy, rz = (-mx * so + mz * co + pz) - c.Cz;
+          const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
+          const float xe = xla, ye = ry * c.cth - zla * c.sth, w = -(ry * c.sth + zla * c.cth);
+          // the four side planes pass through the eye: xe + w tx >= 0 ... are half-spaces for any sign of w; two pixels of slack (the
+          // triangle boxes are padded by DT_TRI_PAD)
+          const float lx = w * c.tx, ly = w * c.ty, sx_ = fabsf(w) * c.tx * (4.f / (float)R.W), sy_ = fabsf(w) * c.ty * (4.f / (float)R.H);
+          uint32_t o = 0u;
+          if (w <= NEAR_Z) o |= 1u;
+          if (xe < -lx - sx_) o |= 2u;
+          if (xe > lx + sx_) o |= 4u;
+          if (ye < -ly - sy_) o |= 8u;
+          if (ye > ly + sy_) o |= 16u;
+          all_out &= o;
+        }
+        livef = all_out == 0u;
+      }
     }
+    s_objlive[tid] = livef ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int o = 0; o < m.n_obj; ++o) { s_first[o] = acc; acc += s_nt[o]; }
+    s_first[m.n_obj] = acc;
+  }
+  __syncthreads();
+  int obj = 0;                             // walk the object list as t grows (t is monotone per thread)
+  for (int t = tid; t < m.n_tris; t += DT_OBJSETUP_T) {
+    while (obj + 1 < m.n_obj && t >= s_first[obj + 1]) ++obj;
+    if (!s_objlive[obj]) continue;        // the whole object is out of view (or invisible)
+    const int obj_first = s_first[obj];
+    const ObjInstDev oi = R.objs[m.obj_off + obj];
     const TriDev td = R.tris[R.meshes[oi.mesh_id].off + (t - obj_first)];
     float px = oi.x, py = oi.y, pz = oi.z, yrot = oi.yrot_deg;
     if (oi.dyn_slot >= 0) {               // DuckieObj: pos = center, y_rot wiggles (objects.py:408-410)
@@ -582,10 +633,8 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
   __syncthreads();
   if (tid < m.n_obj) {                      // per-object screen box = union of its live triangles' boxes
     ObjBox ob;
-    ob.first = 0; ob.pad[0] = ob.pad[1] = 0;
-    for (int o = 0; o < tid; ++o) { const int mid = R.objs[m.obj_off + o].mesh_id; ob.first += mid >= 0 ? R.meshes[mid].n_tris : 0; }
-    const int mid = R.objs[m.obj_off + tid].mesh_id;
-    const int cnt = mid >= 0 ? R.meshes[mid].n_tris : 0;
+    ob.first = s_first[tid]; ob.pad[0] = ob.pad[1] = 0;
+    const int cnt = s_nt[tid];
     const bool live = s_obox[tid][0] != 0x7fffffff;
     ob.bx0 = live ? ord2f(s_obox[tid][0]) : 1e30f; ob.bx1 = live ? ord2f(s_obox[tid][1]) : -1e30f;
     ob.by0 = live ? ord2f(s_obox[tid][2]) : 1e30f; ob.by1 = live ? ord2f(s_obox[tid][3]) : -1e30f;
@@ -599,11 +648,15 @@ __global__ __launch_bounds__(256) void k_obj_setup(SimArrays A, RenderParams R, 
     // raster reads one 8-byte mask per (env, block) instead of walking the env's object boxes
     const int n_blk = ((R.W + DT_TILE_W - 1) / DT_TILE_W) * ((R.H + DT_TILE_H - 1) / DT_TILE_H) * 4;
     const float4* bbx = reinterpret_cast<const float4*>(R.blockbox);
-    for (int b = tid; b < n_blk; b += 256) {
+    unsigned long long livem = 0ull;                 // objects with a live screen box (usually one or none)
+    for (int o = 0; o < m.n_obj; ++o) livem |= s_oboxf[o][0] <= s_oboxf[o][1] ? 1ull << o : 0ull;
+    for (int b = tid; b < n_blk; b += DT_OBJSETUP_T) {
       const float4 bb = bbx[b];                      // x0, x1, y0, y1
       unsigned long long mk = 0ull;
-      for (int o = 0; o < m.n_obj; ++o)
+      for (unsigned long long lm = livem; lm; lm &= lm - 1ull) {
+        const int o = __builtin_ctzll(lm);
         if (!(bb.y < s_oboxf[o][0] || bb.x > s_oboxf[o][1] || bb.w < s_oboxf[o][2] || bb.z > s_oboxf[o][3])) mk |= 1ull << o;
+      }
       R.objmask[(size_t)(pos ? pos[e] : e) * n_blk + b] = mk;   // indexed by position in the render order
     }
   }
@@ -2851,7 +2904,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   if (R.max_tris > 0) {
     if (!(tables & 2)) hipLaunchKernelGGL(k_blk_setup, dim3((unsigned)dt_raster_tiles(R.W, R.H)), dim3(RB), 0, s, R, reinterpret_cast<const float4*>(R.lut), reinterpret_cast<float4*>(R.blockbox));
     tables |= 2;
-    hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(256), 0, s, A, R, cams, pos);
+    hipLaunchKernelGGL(k_obj_setup, dim3(A.N), dim3(DT_OBJSETUP_T), 0, s, A, R, cams, pos);
   }
 
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
