@@ -466,6 +466,8 @@ def main():
                 subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.DEVNULL)
             except Exception:
                 guard["marker"] = None
+        if os.environ.get("DTSIM_BENCH_DIE_IN_GATHER") == "1" and rank == 0:
+            os._exit(17)                           # test hook: what a crash inside the exchange looks like (tests/test_gpu_bench_two_ranks.py)
         frames = torch.as_tensor(sim.frames_device(), device=dev)
         rccl = dist.get_backend() == "nccl"
         rdev = dev if rccl else "cpu"                   # where the control-plane scalars of this leg live
