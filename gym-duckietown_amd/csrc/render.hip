@@ -2469,10 +2469,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
   }
   __syncthreads();
   uint32_t* s_wave = s_mem + R.n_tile_recs * (sizeof(TileLds) / 4);
-  EnvCam* w_cams = reinterpret_cast<EnvCam*>(s_wave) + wave * RES_ENVS;                            // wavefront-local
-  TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + wave * TRI_CAP;
-  uint32_t* w_scr = reinterpret_cast<uint32_t*>(reinterpret_cast<TriCov*>(s_wave + (RB / 64) * RES_ENVS * (sizeof(EnvCam) / 4)) + (RB / 64) * TRI_CAP) +
-                    wave * (RO_SCR_BYTES / 4);       // z-buffer scratch of the pair schedule
+  static_assert(RES_ENVS == 1, "a work item is ONE (raster tile, env) unit: everything about it is wave-uniform");
+  TriCov* w_tris = reinterpret_cast<TriCov*>(s_wave) + wave * TRI_CAP;                             // wavefront-local
+  uint32_t* w_scr = reinterpret_cast<uint32_t*>(reinterpret_cast<TriCov*>(s_wave) + (RB / 64) * TRI_CAP) + wave * (RO_SCR_BYTES / 4);   // z-buffer scratch of the pair schedule
   const int n_front = R.work[2], n_items = n_front + R.work[6];   // written by the raster launch (push_obj_items): heavy items first
   const size_t items_cap = obj_items_cap(R);
   auto item_at = [&](int i) -> uint32_t { return R.items2[i < n_front ? (size_t)i : items_cap - 1 - (size_t)(i - n_front)]; };
@@ -2481,7 +2480,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
 #endif
   const int grab = max(1, min(GRAB_MAX, n_items / (int)(gridDim.x * (RB / 64) * 4)));
   const int n_grabs = (n_items + grab - 1) / grab;
-  auto env_at = [&](int p) -> int { return envq ? (int)envq[p].env : p; };   // position in the render order -> env
   const int n_waves = (int)gridDim.x * (RB / 64);     // first grab = the wavefront's own index, as in k_resolve
   bool first_grab = true;
   while (true) {
@@ -2492,72 +2490,55 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
     }
     first_grab = false;
     if (g >= n_grabs) break;
-    // Round 4: the item loop is software-pipelined -- the id of the item after next and the queue fills (qend) of the next
-    // item are loaded while the current one is processed: the kernel is a chain of dependent round trips per (tile, env)
-    // unit (profiles/r04_variants_ab.txt block G), these were two of them.
+    // The item loop is software-pipelined: everything a unit needs before it can touch its entries -- the id of the item after next, and for
+    // the NEXT item its four entry ranges (the fills of the regions after env p and after env p - 1: eight 16-bit loads on eight lanes), the
+    // frame index of its position and the object masks of its four blocks -- is loaded while the current unit is processed.  Round 5: a
+    // unit is one env, so all of this is wave-uniform; the per-item staging of 32 envs' fills, 32 envs' masks and the EnvCam copy through
+    // LDS (with its barrier) are gone: that chain of dependent round trips was ~ 280 of the kernel's 600 us (profiles/r05_variants_ab.txt, block H).
     static_assert(RB / 64 == 4, "four regions per raster workgroup");
-    auto load_qend = [&](uint32_t item_, int endv_[4]) {
-      const int rwg_ = (int)(item_ / ITEMS_PER_WG);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) endv_[r] = lane < ENVS_PER_BLOCK ? (int)R.qend[((size_t)rwg_ * 4 + r) * ENVS_PER_BLOCK + lane] : 0;
+    auto prefetch = [&](const uint32_t item_, uint32_t& qv, int& ev, unsigned long long& hv) {
+      const int rwg_ = (int)(item_ / ITEMS_PER_WG), p_ = (int)(item_ % ITEMS_PER_WG);
+      const int tile_ = rwg_ % n_tiles, pos_ = min((rwg_ / n_tiles) * ENVS_PER_BLOCK + p_, R.N - 1);
+      qv = 0u;                                          // lane 2r: fill of region r after env p, lane 2r + 1: after env p - 1 (= where p's entries start)
+      if (lane < 8) { const int pp = p_ - (lane & 1); if (pp >= 0) qv = R.qend[((size_t)rwg_ * 4 + (lane >> 1)) * ENVS_PER_BLOCK + pp]; }
+      ev = envq ? (int)envq[pos_].env : pos_;           // position in the render order -> env (one address for the wavefront)
+      hv = 0ull;
+      if (lane < 4) hv = R.objmask[((size_t)pos_ * n_tiles + tile_) * 4 + lane];
     };
     uint32_t item_cur = item_at(g), item_nxt = g + n_grabs < n_items ? item_at(g + n_grabs) : 0u;
-    int endv_nxt[4];
-    load_qend(item_cur, endv_nxt);
+    uint32_t qv_nxt; int ev_nxt; unsigned long long hv_nxt;
+    prefetch(item_cur, qv_nxt, ev_nxt, hv_nxt);
     for (int it = g; it < n_items; it += n_grabs) {  // wave-uniform
       const uint32_t item = item_cur;
-      int endv[4], startv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) endv[r] = endv_nxt[r];
+      const uint32_t qv = qv_nxt;
+      const int ev = ev_nxt;
+      const unsigned long long hv = hv_nxt;
       item_cur = item_nxt;
-      if (it + n_grabs < n_items) load_qend(item_cur, endv_nxt);
+      if (it + n_grabs < n_items) prefetch(item_cur, qv_nxt, ev_nxt, hv_nxt);
       item_nxt = it + 2 * n_grabs < n_items ? item_at(it + 2 * n_grabs) : 0u;
-      const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG) * RES_ENVS;
+      const int rwg = (int)(item / ITEMS_PER_WG), p0 = (int)(item % ITEMS_PER_WG);
       const int tile = rwg % n_tiles, chunk = rwg / n_tiles;
       const int e0 = chunk * ENVS_PER_BLOCK;
       const int ne = min(ENVS_PER_BLOCK, R.N - e0);
       if (p0 >= ne) continue;
-      // per-region entry ranges of the chunk's envs: lane l <-> position e0 + l
-      bool any = false;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int up = __shfl_up(endv[r], 1);
-        startv[r] = lane == 0 ? 0 : up;
-        any |= endv[r] != startv[r];
-      }
-      if (!__ballot(any && lane >= p0 && lane < p0 + RES_ENVS)) continue;   // nothing queued for these envs
-      {  // the item's EnvCams -> wavefront-private LDS (64 bytes per lane; DS ops of one wavefront are ordered)
-        static_assert(sizeof(EnvCam) == 128, "two 64-byte slices per EnvCam");
-        if (lane < 2 * RES_ENVS && p0 + (lane >> 1) < ne) {
-          const uint4* src = reinterpret_cast<const uint4*>(cams + env_at(e0 + p0 + (lane >> 1))) + (lane & 1) * 4;
-          uint4* dst = reinterpret_cast<uint4*>(w_cams) + lane * 4;
-          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-        }
-      }
-      // object masks of the chunk's envs for the four blocks of this raster tile (OR: the unit spans all four)
-      uint32_t mk_lo = 0u, mk_hi = 0u;
-      if (lane < ne) {
-        const unsigned long long* mp = R.objmask + ((size_t)(e0 + lane) * n_tiles + tile) * 4;
-        const unsigned long long v = mp[0] | mp[1] | mp[2] | mp[3];
-        mk_lo = (uint32_t)v; mk_hi = (uint32_t)(v >> 32);
-      }
       const int tile_x0 = (tile % tiles_x) * DT_TILE_W, tile_y0 = (tile / tiles_x) * DT_TILE_H;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #ifdef DT_WAVE_SPANS
       const unsigned long long span_i0 = wall_clock64(); ++span_n;
 #endif
-      for (int p = p0; p < min(p0 + RES_ENVS, ne); ++p) {   // wave-uniform: one (tile, env) unit
+      {                                                // the (tile, env) unit
+        const int p = p0;
         int c_[4], s_[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s_[r] = __builtin_amdgcn_readlane(startv[r], p); c_[r] = __builtin_amdgcn_readlane(endv[r], p) - s_[r]; }
+        for (int r = 0; r < 4; ++r) { s_[r] = __builtin_amdgcn_readlane((int)qv, 2 * r + 1); c_[r] = __builtin_amdgcn_readlane((int)qv, 2 * r) - s_[r]; }
         const int t1 = c_[0], t2 = t1 + c_[1], t3 = t2 + c_[2], n_p = t3 + c_[3];
         if (n_p == 0) continue;
-        const unsigned long long hm0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mk_hi, p) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readlane((int)mk_lo, p);
-        const int env_p = __builtin_amdgcn_readfirstlane(env_at(e0 + p));
-        const EnvCam& c = w_cams[p - p0];
+        unsigned long long hm0 = 0ull;                 // OR of the four blocks' masks: the unit spans the whole raster tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hm0 |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hv >> 32), r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hv, r);
+        const int env_p = __builtin_amdgcn_readfirstlane(ev);
+        const EnvCam& c = cams[env_p];                 // wave-uniform address: scalar loads where the fields are used
+        (void)p;
         const MapU m = map_u(R.maps[c.map_id]);
         const ScreenTri* base = R.stris + (size_t)env_p * R.max_tris;
         const uint2* rng = R.objrange + (size_t)__builtin_amdgcn_readfirstlane(c.map_id) * DTSIM_MAX_OBJECTS;
@@ -2673,8 +2654,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(DT_RO_WAVES,
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next item overwrites w_cams
-      __builtin_amdgcn_wave_barrier();
 #ifdef DT_WAVE_SPANS
       { const unsigned long long d = wall_clock64() - span_i0; span_long = d > span_long ? d : span_long; span_sum += d; span_last = d; if (span_n == 1) { span_first = d; span_first_at = span_i0 - span_t0; } }
 #endif
@@ -2870,7 +2849,7 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
       hipLaunchKernelGGL(k_resolve, rgrid, dim3(RB), lds2, s_res, R, cams, R.queue, R.qcount);
     }
     if (obj) {
-      const size_t lds4 = lds + (size_t)(RB / 64) * RES_ENVS * sizeof(EnvCam) + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
+      const size_t lds4 = lds + (size_t)(RB / 64) * TRI_CAP * sizeof(TriCov) + (size_t)(RB / 64) * RO_SCR_BYTES;
       const dim3 rgrid((unsigned)std::min<size_t>(grid.x, resident_blocks(k_resolve_obj<DT_RES_NB>, lds4)));
       hipLaunchKernelGGL(k_resolve_obj<DT_RES_NB>, rgrid, dim3(RB), lds4, s_res, R, cams, R.queue, 1, has_pos ? envq : (const EnvQ*)nullptr);
     }
