@@ -357,3 +357,31 @@ def test_undistort_wrapper_folded_into_the_raster():
         assert np.array_equal(w.observation(rect[e]), got[e]), e
     assert (got.reshape(N, -1, 3).sum(-1) == 0).mean() > 0.01                      # BORDER_CONSTANT corners
     plain.close(); und.close()
+
+
+def test_domain_rand_with_a_positional_light_takes_the_exact_paths():
+    """Domain randomisation draws a DIRECTIONAL light (simulator.py:565-584: light_pos has w = 0), which is what lets k_raster_v3dr fold the
+    tile plane's light into a per-env constant.  A caller can still write a positional light (DTSIM_FIELD_COLORS, w = 1): those envs get an
+    empty one-ray range, every tile pixel goes to the exact path, and k_resolve_dr evaluates the light per pixel from the EnvCam.  Frames
+    against the oracle with the same light, plane-only thresholds; envs 0 / 2 positional, 1 / 3 as drawn."""
+    N, W, H = 4, 320, 240
+    for map_name, tol in (("small_loop", (1e-3, 5e-4, 0.02)), ("loop_only_duckies", (2e-3, 1e-3, 0.03))):
+        sim = BatchedSimulator(map_name, N, camera_width=W, camera_height=H, distortion=True, domain_rand=True, seed=13)
+        sim.step(np.random.default_rng(5).uniform(0.2, 0.8, (6, N, 2)).astype(np.float32), n_steps=6)
+        col = sim.read(_ffi.FIELD_COLORS).copy()           # [N][16]: horizon, ground, ambient, diffuse, light xyzw
+        lights = {0: (0.3, 2.5, -0.4, 1.0), 2: (-1.0, 1.5, 0.8, 1.0)}
+        for e, L in lights.items():
+            col[e, 12:16] = L
+        sim.write(_ffi.FIELD_COLORS, col)
+        sim.render()
+        frames = sim.frames_host()
+        scene = _scene(map_name)
+        rmap = pdist.distortion_maps(W, H)
+        for e in range(N):
+            cam = _camera(sim, e, W, H, True)
+            if e in lights:
+                cam.L = np.asarray(lights[e], dtype=np.float64)
+            ref = raster.render_obs(cam, scene, "pixel", rmap, obj_states=_obj_states(sim, e, scene) if scene.m.objects else None)
+            s = _stats(frames[e], ref)
+            assert s["frac_gt1"] <= tol[0] and s["frac_gt2"] <= tol[1] and s["mean"] <= tol[2], (map_name, e, s)
+        sim.close()
