@@ -385,3 +385,29 @@ def test_domain_rand_with_a_positional_light_takes_the_exact_paths():
             s = _stats(frames[e], ref)
             assert s["frac_gt1"] <= tol[0] and s["frac_gt2"] <= tol[1] and s["mean"] <= tol[2], (map_name, e, s)
         sim.close()
+
+
+def test_domain_rand_over_two_maps_in_the_render_order():
+    """k_raster_v3dr / k_resolve_dr with more than one map resident (MultiMap slot alternation) and more than one chunk, so that the pass runs in
+    k_env_sort's order: per-position records (EnvD, object masks, queue regions) against per-env ones (EnvCam, frames, triangles), the maps'
+    column offsets in the LDS tile table.  Six envs -- both maps, both chunks, the partial tail chunk -- against the oracle."""
+    N, W, H = 40, 320, 240
+    names = ["loop_only_duckies", "small_loop_only_duckies"]
+    sim = BatchedSimulator(names, N, camera_width=W, camera_height=H, distortion=True, domain_rand=True, seed=23, map_cycle=True, max_steps=100000)
+    sim.reset(mask=(np.arange(N) % 2 == 0))                # multimap_env.py:44-49: the two maps alternate over the slots
+    sim.step(np.random.default_rng(6).uniform(0.2, 0.7, (5, N, 2)).astype(np.float32), n_steps=5)
+    sim.render()
+    frames = sim.frames_host()
+    mid = sim.read(_ffi.FIELD_MAP_ID)
+    assert set(np.unique(mid)) == {0, 1}
+    rpos = sim.read(_ffi.FIELD_RENDER_POS)
+    assert sorted(rpos.tolist()) == list(range(N)) and not np.array_equal(rpos, np.arange(N))     # a real permutation: the sorted order is in use
+    scenes = [_scene(n) for n in names]
+    rmap = pdist.distortion_maps(W, H)
+    env_at = np.argsort(rpos)
+    for e in sorted({0, 1, int(env_at[0]), int(env_at[31]), int(env_at[32]), int(env_at[N - 1])}):
+        scene = scenes[int(mid[e])]
+        ref = raster.render_obs(_camera(sim, e, W, H, True), scene, "pixel", rmap, obj_states=_obj_states(sim, e, scene))
+        s = _stats(frames[e], ref)
+        assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, int(mid[e]), s)
+    sim.close()
