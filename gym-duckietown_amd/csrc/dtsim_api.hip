@@ -267,7 +267,7 @@ int dtsim_create(const dtsim_config* cfg, dtsim_t** out) {
     if (e != hipSuccess) { dtsim_destroy(h); return fail(DTSIM_E_HIP, "hipMalloc(frames %zu B): %s", h->frames_bytes, hipGetErrorString(e)); }
     h->frames = h->frames_own;
     e = hipMalloc(&h->d_lut, sizeof(float) * 4 * (size_t)cfg->cam_height * cfg->cam_width);
-    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64 + 4) + 64 + ((size_t)h->N + 1) * 64 + (size_t)h->N * 384);   // EnvCam[N], EnvFast[N], EnvQ[N], render order [N], (aligned) EnvV[N + 1], EnvD[N]
+    if (e == hipSuccess) e = hipMalloc(&h->d_envcam, (size_t)h->N * (128 + 64 + 64 + 4) + 64 + ((size_t)h->N + 1) * 64 + (size_t)h->N * 320);   // EnvCam[N], EnvFast[N], EnvQ[N], render order [N], (aligned) EnvV[N + 1], EnvD[N]
     if (e == hipSuccess) e = hipMalloc(&h->d_pixtab, (size_t)cfg->cam_height * cfg->cam_width * 64 + 2048);   // PixTab + SampTab + 1 KB store dump + debug counters
     {  // MSAA edge queue: one worst-case region per raster wavefront (render.hip QREGION)
       const size_t n_wg = dt_raster_tiles(cfg->cam_width, cfg->cam_height) * (((size_t)h->N + DT_ENVS_PER_BLOCK - 1) / DT_ENVS_PER_BLOCK);

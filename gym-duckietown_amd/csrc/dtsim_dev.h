@@ -229,7 +229,7 @@ struct RenderParams {
   void* dump;                   // 1 KB scratch: masked lanes of the unconditional frame store write here
   void* pixtab;                 // [H*W] PixTab (16 B) then [H*W] SampTab (48 B): per-pixel tables of the shared camera
   void* envv;                   // [N + 1] EnvV (render.hip): k_raster_v3's per-env constants in render order
-  void* envd;                   // [N] EnvD (render_v3dr.inc, 384 B, render order): k_raster_v3dr's per-env constants (domain randomisation)
+  void* envd;                   // [N] EnvD (render_v3dr.inc, 320 B, render order): k_raster_v3dr's per-env constants (domain randomisation)
   int32_t q3_rows;              // k_raster_v3 (render_v3.inc): rows of its LDS tile table (largest padded grid height); 0: k_raster_q is used
   int32_t pad4_;
   unsigned long long* spans;    // DT_WAVE_SPANS build variant only (else null): [2][2048 workgroups][4 wavefronts]{start, end, items, longest / first item, start of the first, sum, last item} in 100 MHz ticks
