@@ -1599,7 +1599,10 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
                                       const PixTab* __restrict__ pixtab, const SampTab* __restrict__ samptab,
                                       const uint8_t* __restrict__ qtex, const uint32_t* s_qt, uint32_t* w_list,
                                       const uint16_t* w_queue, const int n, const int e0, const int tile_x0, const int wave_y0,
-                                      const int lane, const int i0 = 0, const int p1 = 0, const int p2 = 0, const int p3 = 0) {
+                                      const int lane, const int i0 = 0, const int p1 = 0, const int p2 = 0, const int p3 = 0,
+                                      const uint4* s_envq = nullptr) {
+  // s_envq (V3): the EnvQ records of the chunk's 32 positions, staged in LDS by the workgroup -- an entry's constants are three
+  // ds_read_b128 instead of three 16-byte gathers through the texture unit (in both phases).
   const int npix = R.W * R.H;
   const int LS = R.qlog2;
   const uint32_t SM = (1u << LS) - 1u;
@@ -1686,10 +1689,18 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         pt[u] = PixTab{0.f, 0.f, 0.f, 0xFFFFu};
         if (skip[u]) continue;                       // wave-uniform
         pt[u] = pixtab[pix[u]];
-        const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
-        qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
-        qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
-        const uint4 qd = *reinterpret_cast<const uint4*>(&fq->reach);   // reach, env, pad[0], pad[1] (one 16-byte piece: the path is bound by its vector-memory instruction count)
+        uint4 qd;
+        if (V3 && s_envq) {
+          const uint4* fl = s_envq + el[u] * 4;
+          const uint4 a4 = fl[0];
+          qa[u] = make_float4(__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
+          qb[u] = fl[1]; qd = fl[3];
+        } else {
+          const EnvQ* fq = envq + min(e0 + el[u], R.N - 1);   // position in the render order -> constants, frame index
+          qa[u] = *reinterpret_cast<const float4*>(&fq->A);     // A, B, Cx, Cz
+          qb[u] = *reinterpret_cast<const uint4*>(&fq->Xhi);    // Xhi, Zhi, tab_b, pitch4
+          qd = *reinterpret_cast<const uint4*>(&fq->reach);   // reach, env, pad[0], pad[1] (one 16-byte piece: the path is bound by its vector-memory instruction count)
+        }
         if (V3) qb[u].z = qd.z;
         env[u] = (int)qd.y;
       }
@@ -1755,8 +1766,17 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         // accumulator per channel -- 6 v_dot4 per sample, exact -- and sky / ground samples add their colour once per
         // count.  Tile look-ups go by v_perm like the env loop's; the +-50 m ground-quad test is made in quad coordinates.
         // the env's constants as three 16-byte pieces (round 5: the exact path is bound by the NUMBER of vector-memory instructions it issues)
-        const float4 qa = *reinterpret_cast<const float4*>(&fq->A);
-        const uint4 qb = *reinterpret_cast<const uint4*>(&fq->Xhi), qd = *reinterpret_cast<const uint4*>(&fq->reach);
+        float4 qa;
+        uint4 qb, qd;
+        if (s_envq) {
+          const uint4* fl = s_envq + el * 4;
+          const uint4 a4 = fl[0];
+          qa = make_float4(__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w));
+          qb = fl[1]; qd = fl[3];
+        } else {
+          qa = *reinterpret_cast<const float4*>(&fq->A);
+          qb = *reinterpret_cast<const uint4*>(&fq->Xhi); qd = *reinterpret_cast<const uint4*>(&fq->reach);
+        }
         const float A = qa.x, B = qa.y, Cx = qa.z, Cz = qa.w, Xhi = __uint_as_float(qb.x), Zhi = __uint_as_float(qb.y);
         const uint32_t tab = qd.z;
         const int e = (int)qd.y;
@@ -2817,7 +2837,7 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
     const bool s256 = R.qlog2 == 8 && R.qmax_tiles < 256;
     // k_raster_v3 (render_v3.inc): S = 256 textures, padded grids up to 32 x 24 tiles, up to 4 maps (else k_raster_q)
     if (v3) {
-      const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4;
+      const size_t lds3 = (size_t)R.q3_rows * V3_TAB_PITCH * 4 + (size_t)(RB / 64) * V3_WAVE_LDS * 4 + (size_t)ENVS_PER_BLOCK * sizeof(EnvQ);   // tile table, per-wavefront buffers, the chunk's EnvQ records
 #define LAUNCH_V3(OBJ_) hipLaunchKernelGGL((k_raster_v3<OBJ_>), gridq, dim3(RB), lds3, s, R, cams, fasts, envq, envv, frames_raster, R.qtex, \
                                            reinterpret_cast<const float4*>(R.lut), pixtab, samptab, R.qtiles, R.queue, R.qcount)
       if (obj) LAUNCH_V3(true); else
