@@ -72,6 +72,11 @@ struct dtsim {
   dtsim_probe* d_qout = nullptr;
   dtsim_agent_info* d_agent = nullptr;
   bool rendered = false;          // a render pass has written the per-env cameras (dtsim_draw_lines needs them)
+  RenderParams last_R{};          // the parameters of that pass (dtsim_draw_leds: projected triangles, tables); last_segment: it was the segment view
+  bool last_segment = false;
+  bool leds_ok = false;           // last_R still names live buffers (cleared by dtsim_set_assets / dtsim_set_maps / dtsim_set_distortion_lut, which re-allocate)
+  float* d_leds = nullptr;        // dtsim_draw_leds: device copy of the caller's spheres
+  int leds_cap = 0;
   float* d_lines = nullptr;       // dtsim_draw_lines: device copy of the caller's segments
   int lines_cap = 0;
   int render_tables = 0;          // dt_launch_render: which env-invariant tables are valid (camera LUT + maps unchanged)
@@ -308,7 +313,7 @@ void dtsim_destroy(dtsim_t* h) {
   }
   void* ptrs[] = {h->slab, h->d_blobs, h->d_dyn, h->d_states, h->d_mask, h->d_pool, h->d_actions, h->d_qenv,
                   h->d_qpose, h->d_qout, h->d_agent, h->frames_own, h->d_lut, h->d_texels, h->d_tex, h->d_meshes, h->d_tris,
-                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab, h->d_lines};
+                  h->d_rmaps, h->d_rtiles, h->d_robjs, h->d_envcam, h->d_tilerecs, h->d_stris, h->d_objbox, h->d_objmask, h->d_queue, h->d_qcount, h->d_items, h->d_qend, h->d_obs_tab, h->d_obsc_tab, h->d_sampler, h->d_texels_seg, h->d_mesh_seg, h->d_qtex, h->d_qtiles, h->d_pixtab, h->d_lines, h->d_leds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->overlap.s2) { (void)hipStreamSynchronize(h->overlap.s2); (void)hipStreamDestroy(h->overlap.s2); }
   for (hipEvent_t ev : h->overlap.ev) if (ev) (void)hipEventDestroy(ev);
@@ -339,6 +344,7 @@ static int build_texel_pool(const dtsim_texture* textures, int n_textures, std::
 int dtsim_set_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures, const dtsim_mesh* meshes,
                      int n_meshes) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  h->leds_ok = false;
   h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (n_textures < 0 || n_textures > DTSIM_MAX_TEXTURES) return fail(DTSIM_E_LIMIT, "n_textures %d > %d", n_textures, DTSIM_MAX_TEXTURES);
   if (n_meshes < 0 || n_meshes > DTSIM_MAX_MESHES) return fail(DTSIM_E_LIMIT, "n_meshes %d > %d", n_meshes, DTSIM_MAX_MESHES);
@@ -458,6 +464,7 @@ static void build_quad_block(std::vector<uint32_t>& out, const uint32_t* pool, i
 
 int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
   if (!h || !maps) return fail(DTSIM_E_INVALID, "null argument");
+  h->leds_ok = false;
   h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (n_maps <= 0 || n_maps > DTSIM_MAX_MAPS) return fail(DTSIM_E_LIMIT, "n_maps %d outside [1,%d]", n_maps, DTSIM_MAX_MAPS);
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -691,6 +698,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
 
 int dtsim_set_distortion_lut(dtsim_t* h, const float* rmapx, const float* rmapy) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
+  h->leds_ok = false;
   h->render_tables = 0;           // the cached per-pixel / per-block render tables depend on this
   if (!h->d_lut) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
   if ((rmapx == nullptr) != (rmapy == nullptr)) return fail(DTSIM_E_INVALID, "rmapx/rmapy must both be given");
@@ -907,7 +915,7 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     h->render_tables = dt_launch_render(h->stream, h->A, R, h->render_tables, h->overlap.parts > 1 ? &h->overlap : nullptr);
   }
   HIPCHK(hipGetLastError());
-  h->rendered = true;
+  h->rendered = true; h->last_R = R; h->last_segment = segment; h->leds_ok = true;
 #ifdef DT_WAVE_SPANS
   if (R.spans) {   // the spans of the last render -> the file DTSIM_WAVE_SPANS names (tools/wave_spans.py reads it)
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -997,6 +1005,39 @@ int dtsim_draw_lines(dtsim_t* h, const float* lines, const int32_t* env_idx, int
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));           // `lines` is pageable host memory: the copy must have left it
+  return DTSIM_OK;
+}
+
+int dtsim_draw_leds(dtsim_t* h, const float* spheres, const int32_t* env_idx, int n) {
+  if (!h || (n > 0 && !spheres)) return fail(DTSIM_E_INVALID, "null argument");
+  if (n < 0) return fail(DTSIM_E_INVALID, "n = %d", n);
+  if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
+  if (!h->rendered || !h->leds_ok || h->last_segment) return fail(DTSIM_E_STATE, "dtsim_draw_leds needs a preceding dtsim_render (colour view): it tests the spheres against that pass's scene");
+  if (n == 0) return DTSIM_OK;
+  for (int i = 0; i < n; ++i) {
+    const int e = env_idx ? env_idx[i] : 0;
+    if (e < 0 || e >= h->N) return fail(DTSIM_E_INVALID, "env_idx[%d] = %d out of range [0, %d)", i, e, h->N);
+    if (env_idx && i && env_idx[i] < env_idx[i - 1]) return fail(DTSIM_E_INVALID, "env_idx must be non-decreasing (spheres grouped by env, in draw order)");
+  }
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->leds_cap < n) {
+    if (h->d_leds) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_leds); h->d_leds = nullptr; }
+    h->leds_cap = std::max(n, 256);
+    HIPCHK(hipMalloc(&h->d_leds, sizeof(float) * 8 * (size_t)h->leds_cap));
+  }
+  HIPCHK(hipMemcpyAsync(h->d_leds, spheres, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  RenderParams R = h->last_R;
+  R.frames = h->frames;                               // (dtsim_bind_frames may have moved the output since the pass)
+  int i0 = 0;
+  while (i0 < n) {                                    // one launch per env that has spheres
+    const int e = env_idx ? env_idx[i0] : 0;
+    int i1 = i0;
+    while (i1 < n && (env_idx ? env_idx[i1] : 0) == e) ++i1;
+    dt_launch_overlay_leds(h->stream, R, h->d_leds, i0, i1 - i0, e);
+    i0 = i1;
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));           // `spheres` is pageable host memory: the copy must have left it
   return DTSIM_OK;
 }
 

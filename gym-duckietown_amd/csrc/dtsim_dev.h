@@ -246,6 +246,8 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R, i
 // GL_LINE overlays (draw_curve / draw_bbox) as a post-pass on the resolved frame of `env`: d_lines = [..][9] world-space segments + colour
 // (device memory), `count` of them from `first` on; uses the EnvCam the last render wrote.
 void dt_launch_overlay_lines(hipStream_t s, const RenderParams& R, const float* d_lines, int first, int count, int env);
+// the LED spheres of enable_leds (render.hip k_overlay_leds): [count] spheres of env `env` from d_spheres[first..], world space, R = the last render pass's parameters
+void dt_launch_overlay_leds(hipStream_t s, const RenderParams& R, const float* d_spheres, int first, int count, int env);
 
 #ifndef DT_OBS_STAGE_ROWS
 #define DT_OBS_STAGE_ROWS 8

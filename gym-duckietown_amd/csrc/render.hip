@@ -2790,7 +2790,132 @@ __global__ __launch_bounds__(256) void k_overlay_lines(RenderParams R, const Env
   }
 }
 
+
+// ---- k_overlay_leds: the additively blended LED spheres of enable_leds as a post-pass on the resolved frames --------------------------
+// objects.py:68-121: after a duckiebot's mesh, WorldObj.render_mesh draws per LED a 1 cm gluSphere at alpha 1 and a halo at alpha 0.2 with
+// glBlendFunc(GL_SRC_ALPHA, GL_ONE), depth test and depth writes on, lighting on, no texture.  The host states the spheres in WORLD space in
+// draw order (dtsim_draw_leds: centre, radius, glColor, alpha).  Per OUTPUT pixel (source pixel through the LUT) and MSAA sample: the depth of
+// the opaque scene is recomputed -- the planes by classify(), the meshes by z-buffering the env's projected triangles (ScreenTri, left by the
+// render pass's k_obj_setup) -- and every sphere whose FRONT surface is nearer than the sample's depth adds alpha x its lit colour (GL_COLOR_MATERIAL:
+// colour x (ambient + diffuse N.L) at the hit, clamped) and writes its depth; the pixel becomes frame + sum / 4.  Additive blending is linear, so
+// adding to the resolved frame equals blending into the samples.  Documented deviations (oracle/raster.py overlay_leds states the same
+// interpretation): the analytic sphere for the 10 x 10 tessellation, front surfaces only (a back face that gluSphere happens to
+// emit before the front face would add a second layer), lit per sample instead of per vertex, and all spheres after ALL opaque objects (GL
+// interleaves them with the objects in map order).  Not a hot path: one thread per pixel, the triangle loop only under a sphere's screen box.
+struct LedS { float ex, ey, ez, r, cr, cg, cb, a, bx0, bx1, by0, by1; };     // eye-space centre, radius, colour, alpha, source-pixel box
+__global__ __launch_bounds__(256) void k_overlay_leds(RenderParams R, const EnvCam* __restrict__ cams, const float* __restrict__ spheres,
+                                                      const int first, const int count, const int env) {
+  __shared__ LedS s_led[64];
+  const int tid = threadIdx.x;
+  const int pix = blockIdx.x * 256 + tid;
+  const EnvCam c = cams[env];
+  const MapU m = map_u(R.maps[c.map_id]);
+  const TileLds* tiles = reinterpret_cast<const TileLds*>(R.tile_recs);
+  float nx = 0.f, ny = 0.f, sxp = 0.f, syp = 0.f;
+  bool live = false;
+  if (pix < R.W * R.H) {
+    const float4 l = reinterpret_cast<const float4*>(R.lut)[pix];
+    live = l.z != 0.f;
+    nx = l.x; ny = l.y;
+    sxp = (l.x + 1.f) * 0.5f * (float)R.W; syp = (1.f - l.y) * 0.5f * (float)R.H;       // centre of the source pixel
+  }
+  const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
+  float add[3] = {0.f, 0.f, 0.f};
+  float depth[4] = {0.f, 0.f, 0.f, 0.f};
+  bool have_depth = false, any = false;
+  for (int base = 0; base < count; base += 64) {
+    __syncthreads();
+    if (tid < 64) {
+      LedS sp; sp.r = -1.f; sp.ex = sp.ey = sp.ez = sp.cr = sp.cg = sp.cb = sp.a = 0.f; sp.bx0 = sp.by0 = 1.f; sp.bx1 = sp.by1 = 0.f;
+      if (base + tid < count) {
+        const float* S = spheres + (size_t)(first + base + tid) * 8;
+        const float rx = S[0] - c.Cx, ry = S[1] - c.Cy, rz = S[2] - c.Cz;
+        const float xla = rx * c.sa + rz * c.ca, zla = -(rx * c.ca - rz * c.sa);
+        sp.ex = xla; sp.ey = ry * c.cth - zla * c.sth; sp.ez = ry * c.sth + zla * c.cth;                 // eye space, -z forward
+        const float w = -sp.ez, r = S[3];
+        if (r > 0.f && w + r > NEAR_Z) {
+          sp.r = r; sp.cr = S[4]; sp.cg = S[5]; sp.cb = S[6]; sp.a = S[7];
+          const float wn = fmaxf(w - r, NEAR_Z);
+          const float cx = (sp.ex / w / c.tx + 1.f) * 0.5f * (float)R.W, cy = (1.f - sp.ey / w / c.ty) * 0.5f * (float)R.H;
+          const float rad = r / wn / fminf(c.tx / (float)R.W, c.ty / (float)R.H) * 0.5f * 1.5f + 2.f;     // conservative: only prunes
+          sp.bx0 = cx - rad; sp.bx1 = cx + rad; sp.by0 = cy - rad; sp.by1 = cy + rad;
+          if (!(w > 0.f)) { sp.bx0 = sp.by0 = -1e30f; sp.bx1 = sp.by1 = 1e30f; }                          // centre behind the eye: no box, test everything
+        }
+      }
+      s_led[tid] = sp;
+    }
+    __syncthreads();
+    if (!live) continue;
+    const int n = min(64, count - base);
+    for (int i = 0; i < n; ++i) {
+      const LedS sp = s_led[i];
+      if (!(sp.r > 0.f) || sxp < sp.bx0 || sxp > sp.bx1 || syp < sp.by0 || syp > sp.by1) continue;
+      if (!have_depth) {                               // the opaque scene's depth at the four samples, once per pixel that any sphere may touch
+        have_depth = true;
+        float wbest[4] = {0.f, 0.f, 0.f, 0.f};
+        int tbest[4] = {-1, -1, -1, -1};
+        if (R.stris && R.objbox) {
+          const ObjBox* boxes = R.objbox + (size_t)env * DTSIM_MAX_OBJECTS;
+          const ScreenTri* tb = R.stris + (size_t)env * R.max_tris;
+          const int n_obj = R.maps[c.map_id].n_obj;
+          for (int o = 0; o < n_obj; ++o) {
+            const ObjBox ob = boxes[o];
+            if (ob.count <= 0 || sxp < ob.bx0 - 1.f || sxp > ob.bx1 + 1.f || syp < ob.by0 - 1.f || syp > ob.by1 + 1.f) continue;
+            for (int t = ob.first; t < ob.first + ob.count; ++t) test_tri(tb[t], sxp, syp, wbest, tbest);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const Ray rs = make_ray(nx + ox[q] * sxn, ny - oy[q] * syn, c.tx, c.ty, c.sth, c.cth);
+          const Hit h = classify(c, m, tiles, rs);
+          float d = h.cls == CLS_SKY ? 3.0e38f : h.t;
+          if (tbest[q] >= 0) d = fminf(d, 1.f / wbest[q]);
+          depth[q] = d;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dx = (nx + ox[q] * sxn) * c.tx, dy = (ny - oy[q] * syn) * c.ty;       // eye-space ray (dx, dy, -1) t, t = eye depth
+        const float a = dx * dx + dy * dy + 1.f;
+        const float b = dx * sp.ex + dy * sp.ey - sp.ez;
+        const float cc = sp.ex * sp.ex + sp.ey * sp.ey + sp.ez * sp.ez - sp.r * sp.r;
+        const float disc = b * b - a * cc;
+        if (!(disc > 0.f)) continue;
+        const float t = (b - sqrtf(disc)) / a;
+        if (!(t >= NEAR_Z && t <= FAR_Z && t < depth[q])) continue;
+        const float px = t * dx, py = t * dy, pz = -t;
+        const float inv_r = 1.f / sp.r;
+        const float nxe = (px - sp.ex) * inv_r, nye = (py - sp.ey) * inv_r, nze = (pz - sp.ez) * inv_r;
+        float ndl;
+        if (c.L[3] == 0.f) ndl = nxe * c.L[0] + nye * c.L[1] + nze * c.L[2];
+        else {
+          const float lx = c.L[0] - px, ly = c.L[1] - py, lz = c.L[2] - pz;
+          ndl = (nxe * lx + nye * ly + nze * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+        }
+        ndl = fmaxf(ndl, 0.f);
+        add[0] += sp.a * 255.f * fminf(sp.cr * (c.base[0] + c.dif[0] * ndl), 1.f);
+        add[1] += sp.a * 255.f * fminf(sp.cg * (c.base[1] + c.dif[1] * ndl), 1.f);
+        add[2] += sp.a * 255.f * fminf(sp.cb * (c.base[2] + c.dif[2] * ndl), 1.f);
+        depth[q] = t;
+        any = true;
+      }
+    }
+  }
+  if (live && any) {
+    uint8_t* dst = R.frames + ((size_t)env * R.W * R.H + pix) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dst[k] = (uint8_t)(fminf(fmaxf((float)dst[k] + 0.25f * add[k], 0.f), 255.f) + 0.5f);
+  }
+}
+
 }  // namespace
+
+void dt_launch_overlay_leds(hipStream_t s, const RenderParams& R, const float* d_spheres, int first, int count, int env) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_overlay_leds, dim3((unsigned)((R.W * R.H + 255) / 256)), dim3(256), 0, s, R, reinterpret_cast<const EnvCam*>(R.envcam), d_spheres, first, count, env);
+}
 
 void dt_launch_overlay_lines(hipStream_t s, const RenderParams& R, const float* d_lines, int first, int count, int env) {
   if (count <= 0) return;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 9
+ABI_VERSION = 10
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 32, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
@@ -41,7 +41,7 @@ EXPORTS = [
     "dtsim_abi_version", "dtsim_last_error", "dtsim_device_count", "dtsim_create", "dtsim_destroy",
     "dtsim_set_assets", "dtsim_set_maps", "dtsim_set_distortion_lut", "dtsim_reset",
     "dtsim_set_spawn_pool", "dtsim_step", "dtsim_step_ex", "dtsim_render", "dtsim_render_ex", "dtsim_set_segment_assets", "dtsim_frames_devptr", "dtsim_frames_bytes",
-    "dtsim_bind_frames", "dtsim_draw_lines", "dtsim_allgather_frames", "dtsim_observe", "dtsim_observe_cubic", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read_agent", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
+    "dtsim_bind_frames", "dtsim_draw_lines", "dtsim_draw_leds", "dtsim_allgather_frames", "dtsim_observe", "dtsim_observe_cubic", "dtsim_set_reset_sampler", "dtsim_reset_done", "dtsim_query", "dtsim_read_agent", "dtsim_read", "dtsim_write", "dtsim_field_devptr",
     "dtsim_field_bytes", "dtsim_state_bytes", "dtsim_sync", "dtsim_stream", "dtsim_profile_read",
 ]
 
@@ -183,6 +183,7 @@ def load(path: str | None = None):
         "dtsim_bind_frames": (ci, [vp, vp]),
         "dtsim_allgather_frames": (ci, [vp, vp, vp, vp, C.c_size_t]),
         "dtsim_draw_lines": (ci, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), ci]),
+        "dtsim_draw_leds": (ci, [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), ci]),
         "dtsim_set_reset_sampler": (ci, [vp, C.POINTER(ResetSampler)]),
         "dtsim_reset_done": (ci, [vp]),
         "dtsim_observe": (ci, [vp, vp, ci, ci, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), ci]),

@@ -462,6 +462,22 @@ class BatchedSimulator:
             ip = ei.ctypes.data_as(C.POINTER(C.c_int32))
         _ffi.check(self._lib, self._lib.dtsim_draw_lines(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), ip, int(n)))
 
+    def draw_leds(self, spheres, env_idx=None):
+        """The LED spheres of the reference's enable_leds (objects.py:68-121) as a post-pass on the frames of the last render(): spheres [n, 8] =
+        world-space centre (x, y, z), radius, colour (r, g, b in 0..1), alpha, in draw order; env_idx [n] (non-decreasing) or None = env 0.
+        dtsim_draw_leds (include/dtsim.h)."""
+        a = np.ascontiguousarray(np.asarray(spheres, dtype=np.float32).reshape(-1, 8))
+        n = a.shape[0]
+        if n == 0:
+            return
+        ip = None
+        if env_idx is not None:
+            ei = np.ascontiguousarray(np.asarray(env_idx, dtype=np.int32).reshape(-1))
+            if ei.shape[0] != n:
+                raise ValueError("env_idx needs one entry per sphere")
+            ip = ei.ctypes.data_as(C.POINTER(C.c_int32))
+        _ffi.check(self._lib, self._lib.dtsim_draw_leds(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), ip, int(n)))
+
     def bind_frames(self, devptr: Optional[int]):
         _ffi.check(self._lib, self._lib.dtsim_bind_frames(self._h, C.c_void_p(devptr) if devptr else None))
 

@@ -14,7 +14,8 @@ handle that copies the state; `segment=True` is the segmentation render.
 
 `draw_curve` / `draw_bbox` (round 5): the GL_LINE overlays as a post-pass on the resolved frame (`dtsim_draw_lines`; draw_bbox also switches
 to the reference's debugging camera 0.8 m above the robot).  Not provided (out of scope): the pyglet window itself (nothing
-is displayed), LEDs, `camera_rand`'s carnivalmirror calibration sampling.
+is displayed), `camera_rand`'s carnivalmirror calibration sampling.  `enable_leds` blends the duckiebots' LED spheres
+into the frame as a post-pass (`dtsim_draw_leds`: analytic spheres, front surfaces, after all opaque objects).
 """
 from __future__ import annotations
 
@@ -105,10 +106,9 @@ class Simulator(_EnvBase):
                  camera_rand: bool = False, randomize_maps_on_reset: bool = False, num_tris_distractors: int = 12,
                  color_ground: Sequence[float] = (0.15, 0.15, 0.15), color_sky: Sequence[float] = BLUE_SKY,
                  style: str = "photos", enable_leds: bool = False, device: int = 0, **env_kwargs):
-        if enable_leds or camera_rand:
-            raise NotImplementedError("enable_leds (additively blended gluSpheres) / camera_rand (carnivalmirror calibration sampling) "
-                                      "are outside the path this backend implements")
-        self.enable_leds = enable_leds
+        if camera_rand:
+            raise NotImplementedError("camera_rand (carnivalmirror calibration sampling) is outside the path this backend implements")
+        self.enable_leds = bool(enable_leds)
         self.seed_value = seed
         self.num_tris_distractors = num_tris_distractors
         self.color_ground, self.color_sky = color_ground, list(color_sky)
@@ -361,12 +361,45 @@ class Simulator(_EnvBase):
             v = self._viewer(False, (self.camera_width, self.camera_height))
             self._sync_viewer(v, top_down=False, bbox=True)
             v.render(segment=bool(segment))
+            if self.enable_leds and not segment:
+                v.draw_leds(self._led_spheres())
             v.draw_lines(self._overlay_lines())
             return v.frames_host()[0]
         self._sim.render(segment=bool(segment))
+        if self.enable_leds and not segment:
+            self._sim.draw_leds(self._led_spheres())
         if self.draw_curve:
             self._sim.draw_lines(self._overlay_lines())
         return self._sim.frames_host()[0]
+
+    # ---------------------------------------------------------------- LEDs --
+    _LED_POS = ((0.1, 0.05, -0.05), (0.1, 0.05, 0.05), (0.1, 0.05, 0.0), (-0.1, 0.05, -0.05), (-0.1, 0.05, 0.05))   # glTranslatef(px, pz, py): front_left,
+    # front_right, center, back_left, back_right in the dict's order (objects.py:74-80, 96)
+    _LED_FOLLOWER = ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), (0.0, 0.0, 0.2), (0.5, 0.0, 0.0), (0.5, 0.0, 0.0))           # DuckiebotObj.leds_color (objects.py:218-224)
+    _LED_STATIC = ((0.0, 0.0, 1.0),) * 5                                                                             # a static duckiebot-kind WorldObj (objects.py:86-92)
+
+    def _led_spheres(self) -> np.ndarray:
+        """World-space spheres [n, 8] = centre, radius, glColor, alpha of WorldObj.render_mesh's LEDs (objects.py:68-121), in draw order: for every
+        visible object of kind "duckiebot", per LED the 1 cm sphere at alpha 1 and the halo of radius mean(colour) x 4 cm at alpha 0.2, inside
+        the object's translate / scale / rotate.  dtsim_draw_leds blends them into the rendered frame."""
+        vis = self._sim.read(_ffi.FIELD_OBJ_VISIBLE)[0]
+        cen, yrot, cy = self._sim.read(_ffi.FIELD_OBJ_CENTER)[0], self._sim.read(_ffi.FIELD_OBJ_YROT)[0], self._sim.read(_ffi.FIELD_OBJ_Y)[0]
+        out = []
+        for k, o in enumerate(self.objects):
+            if o.kind != "duckiebot" or not vis[k]:
+                continue
+            if o.dyn_slot >= 0:
+                pos, th = np.array([cen[o.dyn_slot, 0], cy[o.dyn_slot], cen[o.dyn_slot, 1]]), math.radians(float(yrot[o.dyn_slot]))
+            else:
+                pos, th = np.asarray(o.pos, dtype=np.float64), math.radians(float(np.rad2deg(o.angle)))
+            c, s_ = math.cos(th), math.sin(th)
+            for (lx, ly, lz), col in zip(self._LED_POS, self._LED_STATIC if o.static else self._LED_FOLLOWER):
+                col = np.clip(np.asarray(col, dtype=np.float64), 0.0, 1.0)
+                x, y, z = lx * o.scale, ly * o.scale, lz * o.scale
+                cw = np.array([x * c + z * s_, y, -x * s_ + z * c]) + pos         # glRotatef(y_rot, 0, 1, 0) (objects.py:140-146)
+                out.append([*cw, 0.01 * o.scale, *col, 1.0])
+                out.append([*cw, float(np.mean(col)) * 0.04 * o.scale, *col, 0.2])
+        return np.asarray(out, dtype=np.float32).reshape(-1, 8)
 
     # ---------------------------------------------------------------- GL_LINE overlays --
     def _overlay_lines(self) -> np.ndarray:
@@ -429,6 +462,8 @@ class Simulator(_EnvBase):
         v = self._viewer(self.distortion and mode != "free_cam")
         self._sync_viewer(v, top_down=(mode == "top_down"), bbox=self.draw_bbox and mode != "top_down")
         v.render(segment=bool(segment))
+        if self.enable_leds and not segment:             # (the stand-in for self.mesh in the top-down view is not a WorldObj: no LEDs, as in the reference)
+            v.draw_leds(self._led_spheres())
         if self.draw_curve or self.draw_bbox:
             v.draw_lines(self._overlay_lines())
         return v.frames_host()[0]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 9
+#define DTSIM_ABI_VERSION 10
 
 /* error codes */
 #define DTSIM_OK 0
@@ -346,6 +346,15 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags);
  * 1-pixel line under 4x multisampling (coverage per sample, first line wins a sample); the colour is the glColor lit as a surface with
  * normal +y.  Lines are not depth-tested against mesh objects (they lie above the tile plane).  Synchronous (host segments). */
 int dtsim_draw_lines(dtsim_t* h, const float* lines, const int32_t* env_idx, int n);
+/* The LED spheres of enable_leds (objects.py:68-121: per LED of a duckiebot-kind object a 1 cm gluSphere at alpha 1 and a halo at alpha 0.2,
+ * additively blended -- glBlendFunc(GL_SRC_ALPHA, GL_ONE) -- with depth test and depth writes, lit, untextured) as a post-pass on the frames
+ * the last dtsim_render made: `spheres` = [n][8] floats, world-space centre (x, y, z), radius, glColor (r, g, b in 0..1), alpha, in DRAW
+ * ORDER; env_idx as for dtsim_draw_lines.  Per MSAA sample the depth of the opaque scene is recomputed (planes analytically, meshes from
+ * the projected triangles the render pass left) and every sphere whose front surface is nearer adds alpha x its lit colour and writes its
+ * depth; the pixel becomes frame + sum / 4.  Deviations from the GL result (it depends on gluSphere's strip order): analytic spheres, front
+ * surfaces only, all spheres after all opaque objects.  Needs a preceding dtsim_render of the same state (not the segment view).
+ * Synchronous (host spheres). */
+int dtsim_draw_leds(dtsim_t* h, const float* spheres, const int32_t* env_idx, int n);
 void* dtsim_frames_devptr(dtsim_t* h);
 size_t dtsim_frames_bytes(const dtsim_t* h);
 /* Render into caller-owned device memory instead (e.g. a torch tensor that is the

@@ -251,8 +251,9 @@ def _object_instances(scene, obj_states):
     return out
 
 
-def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
-    """[H,W,3] float (0..255) of the un-distorted frame, row 0 = top."""
+def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None, return_depth=False):
+    """[H,W,3] float (0..255) of the un-distorted frame, row 0 = top.  return_depth: also the four per-sample depth buffers
+    (eye depth of the nearest opaque fragment, inf = clear colour) -- what overlay_leds tests the LED spheres against."""
     W, H = cam.W, cam.H
     cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     nxc = 2 * (cols + 0.5) / W - 1
@@ -276,6 +277,7 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
             tris.append((sx[k], sy[k], w[k], lit[k], UV[k], TI[k]))
 
     acc = np.zeros((H, W, 3))
+    depths = []
     for (ox, oy) in SAMPLE_OFFSETS:
         nx, ny = nxc + 2 * ox / W, nyc - 2 * oy / H
         xe, ye, yla, fwd = _rays(cam, nx, ny)
@@ -346,7 +348,8 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None):
             csub = col[y0:y1 + 1, x0:x1 + 1]
             csub[win] = colc[win]
         acc += col
-    return acc / 4.0
+        depths.append(depth)
+    return (acc / 4.0, depths) if return_depth else acc / 4.0
 
 
 def to_u8(img):
@@ -417,9 +420,98 @@ def overlay_lines(img_u8, cam, lines):
     return to_u8(out)
 
 
-def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None, lines=None):
-    """Simulator.render_obs (simulator.py:1953-1972): uint8 [H,W,3]; `lines`: draw_curve / draw_bbox overlays (overlay_lines)."""
-    img = to_u8(render_rectilinear(cam, scene, lighting, obj_states))
+LED_POSITIONS = [(0.1, 0.05, -0.05), (0.1, 0.05, 0.05), (0.1, 0.05, 0.0), (-0.1, 0.05, -0.05), (-0.1, 0.05, 0.05)]   # glTranslatef(px, pz, py) of
+# front_left, front_right, center, back_left, back_right in the dict's order (objects.py:74-80, 90-95)
+LED_FOLLOWER = [(0.5, 0.5, 0.5), (0.5, 0.5, 0.5), (0.0, 0.0, 0.2), (0.5, 0.0, 0.0), (0.5, 0.0, 0.0)]                    # DuckiebotObj.leds_color (objects.py:218-224)
+LED_STATIC = [(0.0, 0.0, 1.0)] * 5                                                                                     # any other duckiebot-kind object (objects.py:86-92)
+
+
+def led_spheres(scene, obj_states=None):
+    """The gluSpheres WorldObj.render_mesh draws for every visible object of kind "duckiebot" when enable_leds is on (objects.py:68-121), in
+    draw order, as world-space rows (cx, cy, cz, radius, r, g, b, alpha): per LED a 1 cm sphere at alpha 1 and a halo of radius
+    mean(colour) * 4 cm at alpha 0.2, inside the object's translate / scale / rotate."""
+    rows = []
+    for k, o in enumerate(scene.m.objects):
+        if o.kind != "duckiebot":
+            continue
+        st = obj_states[k] if obj_states is not None else None
+        if (st is not None and not st.get("visible", True)) or (st is None and not getattr(o, "visible", True)):
+            continue
+        pos = np.asarray(st["pos"] if st is not None else o.pos, dtype=np.float64)
+        yrot = math.radians(st["y_rot"] if st is not None else o.y_rot)
+        c, s_ = math.cos(yrot), math.sin(yrot)
+        cols = LED_STATIC if o.static else LED_FOLLOWER
+        for (lx, ly, lz), col in zip(LED_POSITIONS, cols):
+            col = np.clip(np.asarray(col, dtype=np.float64), 0.0, 1.0)
+            x, y, z = lx * o.scale, ly * o.scale, lz * o.scale
+            cw = np.array([x * c + z * s_, y, -x * s_ + z * c]) + pos
+            rows.append([*cw, 0.01 * o.scale, *col, 1.0])
+            rows.append([*cw, float(np.mean(col)) * 0.04 * o.scale, *col, 0.2])
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 8)
+
+
+def overlay_leds(img_u8, cam, depths, spheres):
+    """The additively blended LED spheres (objects.py:68-121: glBlendFunc(GL_SRC_ALPHA, GL_ONE), depth test and depth writes on) as a pass
+    over the RESOLVED rectilinear image and the per-sample depth buffers of the opaque scene.  One documented interpretation (PARITY
+    UNPINNED: the real result depends on the order in which gluSphere emits its 10 x 10 strips): a sphere is the analytic sphere, only its
+    FRONT surface counts (a back face drawn before its front face would add a second layer), it is lit per sample like a mesh vertex
+    (GL_COLOR_MATERIAL: colour x (ambient + diffuse N.L), clamped) and adds alpha x colour to every sample where its front surface is
+    nearer than whatever the sample's depth holds -- the opaque scene, then the spheres before it in the list, which write depth -- within
+    [near, far].  Spheres are applied after ALL opaque objects (GL interleaves them with the objects: an object drawn after a duckiebot and
+    behind one of its LEDs is hidden there).  A pixel becomes pixel + sum / 4, rounded.  What k_overlay_leds does, in float64."""
+    H, W = img_u8.shape[:2]
+    out = img_u8.astype(np.float64)
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    nxc = 2 * (cols + 0.5) / W - 1
+    nyc = 1 - 2 * (rows + 0.5) / H
+    add = np.zeros((H, W, 3))
+    dep = [d.copy() for d in depths]
+    for sp in np.asarray(spheres, dtype=np.float64).reshape(-1, 8):
+        r = sp[3]
+        if not r > 0:
+            continue
+        pe = cam.to_eye(sp[0:3])
+        w = -pe[2]
+        if w + r <= NEAR:
+            continue
+        # conservative screen box of the sphere
+        wn = max(w - r, NEAR)
+        cx, cy = (pe[0] / w / cam.tx + 1) * 0.5 * W, (1 - pe[1] / w / cam.ty) * 0.5 * H
+        rad = r / wn / min(cam.tx / W, cam.ty / H) * 0.5 * 1.5 + 2
+        x0, x1 = max(int(math.floor(cx - rad)), 0), min(int(math.ceil(cx + rad)), W - 1)
+        y0, y1 = max(int(math.floor(cy - rad)), 0), min(int(math.ceil(cy + rad)), H - 1)
+        if x0 > x1 or y0 > y1:
+            continue
+        for q, (ox, oy) in enumerate(SAMPLE_OFFSETS):
+            nx = nxc[y0:y1 + 1, x0:x1 + 1] + 2 * ox / W
+            ny = nyc[y0:y1 + 1, x0:x1 + 1] - 2 * oy / H
+            dx, dy = nx * cam.tx, ny * cam.ty                 # eye-space ray (dx, dy, -1) t: eye depth = t
+            a = dx * dx + dy * dy + 1.0
+            b = dx * pe[0] + dy * pe[1] - pe[2]               # d . P
+            c = pe @ pe - r * r
+            disc = b * b - a * c
+            hit = disc > 0
+            t = (b - np.sqrt(np.where(hit, disc, 0.0))) / a
+            sub = dep[q][y0:y1 + 1, x0:x1 + 1]
+            win = hit & (t >= NEAR) & (t <= FAR) & (t < sub)
+            if not win.any():
+                continue
+            ph = np.stack([t * dx, t * dy, -t], axis=-1)
+            n = (ph - pe) / r
+            lit = np.minimum(sp[4:7] * (cam.base + cam.dif * cam.ndl(ph, n)[..., None]), 1.0) * 255.0
+            add[y0:y1 + 1, x0:x1 + 1] += np.where(win[..., None], sp[7] * lit, 0.0)
+            sub[win] = t[win]
+    return to_u8(out + 0.25 * add)
+
+
+def render_obs(cam, scene, lighting="gouraud", rmap=None, obj_states=None, lines=None, leds=None):
+    """Simulator.render_obs (simulator.py:1953-1972): uint8 [H,W,3]; `lines`: draw_curve / draw_bbox overlays (overlay_lines); `leds`: the LED
+    spheres of enable_leds (led_spheres -> overlay_leds)."""
+    if leds is not None and len(leds):
+        f, depths = render_rectilinear(cam, scene, lighting, obj_states, return_depth=True)
+        img = overlay_leds(to_u8(f), cam, depths, leds)
+    else:
+        img = to_u8(render_rectilinear(cam, scene, lighting, obj_states))
     if lines is not None and len(lines):
         img = overlay_lines(img, cam, lines)
     if rmap is not None:
