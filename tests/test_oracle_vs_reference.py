@@ -309,3 +309,35 @@ def test_dr_constants_match_the_reference():
                  "self.robot_width = robot_width + 0.01 * np.random.uniform(-1, 1)",
                  "self.robot_length = robot_length + 0.01 * np.random.uniform(-1, 1)"):
         assert frag in obj, frag
+
+
+def test_led_spheres_are_the_reference_s_draw_calls():
+    """enable_leds: WorldObj.render_mesh (objects.py:68-121) run UNMODIFIED with recording GL mocks -- the translate of every LED, the
+    glColor4f before each gluSphere and the sphere radii -- against the table oracle/raster.py (and gym_duckietown/simulator.py) state the
+    spheres from: positions in the dict's order, DuckiebotObj.leds_color for a follower, blue for any other duckiebot-kind object, a
+    1 cm sphere at alpha 1 and a halo of mean(colour) x 4 cm at alpha 0.2."""
+    from oracle import raster
+    r, ns = _ref("loop_dyn_duckiebots", False, 1)
+    gl, glu = ns.objects.gl, ns.objects.gluSphere
+    bot = [o for o in r.objects if o.kind == "duckiebot"][0]
+    blue = copy.copy([o for o in r.objects if o.kind == "duckie"][0])
+    blue.kind = "duckiebot"                              # a static WorldObj of kind duckiebot: not a DuckiebotObj
+    for obj, colours in ((bot, raster.LED_FOLLOWER), (blue, raster.LED_STATIC)):
+        gl.reset_mock(); glu.reset_mock()
+        obj.render_mesh(segment=False, enable_leds=True)
+        tr = [tuple(float(v) for v in c.args) for c in gl.glTranslatef.call_args_list]
+        assert tr == [tuple(p) for p in raster.LED_POSITIONS]
+        cols = [tuple(float(v) for v in c.args) for c in gl.glColor4f.call_args_list]
+        radii = [float(c.args[1]) for c in glu.call_args_list]
+        assert all(c.args[2:] == (10, 10) for c in glu.call_args_list)
+        assert len(cols) == 15 and len(radii) == 10       # per LED: sphere colour, halo colour, reset to white
+        for k, col in enumerate(colours):
+            assert cols[3 * k] == (*col, 1.0) and cols[3 * k + 1] == (*col, 0.2) and cols[3 * k + 2] == (1.0, 1.0, 1.0, 1.0)
+            assert radii[2 * k] == 0.01 and abs(radii[2 * k + 1] - float(np.mean(col)) * 0.04) < 1e-15
+        assert gl.glBlendFunc.call_args_list[0].args == (gl.GL_SRC_ALPHA, gl.GL_ONE)
+    gl.reset_mock(); glu.reset_mock()
+    bot.render_mesh(segment=False, enable_leds=False)
+    assert not glu.called                                 # off by default
+    duck = [o for o in r.objects if o.kind == "duckie"][0]
+    duck.render_mesh(segment=False, enable_leds=True)
+    assert not glu.called                                 # duckiebot-kind objects only
