@@ -411,21 +411,7 @@ class Simulator(_EnvBase):
         out = []
         ang = float(self.cur_angle)
         if self.draw_curve:
-            dir_vec = get_dir_vec(ang)
-            ts = np.arange(20, dtype=np.float64) / 19.0
-            for tile in self.grid:
-                if tile is None or not tile["drivable"]:
-                    continue
-                curves = np.asarray(tile["curves"], dtype=np.float64)
-                heads = curves[:, -1, :] - curves[:, 0, :]
-                heads = heads / np.linalg.norm(heads).reshape(1, -1)           # (the reference's scalar norm: the argmax is unaffected)
-                best = int(np.argmax(np.dot(heads, dir_vec)))
-                for idx in [best] + [i for i in range(len(curves)) if i != best]:
-                    cps = curves[idx]
-                    pts = np.stack([bezier_point(cps, t) for t in ts])
-                    col = (1.0, 0.0, 0.0) if idx == best else (0.0, 0.0, 1.0)
-                    for a, b in zip(pts[:-1], pts[1:]):
-                        out.append([*a, *b, *col])
+            out.extend(curve_overlay_segments(self.grid, ang))
         if self.draw_bbox:
             vis = self._sim.read(_ffi.FIELD_OBJ_VISIBLE)[0]
             cen, yrot = self._sim.read(_ffi.FIELD_OBJ_CENTER)[0], self._sim.read(_ffi.FIELD_OBJ_YROT)[0]
@@ -662,6 +648,29 @@ class Simulator(_EnvBase):
 
 
 # ---- module-level helpers of the reference (simulator.py:2056-2116) ------------------
+def curve_overlay_segments(grid, angle: float) -> list:
+    """draw_curve (simulator.py:1886-1904): per drivable tile, in grid order, the curve whose chord has the largest dot product with the
+    heading first, red, then the tile's other curves, blue; each as bezier_draw draws it (graphics.py:336-349): 20 points at t = i / 19, a
+    line strip = 19 segments.  Rows (ax, ay, az, bx, by, bz, r, g, b)."""
+    out = []
+    dir_vec = get_dir_vec(angle)
+    ts = np.arange(20, dtype=np.float64) / 19.0
+    for tile in grid:
+        if tile is None or not tile["drivable"]:
+            continue
+        curves = np.asarray(tile["curves"], dtype=np.float64)
+        heads = curves[:, -1, :] - curves[:, 0, :]
+        heads = heads / np.linalg.norm(heads).reshape(1, -1)           # (the reference's scalar norm: the argmax is unaffected)
+        best = int(np.argmax(np.dot(heads, dir_vec)))
+        for idx in [best] + [i for i in range(len(curves)) if i != best]:
+            cps = curves[idx]
+            pts = np.stack([bezier_point(cps, t) for t in ts])
+            col = (1.0, 0.0, 0.0) if idx == best else (0.0, 0.0, 1.0)
+            for a, b in zip(pts[:-1], pts[1:]):
+                out.append([*a, *b, *col])
+    return out
+
+
 def bezier_point(cps, t):
     """graphics.py:286-295: cubic Bezier point of the control points [4, 3] at t."""
     cps = np.asarray(cps, dtype=np.float64)

@@ -341,3 +341,32 @@ def test_led_spheres_are_the_reference_s_draw_calls():
     duck = [o for o in r.objects if o.kind == "duckie"][0]
     duck.render_mesh(segment=False, enable_leds=True)
     assert not glu.called                                 # duckiebot-kind objects only
+
+
+def test_curve_overlay_segments_are_the_reference_s_bezier_draw_calls():
+    """draw_curve: graphics.bezier_draw (graphics.py:336-349) run UNMODIFIED with recording GL mocks for every curve of every drivable tile,
+    in the order and with the red / blue choice of simulator.py:1886-1904, against gym_duckietown.simulator.curve_overlay_segments (what
+    the facade hands to dtsim_draw_lines)."""
+    from gym_duckietown.simulator import curve_overlay_segments
+    r, ns = _ref("loop_only_duckies", False, 3)
+    gl = ns.graphics.gl
+    for ang in (0.3, 2.0, -1.2):
+        want = []
+        dir_vec = ns.simulator.get_dir_vec(ang)
+        for tile in r.grid:
+            if tile is None or not tile["drivable"]:
+                continue
+            curves = tile["curves"]
+            heads = curves[:, -1, :] - curves[:, 0, :]
+            heads = heads / np.linalg.norm(heads).reshape(1, -1)                                  # simulator.py:1890-1893
+            best = int(np.argmax(np.dot(heads, dir_vec)))
+            for idx, red in [(best, True)] + [(i, False) for i in range(len(curves)) if i != best]:
+                gl.reset_mock()
+                ns.graphics.bezier_draw(curves[idx], n=20, red=red)
+                col = tuple(float(v) for v in gl.glColor3f.call_args_list[0].args)
+                pts = [tuple(float(v) for v in c.args) for c in gl.glVertex3f.call_args_list]
+                assert len(pts) == 20 and gl.glBegin.call_args.args == (gl.GL_LINE_STRIP,)
+                want += [[*a, *b, *col] for a, b in zip(pts[:-1], pts[1:])]
+        got = np.asarray(curve_overlay_segments(r.grid, ang), dtype=np.float64)
+        assert got.shape == (len(want), 9)
+        assert np.array_equal(got, np.asarray(want, dtype=np.float64))
