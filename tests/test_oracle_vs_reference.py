@@ -370,3 +370,105 @@ def test_curve_overlay_segments_are_the_reference_s_bezier_draw_calls():
         got = np.asarray(curve_overlay_segments(r.grid, ang), dtype=np.float64)
         assert got.shape == (len(want), 9)
         assert np.array_equal(got, np.asarray(want, dtype=np.float64))
+
+
+def _gl_floats(gl, kind):
+    """Arguments of the (GLfloat * n)(...) constructions recorded on the gl mock, in call order (kind: the mock call name)."""
+    return [tuple(float(v) for v in c.args) for c in gl.mock_calls if c[0] == kind]
+
+
+@pytest.mark.parametrize("dr", [False, True])
+def test_frame_gl_arguments_are_the_oracle_s_camera_and_scene(dr):
+    """The GL raster itself cannot run here, but every ARGUMENT the reference hands to it can be read: reset() (simulator.py:565-584) and
+    _render_img (:1707-1951) run UNMODIFIED against a recording gl mock -- projection, model-view, clear colour, light, ground quad, per-tile
+    and per-object transforms -- and are compared with what oracle/raster.py renders from (Camera, Scene): what is left unpinned of the
+    raster is what fixed-function GL does with these numbers, not which numbers it is given."""
+    import math
+    from unittest.mock import MagicMock
+    from oracle import raster
+    seed, W, H = 7, 640, 480
+    r, ns = _ref("small_loop_only_duckies", dr, seed)
+    o = osim.OracleSim(assets.get_map("small_loop_only_duckies"), EXT, domain_rand=dr, seed=seed, do_reset=False)
+    gl = ns.simulator.gl
+    gl.reset_mock()
+    r.reset(); o.reset()
+    assert np.array_equal(r.cur_pos, o.cur_pos) and r.cur_angle == o.cur_angle
+    # ---- reset(): the light (position, ambient, diffuse, specular), simulator.py:565-584
+    lf = _gl_floats(gl, "GLfloat.__mul__()")
+    assert lf[0][:len(o.light_pos)] == tuple(float(v) for v in o.light_pos)      # (a 3-vector under domain randomisation: w is whatever GLfloat * 4 zero-fills = directional)
+    assert lf[1] == tuple(float(v) for v in o.light_ambient) and lf[2] == tuple(float(v) for v in o.light_diffuse) and lf[3] == (0.0, 0.0, 0.0, 1.0)
+    # the vertex lists (simulator.py:386-526): the tile quad grid with its texture coordinates, the ground quad
+    saved_vl, rec_vl = ns.simulator.pyglet.graphics.vertex_list, MagicMock()
+    ns.simulator.pyglet.graphics.vertex_list = rec_vl    # (other tests of this file install their own stand-in on the shared pyglet mock)
+    try:
+        type(r)._init_vlists(r)                          # (refstub's instances carry a no-op in its place: call the class's own)
+    finally:
+        ns.simulator.pyglet.graphics.vertex_list = saved_vl
+    (n_road, road_v, road_t, _, _), (n_gnd, gnd_v) = [c.args for c in rec_vl.call_args_list]
+    road_v, road_t = np.asarray(road_v[1]).reshape(-1, 3), np.asarray(road_t[1]).reshape(-1, 2)
+    gnd_v = np.asarray(gnd_v[1], dtype=np.float64).reshape(4, 3)
+    # ---- one frame
+    r.graphics = True
+    r.shadow_window = MagicMock(); r.draw_bbox = False; r.draw_curve = False; r.enable_leds = False
+    r.road_vlist, r.ground_vlist, r.tri_vlist = MagicMock(), MagicMock(), MagicMock()
+    gl.reset_mock()
+    with pytest.raises(TypeError):                       # glReadPixels wants a ctypes pointer type: every draw call has been issued by then
+        r._render_img(W, H, MagicMock(), MagicMock(), np.zeros((H, W, 3), np.uint8), top_down=False, segment=False)
+    calls = gl.mock_calls
+    by = lambda name: [c for c in calls if c[0] == name]
+    f1 = lambda v: float(np.ravel(v)[0])                   # (the randomiser's draws are 1-element arrays)
+    cam = raster.Camera(o.cur_pos, o.cur_angle, cam_height=f1(o.cam_height), cam_angle_deg=f1(o.cam_angle[0]), cam_fov_y_deg=f1(o.cam_fov_y),
+                        camera_noise=list(o.randomization_settings["camera_noise"]) if dr else (0, 0, 0), domain_rand=dr,
+                        horizon_color=list(o.horizon_color), ground_color=list(o.ground_color), light_pos=list(o.light_pos),
+                        light_ambient=list(o.light_ambient), light_diffuse=list(o.light_diffuse), width=W, height=H)
+    assert _gl_floats(gl, "GLfloat.__mul__()")[0] == (0.3, 0.3, 0.3, 1.0)                      # GL_LIGHT_MODEL_AMBIENT: Camera.base = 0.3 + light ambient
+    assert np.allclose(cam.base, 0.3 + np.asarray(lf[1][:3]), atol=0, rtol=0) and np.array_equal(cam.dif, np.asarray(lf[2][:3]))
+    cc = [float(v) for v in by("glClearColor")[0].args]
+    assert np.array_equal(cam.horizon, np.asarray(cc[:3]) * 255.0)
+    fov, aspect, near, far = by("gluPerspective")[0].args
+    assert float(np.ravel(fov)[0]) == float(np.ravel(o.cam_fov_y)[0]) and aspect == W / float(H) and (near, far) == (raster.NEAR, raster.FAR)
+    assert cam.ty == math.tan(math.radians(float(np.ravel(fov)[0])) / 2) and cam.tx == cam.ty * aspect
+    i_mv = max(i for i, c in enumerate(calls) if c[0] == "gluLookAt")
+    rots = [c.args for c in calls[:i_mv] if c[0] == "glRotatef"][-3:]
+    assert [float(np.ravel(a[0])[0]) for a in rots] == [float(np.ravel(v)[0]) for v in o.cam_angle] and [tuple(a[1:]) for a in rots] == [(1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    assert [c.args for c in calls[:i_mv] if c[0] == "glTranslatef"][-1] == (0, 0, raster.CAMERA_FORWARD_DIST)
+    la = [f1(v) for v in calls[i_mv].args]
+    eye, tgt, up = np.asarray(la[0:3]), np.asarray(la[3:6]), la[6:9]
+    d = np.array([math.cos(o.cur_angle), 0.0, -math.sin(o.cur_angle)])
+    assert up == [0.0, 1.0, 0.0] and np.allclose(tgt - eye, d, atol=1e-15)
+    # model-view = Rx(cam_angle) T(0, 0, forward) LookAt(eye, eye + dir): the eye of the composite sits `forward` ahead of the look-at eye, pitched down
+    assert np.allclose(cam.C, eye + raster.CAMERA_FORWARD_DIST * d, atol=1e-15)
+    assert cam.sth == math.sin(math.radians(f1(rots[0][0]))) and cam.cth == math.cos(math.radians(f1(rots[0][0])))
+    # ---- ground quad: colour, scale and vertices (simulator.py:1806-1812)
+    i_g = next(i for i, c in enumerate(calls) if c[0] == "glScalef")
+    assert calls[i_g].args == (50, 0.01, 50) and [float(v) for v in calls[i_g - 2].args] == [float(v) for v in o.ground_color]
+    assert np.array_equal(cam.ground, np.asarray(o.ground_color, dtype=np.float64)[:3] * 255.0)
+    g = gnd_v * np.array([50, 0.01, 50])
+    assert raster.GROUND_HALF == 50.0 and set(np.abs(g[:, 0])) == {50.0} and set(np.abs(g[:, 2])) == {50.0} and np.allclose(g[:, 1], raster.GROUND_Y, atol=1e-18)
+    # ---- tiles (simulator.py:1853-1884): translate to the tile centre, rotate angle * 90 + 180 about y, the 7 x 7 quad grid with uv = (pu, 1 - pv)
+    scene = raster.Scene(o.map, {}, {})
+    ts = o.map.tile_size
+    tile_calls = [(calls[i + 1].args, calls[i + 2].args) for i, c in enumerate(calls) if c[0] == "glPushMatrix" and calls[i + 2][0] == "glRotatef" and calls[i + 3][0] == "glBindTexture"]
+    tiles = [(i, j) for i in range(o.map.grid_width) for j in range(o.map.grid_height) if o.map.grid[j * o.map.grid_width + i] is not None]
+    assert len(tile_calls) == len(tiles) == int(scene.present.sum())
+    pts = np.random.default_rng(0).uniform(0.02, 0.98, (40, 2))
+    for (tr, rot), (i, j) in zip(tile_calls, tiles):
+        ang = o.map.grid[j * o.map.grid_width + i]["angle"]
+        assert tuple(float(v) for v in tr) == ((i + 0.5) * ts, 0.0, (j + 0.5) * ts) and rot == (ang * 90 + 180, 0, 1, 0)
+        th = math.radians(rot[0])
+        for fx, fz in pts:                                 # world point of the tile -> the quad's local frame (inverse of glRotatef about y) -> its texture coordinate
+            dx, dz = (fx - 0.5) * ts, (fz - 0.5) * ts
+            x, z = dx * math.cos(th) - dz * math.sin(th), dx * math.sin(th) + dz * math.cos(th)
+            u_ref, v_ref = x / ts + 0.5, 1.0 - (z / ts + 0.5)                                    # get_point: tu = pu, tv = 1 - pv, linear over the grid
+            u, v = raster._tile_uv(np.int64(ang), np.float64(fx), np.float64(fz))
+            assert abs(float(u) - u_ref) < 1e-12 and abs(float(v) - v_ref) < 1e-12
+    assert np.allclose(road_v[:, 1], 0.0) and np.allclose(road_t[:, 0], road_v[:, 0] / ts + 0.5) and np.allclose(road_t[:, 1], 1.0 - (road_v[:, 2] / ts + 0.5))
+    assert n_road == 4 * 49 and n_gnd == 4
+    # ---- objects (objects.py:123-148): translate(pos) scale(s) rotate(x_rot = 0, y_rot, z_rot = 0), glColor4f(obj colour)
+    obj_calls = [(calls[i + 1].args, calls[i + 2].args, calls[i + 4].args) for i, c in enumerate(calls)
+                 if c[0] == "glPushMatrix" and calls[i + 2][0] == "glScalef" and calls[i + 2].args != (50, 0.01, 50)]
+    vis = [ob for ob in o.map.objects if ob.visible]
+    assert len(obj_calls) == len(vis) > 0
+    for (tr, sc, ry), ob in zip(obj_calls, vis):
+        assert np.array_equal(np.asarray(tr, dtype=np.float64), np.asarray(ob.pos, dtype=np.float64))
+        assert float(sc[0]) == float(sc[1]) == float(sc[2]) == float(ob.scale) and float(ry[0]) == float(ob.y_rot) and tuple(ry[1:]) == (0, 1, 0)
