@@ -404,14 +404,14 @@ class Simulator(_EnvBase):
     # ---------------------------------------------------------------- GL_LINE overlays --
     def _overlay_lines(self) -> np.ndarray:
         """World-space segments [n, 9] of the reference's line overlays, in its draw order.
-        draw_curve (simulator.py:1886-1904): per drivable tile (row-major) the curve whose chord has the largest dot product with the
-        heading first, red, then the tile's other curves, blue -- bezier_draw (graphics.py:336-349): 20 points, 19 segments, at the
-        height of the control points.  draw_bbox (:1907-1918, objects.py:131-139): the collision rectangle of every visible object,
-        then the agent's, at y = 0.01, red."""
+        draw_curve (simulator.py:1886-1904): per drivable tile (the tile loop's order) the curve whose chord has the largest dot product with
+        the loop's `angle` first, red, then the tile's other curves, blue (curve_overlay_segments: the reference compares with the TILE's
+        orientation index, not the heading) -- bezier_draw (graphics.py:336-349): 20 points, 19 segments, at the height of the control points.  draw_bbox (:1907-1918, objects.py:131-139): the collision rectangle of every visible object,
+        then the agent's (with the reference's shadowed angle: agent_bbox_angle), at y = 0.01, red."""
         out = []
         ang = float(self.cur_angle)
         if self.draw_curve:
-            out.extend(curve_overlay_segments(self.grid, ang))
+            out.extend(curve_overlay_segments(self.grid, self.grid_width, self.grid_height))
         if self.draw_bbox:
             vis = self._sim.read(_ffi.FIELD_OBJ_VISIBLE)[0]
             cen, yrot = self._sim.read(_ffi.FIELD_OBJ_CENTER)[0], self._sim.read(_ffi.FIELD_OBJ_YROT)[0]
@@ -430,7 +430,9 @@ class Simulator(_EnvBase):
                         raw = [(mn[0] * sc, mn[2] * sc), (mx[0] * sc, mn[2] * sc), (mx[0] * sc, mx[2] * sc), (mn[0] * sc, mx[2] * sc)]
                         c = np.array([[now[0] + x * math.cos(th) + z * math.sin(th), now[1] - x * math.sin(th) + z * math.cos(th)] for x, z in raw])
                 loops.append(c)
-            loops.append(get_agent_corners(self.cur_pos, ang))
+            # the agent's own rectangle (:1910-1918) -- at the pose's position but with `angle` as the tile loop above it left it (:1862 rebinds the
+            # name): the orientation INDEX (0..3) of the last tile drawn, read as radians.  Reproduced as the reference draws it.
+            loops.append(get_agent_corners(self.cur_pos, agent_bbox_angle(self.grid, self.grid_width, self.grid_height, ang)))
             for c in loops:
                 for i in range(4):
                     a, b = c[i], c[(i + 1) % 4]
@@ -496,25 +498,13 @@ class Simulator(_EnvBase):
         pos, ang = self.cur_pos, self.cur_angle
         if not self.domain_rand:
             s0.camera_noise[:] = [0.0, 0.0, 0.0]                      # drawn, but only applied under domain_rand (:1768-1769)
-        if top_down:                                                  # gluLookAt((a, H, b), (a, 0, b - 0.01), +y)  (:1786-1798)
-            a = self.grid_width * self.road_tile_size / 2
-            b = self.grid_height * self.road_tile_size / 2
-            h_from_floor = (max(a, b) + 0.1) / math.tan(math.radians(s0.cam_fov_y_deg) / 2)
-            # the camera model puts the eye CAMERA_FORWARD_DIST ahead of `pos` along dir = (cos, 0, -sin)
-            s0.pos[:] = [a, 0.0, b + CAMERA_FORWARD_DIST]
-            s0.angle = math.pi / 2
-            s0.cam_height = h_from_floor
-            s0.cam_angle_deg = math.degrees(math.atan2(h_from_floor, 0.01))
+        vp, va, vh, vdeg = viewer_camera(top_down, bbox, pos, float(ang), self.grid_width, self.grid_height, self.road_tile_size, s0.cam_fov_y_deg)
+        s0.pos[:] = vp
+        s0.angle = va
+        if vh is not None:
+            s0.cam_height, s0.cam_angle_deg = vh, vdeg
+        if top_down:
             s0.camera_noise[:] = [0.0, 0.0, 0.0]
-        elif bbox:                                                    # draw_bbox (:1776-1778): y += 0.8, glRotatef(90, 1, 0, 0), no forward offset
-            d = get_dir_vec(float(ang))
-            s0.pos[:] = [float(pos[0]) - CAMERA_FORWARD_DIST * d[0], 0.0, float(pos[2]) - CAMERA_FORWARD_DIST * d[2]]
-            s0.angle = float(ang)
-            s0.cam_height = 0.8
-            s0.cam_angle_deg = 90.0
-        else:
-            s0.pos[:] = [float(pos[0]), 0.0, float(pos[2])]
-            s0.angle = float(ang)
         v.init_states = st
         v.reset(states=st)
         for f in (_ffi.FIELD_OBJ_CENTER, _ffi.FIELD_OBJ_YROT, _ffi.FIELD_OBJ_Y, _ffi.FIELD_OBJ_ACTIVE, _ffi.FIELD_OBJ_VISIBLE,
@@ -648,26 +638,57 @@ class Simulator(_EnvBase):
 
 
 # ---- module-level helpers of the reference (simulator.py:2056-2116) ------------------
-def curve_overlay_segments(grid, angle: float) -> list:
-    """draw_curve (simulator.py:1886-1904): per drivable tile, in grid order, the curve whose chord has the largest dot product with the
-    heading first, red, then the tile's other curves, blue; each as bezier_draw draws it (graphics.py:336-349): 20 points at t = i / 19, a
-    line strip = 19 segments.  Rows (ax, ay, az, bx, by, bz, r, g, b)."""
+def viewer_camera(top_down: bool, bbox: bool, pos, ang: float, grid_width: int, grid_height: int, tile_size: float, fov_y_deg: float):
+    """The window / debugging views of _render_img as parameters of THIS backend's camera model -- eye = pos + CAMERA_FORWARD_DIST * dir +
+    (0, cam_height, 0), dir = (cos, 0, -sin), pitched down by cam_angle_deg -- returned as (pos, angle, cam_height or None, cam_angle_deg):
+      top_down  gluLookAt((a, H, b), (a, 0, b - 0.01), +y), H = (max(a, b) + 0.1) / tan(fov_y / 2)   (simulator.py:1786-1798)
+      bbox      draw_bbox: y += 0.8, glRotatef(90, 1, 0, 0), no forward offset                        (:1776-1778)
+      else      the agent camera at the current pose (cam_height / cam_angle_deg stay the env's)."""
+    if top_down:
+        a, b = grid_width * tile_size / 2, grid_height * tile_size / 2
+        h_from_floor = (max(a, b) + 0.1) / math.tan(math.radians(fov_y_deg) / 2)
+        return [a, 0.0, b + CAMERA_FORWARD_DIST], math.pi / 2, h_from_floor, math.degrees(math.atan2(h_from_floor, 0.01))
+    if bbox:
+        d = get_dir_vec(float(ang))
+        return [float(pos[0]) - CAMERA_FORWARD_DIST * d[0], 0.0, float(pos[2]) - CAMERA_FORWARD_DIST * d[2]], float(ang), 0.8, 90.0
+    return [float(pos[0]), 0.0, float(pos[2])], float(ang), None, None
+
+
+def agent_bbox_angle(grid, grid_width: int, grid_height: int, angle: float) -> float:
+    """The angle _render_img hands to get_agent_corners for the agent's draw_bbox rectangle (simulator.py:1910-1911): its tile loop
+    (`for i, j in itertools.product(range(grid_width), range(grid_height))`, :1853) rebinds `angle = tile["angle"]` (:1862), so the rectangle
+    is drawn with the orientation index of the LAST non-empty tile in that order, as radians; the pose's angle only if the map has no tile."""
+    for i in range(grid_width - 1, -1, -1):
+        for j in range(grid_height - 1, -1, -1):
+            t = grid[j * grid_width + i]
+            if t is not None:
+                return float(t["angle"])
+    return float(angle)
+
+
+def curve_overlay_segments(grid, grid_width: int, grid_height: int) -> list:
+    """draw_curve (simulator.py:1853-1904) as _render_img draws it: per drivable tile, in the tile loop's order (`itertools.product(range(grid_width),
+    range(grid_height))`: columns outer), first the curve whose chord has the largest dot product with get_dir_vec(angle), red, then the tile's other
+    curves, blue -- where `angle` is NOT the agent's heading: the loop rebinds the name to the tile's orientation index (:1862), so the reference
+    direction is get_dir_vec(0 .. 3 radians) per tile.  Reproduced as drawn.  Each curve as bezier_draw draws it (graphics.py:336-349): 20 points
+    at t = i / 19, a line strip = 19 segments.  Rows (ax, ay, az, bx, by, bz, r, g, b)."""
     out = []
-    dir_vec = get_dir_vec(angle)
     ts = np.arange(20, dtype=np.float64) / 19.0
-    for tile in grid:
-        if tile is None or not tile["drivable"]:
-            continue
-        curves = np.asarray(tile["curves"], dtype=np.float64)
-        heads = curves[:, -1, :] - curves[:, 0, :]
-        heads = heads / np.linalg.norm(heads).reshape(1, -1)           # (the reference's scalar norm: the argmax is unaffected)
-        best = int(np.argmax(np.dot(heads, dir_vec)))
-        for idx in [best] + [i for i in range(len(curves)) if i != best]:
-            cps = curves[idx]
-            pts = np.stack([bezier_point(cps, t) for t in ts])
-            col = (1.0, 0.0, 0.0) if idx == best else (0.0, 0.0, 1.0)
-            for a, b in zip(pts[:-1], pts[1:]):
-                out.append([*a, *b, *col])
+    for i in range(grid_width):
+        for j in range(grid_height):
+            tile = grid[j * grid_width + i]
+            if tile is None or not tile["drivable"]:
+                continue
+            curves = np.asarray(tile["curves"], dtype=np.float64)
+            heads = curves[:, -1, :] - curves[:, 0, :]
+            heads = heads / np.linalg.norm(heads).reshape(1, -1)           # (the reference's scalar norm: the argmax is unaffected)
+            best = int(np.argmax(np.dot(heads, get_dir_vec(float(tile["angle"])))))
+            for idx in [best] + [k for k in range(len(curves)) if k != best]:
+                cps = curves[idx]
+                pts = np.stack([bezier_point(cps, t) for t in ts])
+                col = (1.0, 0.0, 0.0) if idx == best else (0.0, 0.0, 1.0)
+                for p0, p1 in zip(pts[:-1], pts[1:]):
+                    out.append([*p0, *p1, *col])
     return out
 
 

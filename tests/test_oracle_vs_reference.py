@@ -343,32 +343,40 @@ def test_led_spheres_are_the_reference_s_draw_calls():
     assert not glu.called                                 # duckiebot-kind objects only
 
 
-def test_curve_overlay_segments_are_the_reference_s_bezier_draw_calls():
-    """draw_curve: graphics.bezier_draw (graphics.py:336-349) run UNMODIFIED with recording GL mocks for every curve of every drivable tile,
-    in the order and with the red / blue choice of simulator.py:1886-1904, against gym_duckietown.simulator.curve_overlay_segments (what
-    the facade hands to dtsim_draw_lines)."""
+def test_curve_overlay_segments_are_the_reference_s_draw_calls():
+    """draw_curve: _render_img (simulator.py:1853-1904) run UNMODIFIED with draw_curve on against a recording gl mock -- the colour and the 20
+    vertices of every line strip bezier_draw (graphics.py:336-349) emits, in order -- against gym_duckietown.simulator.curve_overlay_segments
+    (what the facade hands to dtsim_draw_lines).  Bit-identical, including the reference's quirk: the "heading" the red curve is chosen by is
+    the tile's orientation index (the tile loop rebinds `angle`), not the agent's."""
+    from unittest.mock import MagicMock
     from gym_duckietown.simulator import curve_overlay_segments
-    r, ns = _ref("loop_only_duckies", False, 3)
-    gl = ns.graphics.gl
-    for ang in (0.3, 2.0, -1.2):
-        want = []
-        dir_vec = ns.simulator.get_dir_vec(ang)
-        for tile in r.grid:
-            if tile is None or not tile["drivable"]:
-                continue
-            curves = tile["curves"]
-            heads = curves[:, -1, :] - curves[:, 0, :]
-            heads = heads / np.linalg.norm(heads).reshape(1, -1)                                  # simulator.py:1890-1893
-            best = int(np.argmax(np.dot(heads, dir_vec)))
-            for idx, red in [(best, True)] + [(i, False) for i in range(len(curves)) if i != best]:
-                gl.reset_mock()
-                ns.graphics.bezier_draw(curves[idx], n=20, red=red)
-                col = tuple(float(v) for v in gl.glColor3f.call_args_list[0].args)
-                pts = [tuple(float(v) for v in c.args) for c in gl.glVertex3f.call_args_list]
-                assert len(pts) == 20 and gl.glBegin.call_args.args == (gl.GL_LINE_STRIP,)
-                want += [[*a, *b, *col] for a, b in zip(pts[:-1], pts[1:])]
-        got = np.asarray(curve_overlay_segments(r.grid, ang), dtype=np.float64)
-        assert got.shape == (len(want), 9)
+    W, H = 640, 480
+    for m, seed in (("loop_only_duckies", 3), ("small_loop_only_duckies", 4)):
+        r, ns = _ref(m, False, seed)
+        r.reset()
+        gl = ns.simulator.gl
+        assert ns.graphics.gl is gl
+        r.graphics = True
+        r.shadow_window = MagicMock(); r.draw_curve = True; r.enable_leds = False; r.draw_bbox = False
+        r.road_vlist, r.ground_vlist, r.tri_vlist = MagicMock(), MagicMock(), MagicMock()
+        gl.reset_mock()
+        with pytest.raises(TypeError):                   # glReadPixels wants a ctypes pointer type: every draw call has been issued by then
+            r._render_img(W, H, MagicMock(), MagicMock(), np.zeros((H, W, 3), np.uint8), top_down=False, segment=False)
+        want, col, pts = [], None, None
+        for c in gl.mock_calls:
+            if c[0] == "glBegin" and c.args == (gl.GL_LINE_STRIP,):
+                pts = []
+            elif c[0] == "glColor3f" and pts is not None and not pts:
+                col = tuple(float(v) for v in c.args)
+            elif c[0] == "glVertex3f" and pts is not None:
+                pts.append(tuple(float(v) for v in c.args))
+            elif c[0] == "glEnd" and pts is not None:
+                assert len(pts) == 20 and col in ((1.0, 0.0, 0.0), (0.0, 0.0, 1.0))
+                want += [[*p0, *p1, *col] for p0, p1 in zip(pts[:-1], pts[1:])]
+                pts = None
+        got = np.asarray(curve_overlay_segments(r.grid, r.grid_width, r.grid_height), dtype=np.float64)
+        n_curves = sum(len(t["curves"]) for t in r.grid if t is not None and t["drivable"])
+        assert got.shape == (19 * n_curves, 9) == (len(want), 9)
         assert np.array_equal(got, np.asarray(want, dtype=np.float64))
 
 
@@ -472,3 +480,62 @@ def test_frame_gl_arguments_are_the_oracle_s_camera_and_scene(dr):
     for (tr, sc, ry), ob in zip(obj_calls, vis):
         assert np.array_equal(np.asarray(tr, dtype=np.float64), np.asarray(ob.pos, dtype=np.float64))
         assert float(sc[0]) == float(sc[1]) == float(sc[2]) == float(ob.scale) and float(ry[0]) == float(ob.y_rot) and tuple(ry[1:]) == (0, 1, 0)
+
+
+@pytest.mark.parametrize("mode", ["top_down", "bbox"])
+def test_window_views_gl_arguments_are_the_facade_s_viewer_camera(mode):
+    """render(mode="top_down") and draw_bbox: the reference's model-view for those views (simulator.py:1776-1778, 1786-1798), read from the
+    recording gl mock, against gym_duckietown.simulator.viewer_camera (the parameters the facade gives this backend's camera model) -- and,
+    for draw_bbox, the line loops it draws (objects.py:131-139, simulator.py:1910-1918) against the collision rectangles the facade outlines."""
+    import math
+    from unittest.mock import MagicMock
+    from gym_duckietown.simulator import viewer_camera
+    from oracle import raster
+    W, H = 800, 600
+    r, ns = _ref("small_loop_only_duckies", False, 9)
+    o = osim.OracleSim(assets.get_map("small_loop_only_duckies"), EXT, domain_rand=False, seed=9, do_reset=False)
+    gl = ns.simulator.gl
+    r.reset(); o.reset()
+    r.graphics = True
+    r.shadow_window = MagicMock(); r.draw_curve = False; r.enable_leds = False; r.draw_bbox = mode == "bbox"
+    r.road_vlist, r.ground_vlist, r.tri_vlist, r.mesh = MagicMock(), MagicMock(), MagicMock(), MagicMock()
+    gl.reset_mock()
+    with pytest.raises(TypeError):
+        r._render_img(W, H, MagicMock(), MagicMock(), np.zeros((H, W, 3), np.uint8), top_down=mode == "top_down", segment=False)
+    calls = gl.mock_calls
+    i_la = max(i for i, c in enumerate(calls) if c[0] == "gluLookAt")
+    la = [float(np.ravel(v)[0]) for v in calls[i_la].args]
+    eye, tgt = np.asarray(la[0:3]), np.asarray(la[3:6])
+    i_mv = max(i for i, c in enumerate(calls[:i_la]) if c[0] == "glLoadIdentity")
+    pre = [c for c in calls[i_mv:i_la] if c[0] in ("glRotatef", "glTranslatef")]
+    fov = float(np.ravel(o.cam_fov_y)[0])
+    vp, va, vh, vdeg = viewer_camera(mode == "top_down", mode == "bbox", o.cur_pos, o.cur_angle, o.map.grid_width, o.map.grid_height, o.map.tile_size, fov)
+    cam = raster.Camera(vp, va, cam_height=vh, cam_angle_deg=vdeg, cam_fov_y_deg=fov, width=W, height=H)
+    if mode == "top_down":
+        assert pre == []                                                       # no pitch, no forward offset: the look-at alone
+        assert np.allclose(cam.C, eye, atol=1e-12)
+        fwd = (tgt - eye) / np.linalg.norm(tgt - eye)                          # the view direction of the look-at = the camera's pitched forward axis
+        mine = np.array([cam.ca * cam.cth, -cam.sth, -cam.sa * cam.cth])
+        assert np.allclose(mine, fwd, atol=1e-12)
+    else:
+        assert [(c[0], c.args) for c in pre] == [("glRotatef", (90, 1, 0, 0))]
+        assert np.allclose(cam.C, eye, atol=1e-15) and abs(eye[1] - (o.cur_pos[1] + 0.8)) < 1e-15
+        assert abs(cam.sth - 1.0) < 1e-15 and abs(cam.cth) < 1e-15             # looking straight down
+        d = np.array([math.cos(o.cur_angle), 0.0, -math.sin(o.cur_angle)])
+        assert np.allclose(tgt - eye, d, atol=1e-15)
+        # the line loops: every visible object's obj_corners, then the agent's, at y = 0.01 (the objects draw through objects.gl)
+        all_v = [tuple(float(v) for v in c.args) for c in calls if c[0] == "glVertex3f"]           # (objects.gl is the same mock: one sequence)
+        vis = [ob for ob in o.map.objects if ob.visible]
+        assert len(all_v) == 4 * len(vis) + 4
+        obj_v = all_v[:-4]
+        for k, ob in enumerate(vis):
+            c = np.asarray(ob.obj_corners, dtype=np.float64)
+            c = c.T if c.shape == (2, 4) else c.reshape(4, 2)
+            assert obj_v[4 * k:4 * k + 4] == [(float(c[i, 0]), 0.01, float(c[i, 1])) for i in range(4)]
+        ag = all_v[-4:]
+        # the agent's rectangle uses `angle` as the tile loop left it (simulator.py:1862 rebinds the name): the last tile's orientation index as radians
+        from gym_duckietown.simulator import agent_bbox_angle
+        a_box = agent_bbox_angle(o.map.grid, o.map.grid_width, o.map.grid_height, o.cur_angle)
+        assert a_box in (0.0, 1.0, 2.0, 3.0)
+        want = osim.get_agent_corners(o.cur_pos, a_box)
+        assert ag == [(float(want[i, 0]), 0.01, float(want[i, 1])) for i in range(4)]
