@@ -517,6 +517,10 @@ def test_window_views_gl_arguments_are_the_facade_s_viewer_camera(mode):
         fwd = (tgt - eye) / np.linalg.norm(tgt - eye)                          # the view direction of the look-at = the camera's pitched forward axis
         mine = np.array([cam.ca * cam.cth, -cam.sth, -cam.sa * cam.cth])
         assert np.allclose(mine, fwd, atol=1e-12)
+        # the agent's own mesh in this view (simulator.py:1920-1927): translate(cur_pos) scale(1) rotate(cur_angle in degrees about y), drawn unscaled
+        i_m = max(i for i, c in enumerate(calls) if c[0] == "glScalef")
+        assert calls[i_m].args == (1, 1, 1) and np.array_equal(np.asarray(calls[i_m - 1].args, dtype=np.float64), np.asarray(o.cur_pos, dtype=np.float64))
+        assert float(calls[i_m + 1].args[0]) == o.cur_angle * 180 / np.pi and tuple(calls[i_m + 1].args[1:]) == (0, 1, 0) and r.mesh.render.called
     else:
         assert [(c[0], c.args) for c in pre] == [("glRotatef", (90, 1, 0, 0))]
         assert np.allclose(cam.C, eye, atol=1e-15) and abs(eye[1] - (o.cur_pos[1] + 0.8)) < 1e-15
@@ -539,3 +543,37 @@ def test_window_views_gl_arguments_are_the_facade_s_viewer_camera(mode):
         assert a_box in (0.0, 1.0, 2.0, 3.0)
         want = osim.get_agent_corners(o.cur_pos, a_box)
         assert ag == [(float(want[i, 0]), 0.01, float(want[i, 1])) for i in range(4)]
+
+
+def test_segment_view_gl_state_is_the_oracle_s_segment_view():
+    """_render_img(segment=True) (simulator.py:1730-1737, 1753, 1808, 1815) under the recording gl mock: lighting, LIGHT0 and COLOR_MATERIAL
+    disabled, the colour buffer cleared to and the ground quad drawn in (255, 0, 255), no distractor triangles, the objects rendered with
+    segment=True -- what raster.segment_view turns a (camera, scene) into: base 1 / diffuse 0 (fragment = texture x vertex colour), magenta."""
+    from unittest.mock import MagicMock
+    from oracle import raster
+    W, H = 160, 120
+    r, ns = _ref("small_loop_only_duckies", False, 11)
+    r.reset()
+    gl = ns.simulator.gl
+    r.graphics = True
+    r.shadow_window = MagicMock(); r.draw_curve = False; r.enable_leds = False; r.draw_bbox = False
+    r.road_vlist, r.ground_vlist, r.tri_vlist = MagicMock(), MagicMock(), MagicMock()
+    for ob in r.objects:
+        ob.render = MagicMock()
+    gl.reset_mock()
+    with pytest.raises(TypeError):
+        r._render_img(W, H, MagicMock(), MagicMock(), np.zeros((H, W, 3), np.uint8), top_down=False, segment=True)
+    calls = gl.mock_calls
+    dis = [c.args[0] for c in calls if c[0] == "glDisable"]
+    assert gl.GL_LIGHT0 in dis and gl.GL_LIGHTING in dis and gl.GL_COLOR_MATERIAL in dis
+    en = [c.args[0] for c in calls if c[0] == "glEnable"]
+    assert gl.GL_LIGHTING not in en and gl.GL_LIGHT0 not in en and gl.GL_COLOR_MATERIAL not in en
+    assert [float(v) for v in [c for c in calls if c[0] == "glClearColor"][0].args] == [255.0, 0.0, 255.0, 1.0]
+    i_g = next(i for i, c in enumerate(calls) if c[0] == "glScalef")
+    assert [float(v) for v in calls[i_g - 2].args] == [255.0, 0.0, 255.0]
+    assert not r.tri_vlist.draw.called                                       # "if not segment": no distractors
+    assert all(ob.render.call_args.kwargs["segment"] is True for ob in r.objects)
+    cam = raster.Camera(r.cur_pos, r.cur_angle, width=W, height=H)
+    c2, _ = raster.segment_view(cam, raster.Scene(osim.OracleMap(assets.get_map("small_loop_only_duckies"), EXT), {}, {}), {}, {})
+    assert np.array_equal(c2.base, np.ones(3)) and np.array_equal(c2.dif, np.zeros(3))
+    assert np.array_equal(c2.horizon, [255.0, 0.0, 255.0]) and np.array_equal(c2.ground, [255.0, 0.0, 255.0])   # (clamped to 1.0 = 255 by the colour buffer)
