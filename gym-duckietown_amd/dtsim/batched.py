@@ -42,7 +42,7 @@ class BatchedSimulator:
                  map_cycle: bool = False, map_random: bool = False, transform_uses_width: bool = False,
                  map_data: Optional[dict] = None,
                  asset_root: Optional[str] = None, style: str = "photos", device_reset: bool = False,
-                 undistort: bool = False,
+                 undistort: bool = False, per_env_camera: bool = False,
                  do_reset: bool = True):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
@@ -77,7 +77,10 @@ class BatchedSimulator:
         flags = 0
         flags |= _ffi.F_RENDER if render else 0
         flags |= _ffi.F_DISTORTION if (render and distortion) else 0
-        flags |= _ffi.F_DOMAIN_RAND if domain_rand else 0
+        # per_env_camera: render through the per-env camera / light path (the device flag of domain randomisation) while the reset draws stay
+        # those of domain_rand=False -- for callers that write a per-env light or camera themselves (the gym facade's GL light capture)
+        self.per_env_camera = bool(per_env_camera)
+        flags |= _ffi.F_DOMAIN_RAND if (domain_rand or per_env_camera) else 0
         flags |= _ffi.F_AUTO_RESET if auto_reset else 0
         flags |= _ffi.F_ACTIONS_F64 if actions_f64 else 0
         flags |= _ffi.F_PROFILE if profile else 0
@@ -233,6 +236,8 @@ class BatchedSimulator:
                 dynamics_rand=self.dynamics_rand, color_sky=self.color_sky, color_ground=self.color_ground,
                 num_tris_distractors=self.num_tris_distractors, n_visible_draw=(), user_tile_start=self.user_tile_start)
             st.map_id = mi | (_ffi.MAP_RELOAD if self.map_random else 0)
+            if self.per_env_camera and not self.domain_rand:
+                st.camera_noise[:] = [0.0, 0.0, 0.0]             # drawn, but only applied under domain_rand (simulator.py:1768-1769)
             self.init_states[e] = st
             self.env_state[e].spawn_attempts = 0
             if mt.start_pose is not None:                       # simulator.py:679-688

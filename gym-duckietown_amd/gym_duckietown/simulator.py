@@ -109,6 +109,8 @@ class Simulator(_EnvBase):
         if camera_rand:
             raise NotImplementedError("camera_rand (carnivalmirror calibration sampling) is outside the path this backend implements")
         self.enable_leds = bool(enable_leds)
+        self.gl_light_capture = bool(env_kwargs.pop("gl_light_capture", True))   # reset()'s light through the last frame's model-view, as GL does (False: as given)
+        self._gl_modelview = None        # what the last frame left (None: the identity -- nothing drawn yet)
         self.seed_value = seed
         self.num_tris_distractors = num_tris_distractors
         self.color_ground, self.color_sky = color_ground, list(color_sky)
@@ -144,7 +146,7 @@ class Simulator(_EnvBase):
                 accept_start_angle_deg=accept_start_angle_deg, user_tile_start=user_tile_start, seed=seed,
                 distortion=self.distortion, dynamics_rand=dynamics_rand, num_tris_distractors=num_tris_distractors,
                 color_ground=color_ground, color_sky=color_sky, action_mode=self._ACTION_MODE, actions_f64=True,
-                device=device, style=style, do_reset=False, **env_kwargs)
+                device=device, style=style, do_reset=False, per_env_camera=self.gl_light_capture, **env_kwargs)
         except KeyError as e:
             raise InvalidMapException("Cannot load map data", map_name=map_name) from e
         except Exception as e:
@@ -330,6 +332,14 @@ class Simulator(_EnvBase):
             self._viewers = {}
         st = self._sim.init_states[0]
         es = self._sim.env_state[0]
+        if self.gl_light_capture and self._gl_modelview is not None:
+            # glLightfv(GL_POSITION) in reset() (simulator.py:565-584) is transformed by the model-view current at the call: the one the LAST frame of
+            # the previous episode left (the identity at the first reset, inside __init__).  The light the device takes is eye-space: hand it over so.
+            lp = gl_light_to_eye(self._gl_modelview, list(st.light_pos))
+            st.light_pos[:] = lp
+            col = self._sim.read(_ffi.FIELD_COLORS).copy()
+            col[0, 12:16] = lp
+            self._sim.write(_ffi.FIELD_COLORS, col)
         self.randomization_settings = es.settings
         self.horizon_color = np.array(list(st.horizon_color))
         self.ground_color = np.array(list(st.ground_color))
@@ -357,6 +367,7 @@ class Simulator(_EnvBase):
         """simulator.py:1953-1972; `segment=True` is the segmentation render (:1730-1737, 1753, 1808, 1879).
         draw_curve / draw_bbox (:1776-1778, 1886-1918): the GL_LINE overlays are a post-pass on the resolved frame
         (dtsim_draw_lines); with draw_bbox the view is the reference's debugging camera 0.8 m above the robot, looking down."""
+        self._note_modelview(False, self.draw_bbox)
         if self.draw_bbox:
             v = self._viewer(False, (self.camera_width, self.camera_height))
             self._sync_viewer(v, top_down=False, bbox=True)
@@ -449,12 +460,28 @@ class Simulator(_EnvBase):
             return
         v = self._viewer(self.distortion and mode != "free_cam")
         self._sync_viewer(v, top_down=(mode == "top_down"), bbox=self.draw_bbox and mode != "top_down")
+        self._note_modelview(mode == "top_down", self.draw_bbox and mode != "top_down")
         v.render(segment=bool(segment))
         if self.enable_leds and not segment:             # (the stand-in for self.mesh in the top-down view is not a WorldObj: no LEDs, as in the reference)
             v.draw_leds(self._led_spheres())
         if self.draw_curve or self.draw_bbox:
             v.draw_lines(self._overlay_lines())
         return v.frames_host()[0]
+
+    def _note_modelview(self, top_down: bool, bbox: bool):
+        """Remember the model-view the frame being drawn leaves behind (what the next reset()'s glLightfv is transformed by): the composite
+        Rx(cam_angle) T(0, 0, forward) LookAt as this backend's camera -- eye C, yaw (sa, ca), pitch (sth, cth)."""
+        st = self._sim.init_states[0]
+        pos = np.asarray(self.cur_pos, dtype=np.float64)
+        if self.domain_rand and not top_down:
+            pos = pos + np.asarray(list(st.camera_noise), dtype=np.float64)          # simulator.py:1768-1769
+        vp, va, vh, vdeg = viewer_camera(top_down, bbox, pos, float(self.cur_angle), self.grid_width, self.grid_height, self.road_tile_size, st.cam_fov_y_deg)
+        h = st.cam_height if vh is None else vh
+        deg = st.cam_angle_deg if vdeg is None else vdeg
+        y0 = 0.0 if (top_down or bbox) else float(pos[1])
+        sa, ca = math.sin(va), math.cos(va)
+        self._gl_modelview = dict(C=np.array([vp[0] + CAMERA_FORWARD_DIST * ca, y0 + h, vp[2] - CAMERA_FORWARD_DIST * sa]), sa=sa, ca=ca,
+                                  sth=math.sin(math.radians(deg)), cth=math.cos(math.radians(deg)))
 
     # ------------------------------------------------------------------ viewer --
     def _viewer(self, distortion: bool, size=None):
@@ -638,6 +665,17 @@ class Simulator(_EnvBase):
 
 
 # ---- module-level helpers of the reference (simulator.py:2056-2116) ------------------
+def gl_light_to_eye(mv: dict, light_pos) -> list:
+    """A GL_POSITION 4-vector through the model-view `mv` (eye C, yaw sa / ca, pitch sth / cth; the composite of _render_img's
+    Rx(cam_angle) T(0, 0, forward) LookAt): a position (w != 0) is taken relative to the eye and rotated, a direction (w = 0) only rotated."""
+    L = [float(v) for v in light_pos] + [0.0] * (4 - len(light_pos))
+    w = L[3]
+    rx, ry, rz = (L[0] / w - mv["C"][0], L[1] / w - mv["C"][1], L[2] / w - mv["C"][2]) if w != 0.0 else (L[0], L[1], L[2])
+    xla = rx * mv["sa"] + rz * mv["ca"]
+    zla = -(rx * mv["ca"] - rz * mv["sa"])
+    return [xla, ry * mv["cth"] - zla * mv["sth"], ry * mv["sth"] + zla * mv["cth"], 1.0 if w != 0.0 else 0.0]
+
+
 def viewer_camera(top_down: bool, bbox: bool, pos, ang: float, grid_width: int, grid_height: int, tile_size: float, fov_y_deg: float):
     """The window / debugging views of _render_img as parameters of THIS backend's camera model -- eye = pos + CAMERA_FORWARD_DIST * dir +
     (0, cam_height, 0), dir = (cos, 0, -sin), pitched down by cam_angle_deg -- returned as (pos, angle, cam_height or None, cam_angle_deg):

@@ -152,7 +152,7 @@ def test_render_modes_window_views_match_oracle():
     st = env._sim.init_states[0]
     states = [dict(pos=o.pos, y_rot=o.y_rot, visible=True) for o in om.objects]
     cam = raster.Camera(env.cur_pos, env.cur_angle, width=WW, height=WH, horizon_color=list(st.horizon_color),
-                        ground_color=list(st.ground_color))
+                        ground_color=list(st.ground_color), light_pos=list(st.light_pos))
     ref = raster.render_obs(cam, scene, "pixel", None, obj_states=states)
     d = np.abs(free.astype(int) - ref.astype(int)).max(-1)
     assert (d > 1).mean() <= 2e-3 and np.abs(free.astype(int) - ref.astype(int)).mean() <= 0.03, ((d > 1).mean(),)
@@ -161,7 +161,7 @@ def test_render_modes_window_views_match_oracle():
     a, b = env.grid_width * env.road_tile_size / 2, env.grid_height * env.road_tile_size / 2
     Hf = (max(a, b) + 0.1) / math.tan(math.radians(75.0) / 2)
     tcam = raster.Camera([a, 0.0, b + 0.066], math.pi / 2, cam_height=Hf, cam_angle_deg=math.degrees(math.atan2(Hf, 0.01)),
-                         width=WW, height=WH, horizon_color=list(st.horizon_color), ground_color=list(st.ground_color))
+                         width=WW, height=WH, horizon_color=list(st.horizon_color), ground_color=list(st.ground_color), light_pos=list(st.light_pos))
     assert np.allclose(tcam.C, [a, Hf, b], atol=1e-12)
     fwd = np.array([0.0, -Hf, -0.01]) / math.hypot(Hf, 0.01)                   # gluLookAt forward
     assert np.allclose(tcam.to_eye(tcam.C + fwd), [0, 0, -1], atol=1e-9)       # eye space looks down -z
@@ -314,7 +314,7 @@ def test_undistort_property_skips_the_fisheye_like_the_reference():
     w = UndistortWrapper(env)
     assert env.undistort is True
     folded = BatchedSimulator(kw["map_name"], 1, domain_rand=False, seed=5, camera_width=160, camera_height=120,
-                              distortion=True, undistort=True)
+                              distortion=True, undistort=True, per_env_camera=True)   # (the render path the facade uses: its light is per env)
     folded.render()
     assert np.array_equal(w.observation(env.render_obs()), folded.frames_host()[0])
     env.close(); plain.close()
@@ -557,3 +557,40 @@ def test_two_ranks_on_one_gpu_exchange_the_real_batches(tmp_path):
             assert np.array_equal(got[f"{what}_{t}"], want), (what, t)
         assert np.array_equal(got[f"{what}_all"], ref.frames_host()), what
     ref.close()
+
+
+def test_reset_captures_the_light_through_the_last_frame_s_model_view():
+    """GL transforms GL_POSITION by the model-view current at the glLightfv call; reset() (simulator.py:565-584) issues it with what the last
+    _render_img left: the identity at the first reset (inside __init__), the last frame's camera of the previous episode afterwards.  The facade
+    hands the device the eye-space light accordingly; frames of the second episode against the oracle lit the same way.  Domain randomisation:
+    the drawn DIRECTION is rotated only.  gl_light_capture=False keeps the light as given."""
+    from gym_duckietown.simulator import Simulator
+    from oracle import raster
+    from test_gpu_render import _camera, _scene, _stats
+    W, H = 320, 240
+    scene = _scene("small_loop")
+    for dr in (False, True):
+        env = Simulator(map_name="small_loop", domain_rand=dr, camera_width=W, camera_height=H, seed=6, distortion=False)
+        first = [float(v) for v in env._sim.init_states[0].light_pos]
+        if not dr:
+            assert first == [0.0, 3.0, 0.0, 1.0]                               # nothing drawn before the first reset: the identity
+        for _ in range(7):
+            env.step(np.array([0.6, 0.3]))
+        cam_prev = _camera(env._sim, 0, W, H, dr)                              # the camera of the last frame of episode 1
+        obs = env.reset()
+        st = env._sim.init_states[0]
+        got = [float(v) for v in st.light_pos]
+        raw = [0.0, 3.0, 0.0, 1.0] if not dr else [float(v) for v in env.randomization_settings["light_pos"]] + [0.0]
+        want = cam_prev.to_eye(np.asarray(raw[:3])) if raw[3] else cam_prev.normal_to_eye(np.asarray(raw[:3]))
+        assert got[3] == raw[3] and np.allclose(got[:3], want, rtol=0, atol=1e-9), (got, want)
+        assert not np.allclose(got[:3], raw[:3], atol=1e-3)                    # it did move
+        col = env._sim.read(_ffi.FIELD_COLORS)[0]
+        assert np.allclose(col[12:16], got, rtol=1e-6, atol=1e-6)
+        ref = raster.render_obs(_camera(env._sim, 0, W, H, dr), scene, "pixel", None)   # (reads the init state's light)
+        s = _stats(obs, ref)
+        assert s["mean"] <= 0.05 and s["frac_gt2"] <= 1e-3, (dr, s)
+        env.close()
+    env = Simulator(map_name="small_loop", domain_rand=False, camera_width=W, camera_height=H, seed=6, distortion=False, gl_light_capture=False)
+    env.step(np.array([0.6, 0.3])); env.reset()
+    assert [float(v) for v in env._sim.init_states[0].light_pos] == [0.0, 3.0, 0.0, 1.0]
+    env.close()

@@ -36,7 +36,7 @@ def _camera(sim, e, W, H, dr):
     ang = sim.read(_ffi.FIELD_ANGLE)[e]
     if not dr:
         return raster.Camera(pos, ang, width=W, height=H, horizon_color=list(st.horizon_color),
-                             ground_color=list(st.ground_color))
+                             ground_color=list(st.ground_color), light_pos=list(st.light_pos))   # ((0, 3, 0, 1) unless the facade captured it through a model-view)
     return raster.Camera(pos, ang, cam_height=st.cam_height, cam_angle_deg=st.cam_angle_deg,
                          cam_fov_y_deg=st.cam_fov_y_deg, camera_noise=list(st.camera_noise), domain_rand=True,
                          horizon_color=list(st.horizon_color), ground_color=list(st.ground_color),
