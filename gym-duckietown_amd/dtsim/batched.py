@@ -467,6 +467,37 @@ class BatchedSimulator:
             ip = ei.ctypes.data_as(C.POINTER(C.c_int32))
         _ffi.check(self._lib, self._lib.dtsim_draw_lines(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), ip, int(n)))
 
+    _LED_POS = ((0.1, 0.05, -0.05), (0.1, 0.05, 0.05), (0.1, 0.05, 0.0), (-0.1, 0.05, -0.05), (-0.1, 0.05, 0.05))   # glTranslatef(px, pz, py): front_left,
+    # front_right, center, back_left, back_right in the dict's order (objects.py:74-80, 96)
+    _LED_FOLLOWER = ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), (0.0, 0.0, 0.2), (0.5, 0.0, 0.0), (0.5, 0.0, 0.0))           # DuckiebotObj.leds_color (objects.py:218-224)
+    _LED_STATIC = ((0.0, 0.0, 1.0),) * 5                                                                             # a static duckiebot-kind WorldObj (objects.py:86-92)
+
+    def led_spheres(self, envs=None):
+        """The spheres WorldObj.render_mesh draws with enable_leds (objects.py:68-121) for the given envs (default: all), from the current object
+        states: per visible object of kind "duckiebot" and LED, the 1 cm sphere at alpha 1 and the halo of radius mean(colour) x 4 cm at alpha 0.2,
+        inside the object's translate / scale / rotate, in draw order.  Returns (spheres [n, 8] float32, env_idx [n] int32) for draw_leds()."""
+        envs = range(self.num_envs) if envs is None else [int(e) for e in envs]
+        vis_all, cen_all = self.read(_ffi.FIELD_OBJ_VISIBLE), self.read(_ffi.FIELD_OBJ_CENTER)
+        yrot_all, cy_all = self.read(_ffi.FIELD_OBJ_YROT), self.read(_ffi.FIELD_OBJ_Y)
+        out, idx = [], []
+        for e in envs:
+            for k, o in enumerate(self.maps[int(self.env_map[e])].objects):
+                if o.kind != "duckiebot" or not vis_all[e][k]:
+                    continue
+                if o.dyn_slot >= 0:
+                    pos = np.array([cen_all[e][o.dyn_slot, 0], cy_all[e][o.dyn_slot], cen_all[e][o.dyn_slot, 1]], dtype=np.float64)
+                    th = math.radians(float(yrot_all[e][o.dyn_slot]))
+                else:
+                    pos, th = np.asarray(o.pos, dtype=np.float64), float(o.angle)
+                c, s_ = math.cos(th), math.sin(th)
+                for (lx, ly, lz), col in zip(self._LED_POS, self._LED_STATIC if o.static else self._LED_FOLLOWER):
+                    col = np.clip(np.asarray(col, dtype=np.float64), 0.0, 1.0)
+                    x, y, z = lx * o.scale, ly * o.scale, lz * o.scale
+                    cw = np.array([x * c + z * s_, y, -x * s_ + z * c]) + pos         # glRotatef(y_rot, 0, 1, 0) (objects.py:140-146)
+                    out.append([*cw, 0.01 * o.scale, *col, 1.0]); idx.append(e)
+                    out.append([*cw, float(np.mean(col)) * 0.04 * o.scale, *col, 0.2]); idx.append(e)
+        return np.asarray(out, dtype=np.float32).reshape(-1, 8), np.asarray(idx, dtype=np.int32)
+
     def draw_leds(self, spheres, env_idx=None):
         """The LED spheres of the reference's enable_leds (objects.py:68-121) as a post-pass on the frames of the last render(): spheres [n, 8] =
         world-space centre (x, y, z), radius, colour (r, g, b in 0..1), alpha, in draw order; env_idx [n] (non-decreasing) or None = env 0.

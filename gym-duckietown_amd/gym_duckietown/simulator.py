@@ -384,33 +384,10 @@ class Simulator(_EnvBase):
         return self._sim.frames_host()[0]
 
     # ---------------------------------------------------------------- LEDs --
-    _LED_POS = ((0.1, 0.05, -0.05), (0.1, 0.05, 0.05), (0.1, 0.05, 0.0), (-0.1, 0.05, -0.05), (-0.1, 0.05, 0.05))   # glTranslatef(px, pz, py): front_left,
-    # front_right, center, back_left, back_right in the dict's order (objects.py:74-80, 96)
-    _LED_FOLLOWER = ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5), (0.0, 0.0, 0.2), (0.5, 0.0, 0.0), (0.5, 0.0, 0.0))           # DuckiebotObj.leds_color (objects.py:218-224)
-    _LED_STATIC = ((0.0, 0.0, 1.0),) * 5                                                                             # a static duckiebot-kind WorldObj (objects.py:86-92)
-
     def _led_spheres(self) -> np.ndarray:
-        """World-space spheres [n, 8] = centre, radius, glColor, alpha of WorldObj.render_mesh's LEDs (objects.py:68-121), in draw order: for every
-        visible object of kind "duckiebot", per LED the 1 cm sphere at alpha 1 and the halo of radius mean(colour) x 4 cm at alpha 0.2, inside
-        the object's translate / scale / rotate.  dtsim_draw_leds blends them into the rendered frame."""
-        vis = self._sim.read(_ffi.FIELD_OBJ_VISIBLE)[0]
-        cen, yrot, cy = self._sim.read(_ffi.FIELD_OBJ_CENTER)[0], self._sim.read(_ffi.FIELD_OBJ_YROT)[0], self._sim.read(_ffi.FIELD_OBJ_Y)[0]
-        out = []
-        for k, o in enumerate(self.objects):
-            if o.kind != "duckiebot" or not vis[k]:
-                continue
-            if o.dyn_slot >= 0:
-                pos, th = np.array([cen[o.dyn_slot, 0], cy[o.dyn_slot], cen[o.dyn_slot, 1]]), math.radians(float(yrot[o.dyn_slot]))
-            else:
-                pos, th = np.asarray(o.pos, dtype=np.float64), math.radians(float(np.rad2deg(o.angle)))
-            c, s_ = math.cos(th), math.sin(th)
-            for (lx, ly, lz), col in zip(self._LED_POS, self._LED_STATIC if o.static else self._LED_FOLLOWER):
-                col = np.clip(np.asarray(col, dtype=np.float64), 0.0, 1.0)
-                x, y, z = lx * o.scale, ly * o.scale, lz * o.scale
-                cw = np.array([x * c + z * s_, y, -x * s_ + z * c]) + pos         # glRotatef(y_rot, 0, 1, 0) (objects.py:140-146)
-                out.append([*cw, 0.01 * o.scale, *col, 1.0])
-                out.append([*cw, float(np.mean(col)) * 0.04 * o.scale, *col, 0.2])
-        return np.asarray(out, dtype=np.float32).reshape(-1, 8)
+        """World-space spheres [n, 8] = centre, radius, glColor, alpha of WorldObj.render_mesh's LEDs (objects.py:68-121), in draw order
+        (BatchedSimulator.led_spheres); dtsim_draw_leds blends them into the rendered frame."""
+        return self._sim.led_spheres([0])[0]
 
     # ---------------------------------------------------------------- GL_LINE overlays --
     def _overlay_lines(self) -> np.ndarray:

@@ -139,3 +139,29 @@ def test_simulator_enable_leds():
     env.close()
     with pytest.raises(NotImplementedError):
         Simulator(map_name="small_loop", camera_rand=True)
+
+
+def test_batched_led_spheres_for_every_env_and_map():
+    """BatchedSimulator.led_spheres(): the vector API's statement of the spheres -- per env, from ITS map's objects and their current poses --
+    against the oracle's list per env; drawn for all envs in one dtsim_draw_leds call."""
+    N, W, H = 4, 160, 120
+    names = ["loop_dyn_duckiebots", "loop_only_duckies"]
+    sim = BatchedSimulator(names, N, camera_width=W, camera_height=H, distortion=False, domain_rand=False, seed=12, map_cycle=True)
+    sim.reset(mask=(np.arange(N) % 2 == 0))
+    sim.step(np.random.default_rng(9).uniform(0.2, 0.6, (20, N, 2)).astype(np.float32), n_steps=20)
+    sp, idx = sim.led_spheres()
+    scenes = [_scene(n) for n in names]
+    mid = sim.read(_ffi.FIELD_MAP_ID)
+    assert set(np.unique(mid)) == {0, 1}
+    for e in range(N):
+        sc = scenes[int(mid[e])]
+        want = raster.led_spheres(sc, _obj_states(sim, e, sc))
+        got = sp[idx == e]
+        assert got.shape == want.shape and (want.shape[0] > 0) == (int(mid[e]) == 0)       # only the duckiebot map has LEDs
+        assert np.allclose(got, want, atol=1e-5)
+    assert np.all(np.diff(idx) >= 0)
+    sim.render()
+    sim.draw_leds(sp, idx)                               # (the fixture's unit meshes put these LEDs inside the bodies: the call itself is what is exercised)
+    sub, _ = sim.led_spheres([1])
+    assert sub.shape[0] == int((idx == 1).sum())
+    sim.close()
