@@ -194,6 +194,24 @@ def trafficlight(d):
         Image.fromarray(img).save(os.path.join(d, f"trafficlight_card{k}.jpg"), quality=95)
 
 
+def duckie(d):
+    """The procedural stand-in duckie (dtsim.assets.get_mesh) as OBJ / MTL, so that the reference's parser and the product's
+    see the same file (the recentring quirk of objmesh.py:214-226 then applies to both)."""
+    from dtsim import assets
+    m = assets.get_mesh("duckie")
+    o = Obj()
+    mats, cur = {}, None
+    for t in range(m.n_tris):
+        col = tuple(round(float(c), 4) for c in m.colors[t, 0])
+        name = mats.setdefault(col, f"duckie_mat{len(mats)}")
+        if name != cur:
+            o.usemtl(name)
+            cur = name
+        o.tri([tuple(m.verts[t, k]) for k in range(3)], [tuple(m.normals[t, k]) for k in range(3)])
+    o.write(os.path.join(d, "duckie.obj"), "duckie.mtl")
+    write_mtl(os.path.join(d, "duckie.mtl"), {name: {"Kd": col} for col, name in mats.items()})
+
+
 MAP = """# test map for real-asset ingestion (MapFormat1)
 tiles:
 - [grass, asphalt, floor, grass, grass]
@@ -216,7 +234,7 @@ def main():
     from dtsim import assets
     meshes = os.path.join(OUT, "meshes")
     os.makedirs(meshes, exist_ok=True)
-    cone(meshes); sign_generic(meshes); duckiebot(meshes); tree(meshes); trafficlight(meshes)
+    cone(meshes); sign_generic(meshes); duckiebot(meshes); tree(meshes); trafficlight(meshes); duckie(meshes)
     for kind in ("grass", "asphalt", "floor", "straight", "curve_left", "curve_right", "3way_left", "4way"):
         tex = assets.make_texture(kind, 128)[..., :3]
         save_png(os.path.join(OUT, "textures", "tiles-processed", "photos", kind, "texture.png"), tex)
