@@ -124,6 +124,12 @@ def _enums() -> dict:
     return out
 
 
+def _as_double(v):
+    """What ctypes' c_double does with an argument: float(v) -- which also takes the 1-element arrays the reference's
+    randomiser hands out (cam_fov_y, cam_height under domain randomisation)."""
+    return c_double(v).value
+
+
 class _Quadric:
     """GLUquadric defaults (quad.c gluNewQuadric): GLU_SMOOTH normals, GLU_OUTSIDE, GLU_FILL, no texture coordinates."""
 
@@ -147,7 +153,7 @@ def _make_gl(lib) -> types.ModuleType:
     # ---- GLU (libGLU is absent; SGI libutil restated) ----
     def gluPerspective(fovy, aspect, zNear, zFar):
         """project.c gluPerspective: double matrix through glMultMatrixd."""
-        fovy, aspect, zNear, zFar = float(fovy), float(aspect), float(zNear), float(zFar)
+        fovy, aspect, zNear, zFar = _as_double(fovy), _as_double(aspect), _as_double(zNear), _as_double(zFar)
         radians = fovy / 2 * math.pi / 180
         deltaZ = zFar - zNear
         sine = math.sin(radians)
@@ -167,6 +173,7 @@ def _make_gl(lib) -> types.ModuleType:
         """project.c gluLookAt: forward / side / up in FLOAT, glMultMatrixf, then glTranslated(-eye)."""
         import numpy as np
         f32 = np.float32
+        ex, ey, ez, cx, cy, cz, ux, uy, uz = (_as_double(v) for v in (ex, ey, ez, cx, cy, cz, ux, uy, uz))
         fwd = np.array([cx - ex, cy - ey, cz - ez], dtype=f32)     # (double differences stored into GLfloat)
         up = np.array([ux, uy, uz], dtype=f32)
 

@@ -32,7 +32,10 @@ import numpy as np
 NEAR, FAR = 0.04, 100.0
 GROUND_Y, GROUND_HALF = -0.008, 50.0
 CAMERA_FORWARD_DIST = 0.066
-SAMPLE_OFFSETS = [(-0.125, -0.375), (0.375, -0.125), (-0.375, 0.125), (0.125, 0.375)]  # (dx, dy) px, +y down
+# 4x MSAA sample positions, (dx, dy) in pixels from the pixel centre, +y DOWN the returned image.  GL_SAMPLE_POSITION on Mesa
+# llvmpipe: (0.375, 0.125) (0.875, 0.375) (0.125, 0.625) (0.625, 0.875) from the pixel's lower-left corner in window
+# coordinates (+y up; confirmed by rasterising 0.1-px squares, oracle/gl/measure_filter.py); _render_img flips the rows.
+SAMPLE_OFFSETS = [(-0.125, 0.375), (0.375, 0.125), (-0.375, -0.125), (0.125, -0.375)]
 
 
 class Camera:
@@ -111,18 +114,39 @@ def _tile_uv(angle, fx, fz):
     return u, v
 
 
+FILTER = "llvmpipe"      # "llvmpipe": Mesa's fixed-point GL_LINEAR (what the GL goldens were rendered with); "exact": float64 weights
+
+
 def _bilinear_repeat(tex, u, v):
-    """GL_LINEAR / GL_REPEAT fetch; tex [h,w,4] uint8 with row 0 = v=0."""
+    """GL_LINEAR / GL_REPEAT fetch; tex [h,w,4] uint8 with row 0 = v=0.
+
+    GL leaves the precision of the filter to the implementation.  FILTER = "llvmpipe" is the arithmetic of Mesa's llvmpipe for
+    8-bit unorm textures, MEASURED on Mesa 23.2.1 (oracle/gl/measure_filter.py: bit-identical on 786 432 random cases; it is
+    gallivm's AoS sampling path, lp_bld_sample_aos.c): the texel coordinate times 256, rounded, minus 128 (half a texel) --
+    the integer part addresses the texels, the low 8 bits are the weight; lerp(w, p, q) = p + ((w (q - p) + 128) >> 8),
+    first along s for both rows, THEN along t on the 8-bit results; the sampler hands an 8-bit colour to the (float)
+    texture environment.  FILTER = "exact": float64 bilinear (the oracle before the GL goldens existed)."""
     h, w = tex.shape[:2]
-    x, y = u * w - 0.5, v * h - 0.5
-    x0f, y0f = np.floor(x), np.floor(y)
-    ax, ay = (x - x0f)[..., None], (y - y0f)[..., None]
-    x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
+    if FILTER == "exact":
+        x, y = u * w - 0.5, v * h - 0.5
+        x0f, y0f = np.floor(x), np.floor(y)
+        ax, ay = (x - x0f)[..., None], (y - y0f)[..., None]
+        x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
+        x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+        t = tex[..., :3].astype(np.float64)
+        top = t[y0, x0] + ax * (t[y0, x1] - t[y0, x0])
+        bot = t[y1, x0] + ax * (t[y1, x1] - t[y1, x0])
+        return top + ay * (bot - top)
+    f32 = np.float32
+    xs = np.floor((np.asarray(u, dtype=f32) * f32(w)) * f32(256) + f32(0.5)).astype(np.int64) - 128
+    ys = np.floor((np.asarray(v, dtype=f32) * f32(h)) * f32(256) + f32(0.5)).astype(np.int64) - 128
+    ax, ay = (xs & 255)[..., None], (ys & 255)[..., None]
+    x0, y0 = (xs >> 8) % w, (ys >> 8) % h
     x1, y1 = (x0 + 1) % w, (y0 + 1) % h
-    t = tex[..., :3].astype(np.float64)
-    top = t[y0, x0] + ax * (t[y0, x1] - t[y0, x0])
-    bot = t[y1, x0] + ax * (t[y1, x1] - t[y1, x0])
-    return top + ay * (bot - top)
+    t = tex[..., :3].astype(np.int64)
+    top = t[y0, x0] + ((ax * (t[y0, x1] - t[y0, x0]) + 128) >> 8)
+    bot = t[y1, x0] + ((ax * (t[y1, x1] - t[y1, x0]) + 128) >> 8)
+    return (top + ((ay * (bot - top) + 128) >> 8)).astype(np.float64)
 
 
 class Scene:
@@ -184,7 +208,10 @@ def _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc):
         wz = np.where(centre_down, wz_c, wz_s)[g]
         corners = np.array([[-GROUND_HALF, GROUND_Y, -GROUND_HALF], [GROUND_HALF, GROUND_Y, -GROUND_HALF],
                             [-GROUND_HALF, GROUND_Y, GROUND_HALF], [GROUND_HALF, GROUND_Y, GROUND_HALF]])
-        nd = np.broadcast_to(cam.ndl(cam.to_eye(corners), np.array([0.0, cam.cth, cam.sth])), (4,))
+        # the ground vertex list carries no normals (simulator.py:526): GL lights it with the CURRENT normal -- (0, 0, 1), the
+        # initial value, nothing in the reference's default path calls glNormal -- through the inverse transpose of
+        # glScalef(50, 0.01, 50) (:1810), un-normalised: length 1/50, so the diffuse term all but vanishes.
+        nd = np.broadcast_to(cam.ndl(cam.to_eye(corners), cam.normal_to_eye(np.array([0.0, 0.0, 1.0 / GROUND_HALF]))), (4,))
         a = np.clip((wx + GROUND_HALF) / (2 * GROUND_HALF), 0, 1)
         b = np.clip((wz + GROUND_HALF) / (2 * GROUND_HALF), 0, 1)
         n0 = nd[0] + a * (nd[1] - nd[0])
@@ -235,7 +262,10 @@ def _object_instances(scene, obj_states):
         V = mesh.verts.astype(np.float64) * o.scale
         Vw = np.stack([V[..., 0] * c + V[..., 2] * s, V[..., 1], -V[..., 0] * s + V[..., 2] * c], axis=-1) + pos
         Nn = mesh.normals.astype(np.float64)
-        Nw = np.stack([Nn[..., 0] * c + Nn[..., 2] * s, Nn[..., 1], -Nn[..., 0] * s + Nn[..., 2] * c], axis=-1)
+        # GL transforms normals by the inverse transpose of the model-view and does NOT renormalise them (GL_NORMALIZE /
+        # GL_RESCALE_NORMAL are never enabled in the reference): glScalef(scale) divides them by `scale`, and whatever length
+        # the OBJ file gives them stays.  Measured against Mesa llvmpipe (tests/test_gl_golden.py).
+        Nw = np.stack([Nn[..., 0] * c + Nn[..., 2] * s, Nn[..., 1], -Nn[..., 0] * s + Nn[..., 2] * c], axis=-1) / o.scale
         T = Vw.shape[0]
         uvs = np.asarray(getattr(mesh, "uvs", np.zeros((T, 3, 2))), dtype=np.float64)
         texs = getattr(mesh, "textures", None) or []
@@ -266,7 +296,6 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None, return_d
     for Vw, Nw, Cc, UV, TI in _object_instances(scene, obj_states):
         Pe = cam.to_eye(Vw)
         Ne = cam.normal_to_eye(Nw)
-        Ne = Ne / np.linalg.norm(Ne, axis=-1, keepdims=True)
         lit = np.minimum(Cc * (cam.base + cam.dif * cam.ndl(Pe, Ne)[..., None]), 1.0) * 255.0
         w = -Pe[..., 2]
         ok = (w > NEAR).all(axis=1)
