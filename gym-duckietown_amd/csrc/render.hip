@@ -290,11 +290,15 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
     const float xla = rx * c.sa + rz * c.ca;          // . right = (sin a, 0, cos a)
     const float zla = -(rx * c.ca - rz * c.sa);       // -(. dir)
     const float ye = ry * c.cth - zla * c.sth, ze = ry * c.sth + zla * c.cth, xe = xla;
+    // The ground vertex list has no normals (simulator.py:526): GL lights it with the CURRENT normal -- (0, 0, 1), GL's initial value;
+    // nothing on the reference's default path calls glNormal -- taken through the inverse transpose of glScalef(50, 0.01, 50) (:1810)
+    // and the view rotation, NOT renormalised (GL_NORMALIZE is off): length 1/50.  Pinned on Mesa llvmpipe (tests/test_gpu_gl_golden.py).
+    const float gnx = c.ca * (1.f / GROUND_HALF), gny = -c.sa * c.sth * (1.f / GROUND_HALF), gnz = c.sa * c.cth * (1.f / GROUND_HALF);
     float ndl;
-    if (L[3] == 0.f) ndl = c.cth * L[1] + c.sth * L[2];
+    if (L[3] == 0.f) ndl = gnx * L[0] + gny * L[1] + gnz * L[2];
     else {
       const float lx = L[0] - xe, ly = L[1] - ye, lz = L[2] - ze;
-      ndl = (c.cth * ly + c.sth * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
+      ndl = (gnx * lx + gny * ly + gnz * lz) * rsqrtf(lx * lx + ly * ly + lz * lz);
     }
     c.gndl[k] = fmaxf(ndl, 0.f);
   }
@@ -431,7 +435,24 @@ __device__ inline float plane_ndl(const float L[4], float sth, float cth, const 
   return fmaxf(ndl, 0.f);
 }
 
-// bilinear GL_LINEAR/GL_REPEAT fetch from the padded texture, times the lit vertex colour I.
+// ---- GL_LINEAR as the reference's renderer computes it -------------------------------------------------------------------
+// GL leaves the filter's precision to the implementation.  The reference's CI renderer -- Mesa llvmpipe, the one the GL goldens
+// come from (tests/golden/ref_gl_*.npz) -- filters RGBA8 textures in integers (measured bit-exact, profiles/r06_gl_filter_precision.txt):
+// texel coordinate * 256, rounded, minus half a texel; the low 8 bits are the weight; lerp(w, p, q) = p + ((w (q - p) + 128) >> 8),
+// along s for both rows, then along t on the 8-bit results.  gl_fix: coordinate already shifted by the half texel -> fixed point.
+__device__ inline int gl_lerp8(int w, int p, int q) { return p + ((w * (q - p) + 128) >> 8); }
+__device__ inline int gl_fix(float x) { return (int)floorf(fmaf(x, 256.f, 0.5f)); }
+__device__ inline void gl_linear_rgb(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int wx, int wy, int out[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c00 = (int)((t00 >> (8 * k)) & 255u), c10 = (int)((t10 >> (8 * k)) & 255u);
+    const int c01 = (int)((t01 >> (8 * k)) & 255u), c11 = (int)((t11 >> (8 * k)) & 255u);
+    out[k] = gl_lerp8(wy, gl_lerp8(wx, c00, c10), gl_lerp8(wx, c01, c11));
+  }
+}
+
+// GL_LINEAR/GL_REPEAT fetch from the padded texture (the exact paths and the generic raster: llvmpipe's arithmetic), times the lit
+// vertex colour I.
 __device__ inline void tile_color(const RenderParams& R, const TileLds& tr, float fx, float fz, const float I[3],
                                   float out[3]) {
   if (!(tr.flags & 2u)) {  // untextured tile: white vertex colour
@@ -439,39 +460,29 @@ __device__ inline void tile_color(const RenderParams& R, const TileLds& tr, floa
     return;
   }
   const float x = fmaf(tr.mxz, fz, fmaf(tr.mxx, fx, tr.ox)), y = fmaf(tr.myz, fz, fmaf(tr.myx, fx, tr.oy));
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float ax = x - x0f, ay = y - y0f;
-  const int x0 = ((int)x0f) & (R.tex_w - 1), y0 = ((int)y0f) & (R.tex_h - 1);
+  const int xf = gl_fix(x), yf = gl_fix(y);
+  const int x0 = (xf >> 8) & (R.tex_w - 1), y0 = (yf >> 8) & (R.tex_h - 1);
   const uint32_t* pt = R.texels + tr.tex_off + y0 * (R.tex_w + 1) + x0;
   uint2 top2, bot2;               // two 8-byte loads: (x0,y0),(x0+1,y0) and the row above
   __builtin_memcpy(&top2, pt, 8);
   __builtin_memcpy(&bot2, pt + (R.tex_w + 1), 8);
+  int T[3];
+  gl_linear_rgb(top2.x, top2.y, bot2.x, bot2.y, xf & 255, yf & 255, T);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float c00 = (float)((top2.x >> (8 * k)) & 255u), c10 = (float)((top2.y >> (8 * k)) & 255u);
-    const float c01 = (float)((bot2.x >> (8 * k)) & 255u), c11 = (float)((bot2.y >> (8 * k)) & 255u);
-    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
-    out[k] = (top + ay * (bot - top)) * I[k];
-  }
+  for (int k = 0; k < 3; ++k) out[k] = (float)T[k] * I[k];
 }
 
-// GL_LINEAR / GL_REPEAT fetch of a mesh texture at (u, v) in texture coordinates; out in 0..1.
+// GL_LINEAR / GL_REPEAT fetch of a mesh texture at (u, v) in texture coordinates; out in 0..1 (the sampler's 8-bit result / 255).
 // Any power-of-two size; storage is the padded (h+1) x (w+1) layout of the texel pool.
 __device__ inline void mesh_texel(const RenderParams& R, int tex, float u, float v, float out[3]) {
   const TexDev td = R.tex[tex];
-  const float x = u * (float)td.w - 0.5f, y = v * (float)td.h - 0.5f;
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float ax = x - x0f, ay = y - y0f;
-  const int x0 = ((int)x0f) & (td.w - 1), y0 = ((int)y0f) & (td.h - 1);
+  const int xf = gl_fix(u * (float)td.w) - 128, yf = gl_fix(v * (float)td.h) - 128;
+  const int x0 = (xf >> 8) & (td.w - 1), y0 = (yf >> 8) & (td.h - 1);
   const uint32_t* pt = R.texels + td.off + y0 * (td.w + 1) + x0;
-  const uint32_t t00 = pt[0], t10 = pt[1], t01 = pt[td.w + 1], t11 = pt[td.w + 2];
+  int T[3];
+  gl_linear_rgb(pt[0], pt[1], pt[td.w + 1], pt[td.w + 2], xf & 255, yf & 255, T);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
-    const float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
-    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
-    out[k] = (top + ay * (bot - top)) * (1.f / 255.f);
-  }
+  for (int k = 0; k < 3; ++k) out[k] = (float)T[k] * (1.f / 255.f);
 }
 
 __device__ inline float ground_ndl(const EnvCam& c, float wx, float wz) {
@@ -579,11 +590,12 @@ __global__ __launch_bounds__(DT_OBJSETUP_T) void k_obj_setup(SimArrays A, Render
       const float xe = xla, ye = ry * c.cth - zla * c.sth, ze = ry * c.sth + zla * c.cth;
       w[v] = -ze;
       ok = ok && (w[v] > NEAR_Z);
-      // normal: Ry(y_rot) then view rotation, normalised
+      // normal: Ry(y_rot) then view rotation, through the inverse transpose of glScalef(scale) (objects.py:142) = divided by the scale, and NOT
+      // renormalised (GL_NORMALIZE / GL_RESCALE_NORMAL are never enabled): whatever length the OBJ file gives it stays.  Pinned on Mesa llvmpipe.
       const float nwx = td.n[v][0] * co + td.n[v][2] * so, nwy = td.n[v][1], nwz = -td.n[v][0] * so + td.n[v][2] * co;
       const float nxl = nwx * c.sa + nwz * c.ca, nzl = -(nwx * c.ca - nwz * c.sa);
       float nex = nxl, ney = nwy * c.cth - nzl * c.sth, nez = nwy * c.sth + nzl * c.cth;
-      const float ninv = rsqrtf(nex * nex + ney * ney + nez * nez);
+      const float ninv = 1.f / oi.scale;
       nex *= ninv; ney *= ninv; nez *= ninv;
       float ndl;
       if (c.L[3] == 0.f) ndl = nex * c.L[0] + ney * c.L[1] + nez * c.L[2];
@@ -750,7 +762,7 @@ __device__ inline void test_tri(const Tri& st, float pcx, float pcy, float wbest
 template <typename Tri>
 __device__ inline void test_tri_inside(const Tri& st, float pcx, float pcy, float wbest[4], int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
   // b0(q) = ((x1-qx)(y2-qy) - (x2-qx)(y1-qy)) / area: d/dqx = (y1-y2)/area, d/dqy = (x2-x1)/area; b1 likewise;
   // w(q) = iw2 + b0 (iw0 - iw2) + b1 (iw1 - iw2)
   const float ia = st.inv_area;
@@ -856,7 +868,7 @@ __device__ inline void zbuffer_chunk(const TriCov* w_tris, uint32_t* w_scr, int 
         if (act) {
           const TriCov& st = w_tris[pr >> 6];
           const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-          const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+          const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
           const float ia = st.inv_area;
           const float e0x = st.sx[0] - qx, e0y = st.sy[0] - qy, e1x = st.sx[1] - qx, e1y = st.sy[1] - qy, e2x = st.sx[2] - qx, e2y = st.sy[2] - qy;
           const float b0c = (e1x * e2y - e2x * e1y) * ia, b1c = (e2x * e0y - e0x * e2y) * ia;
@@ -921,7 +933,7 @@ __device__ inline uint32_t shade_msaa(const EnvCam& c, const MapU& m, const Rend
                                       const TileLds* tiles, float nx, float ny, const ScreenTri* tris,
                                       const float zbest[4], const int tbest[4]) {
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   const Ray rc = make_ray(nx, ny, c.tx, c.ty, c.sth, c.cth);
   // 1. coverage: which primitive owns each sample.  key: 0 sky, 1 ground, 2|tj<<2|ti<<14 tile,
@@ -1331,15 +1343,16 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
         for (int k = 0; k < PPT; ++k) px[k] = (pv[k].flags & PF_VALID) ? hor_rgb : 0u;
       } else {
       uint2 top2[PPT], bot2[PPT];
-      float ax[PPT], ay[PPT];
+      int wxi[PPT], wyi[PPT];                        // 8-bit filter weights (gl_fix)
       const uint8_t* tex_bytes = reinterpret_cast<const uint8_t*>(texels);
       const uint32_t row_bytes = (uint32_t)tw1 * 4u;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const float x = fmaf(tr[k].mxz, fz[k], fmaf(tr[k].mxx, fx[k], tr[k].ox));
         const float y = fmaf(tr[k].myz, fz[k], fmaf(tr[k].myx, fx[k], tr[k].oy));
-        ax[k] = __builtin_amdgcn_fractf(x); ay[k] = __builtin_amdgcn_fractf(y);
-        const uint32_t x0 = (uint32_t)(flr_i32(x) & xmask), y0 = (uint32_t)(flr_i32(y) & ymask);
+        const int xf = gl_fix(x), yf = gl_fix(y);
+        wxi[k] = xf & 255; wyi[k] = yf & 255;
+        const uint32_t x0 = (uint32_t)((xf >> 8) & xmask), y0 = (uint32_t)((yf >> 8) & ymask);
         // 32-bit byte offset from the (uniform) pool base -> saddr-form loads; always in bounds
         const uint32_t off = (__umul24(y0, (uint32_t)tw1) + x0 + tr[k].tex_off) << 2;
         __builtin_memcpy(&top2[k], tex_bytes + off, 8);
@@ -1348,19 +1361,16 @@ __global__ __launch_bounds__(RB) void k_raster(RenderParams R, const EnvCam* __r
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const PixInv& p = pv[k];
-        // bilinear as 4 weights.  Shared camera: pv.ndl holds the lit factor min(base + dif*ndl, 1)
-        // (all channels equal) and is folded into the weights: w00 + w10 + w01 + w11 = I.
-        const float wy1 = DR ? ay[k] : ay[k] * p.ndl, wy0 = (DR ? 1.f : p.ndl) - wy1;
-        const float w10_ = ax[k] * wy0, w11_ = ax[k] * wy1;
-        const float w00_ = wy0 - w10_, w01_ = wy1 - w11_;
-        float v0 = fmaf(ubyte0(bot2[k].y), w11_, fmaf(ubyte0(bot2[k].x), w01_, fmaf(ubyte0(top2[k].y), w10_, ubyte0(top2[k].x) * w00_)));
-        float v1 = fmaf(ubyte1(bot2[k].y), w11_, fmaf(ubyte1(bot2[k].x), w01_, fmaf(ubyte1(top2[k].y), w10_, ubyte1(top2[k].x) * w00_)));
-        float v2 = fmaf(ubyte2(bot2[k].y), w11_, fmaf(ubyte2(bot2[k].x), w01_, fmaf(ubyte2(top2[k].y), w10_, ubyte2(top2[k].x) * w00_)));
+        // llvmpipe's integer GL_LINEAR (gl_linear_rgb), then the lit factor: pv.ndl holds min(base + dif*ndl, 1) for the shared
+        // camera (all channels equal), max(0, N.L) under domain randomisation (per-channel base / dif)
+        int T[3];
+        gl_linear_rgb(top2[k].x, top2[k].y, bot2[k].x, bot2[k].y, wxi[k], wyi[k], T);
+        float v0 = (float)T[0], v1 = (float)T[1], v2 = (float)T[2];
         if (DR) {
           v0 *= fminf(fmaf(dif0, p.ndl, base0), 1.f);
           v1 *= fminf(fmaf(dif1, p.ndl, base1), 1.f);
           v2 *= fminf(fmaf(dif2, p.ndl, base2), 1.f);
-        }
+        } else { v0 *= p.ndl; v1 *= p.ndl; v2 *= p.ndl; }
         uint32_t rgb = 0;
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0, rgb);
         rgb = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, rgb);
@@ -1513,7 +1523,7 @@ __global__ void k_pix_setup(RenderParams R, const float4* __restrict__ lut, PixT
   pixtab[pix] = t;
   SampTab sp;
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   sp.flags = 0u;
   float dlr[4], dlf[4];
@@ -1554,35 +1564,34 @@ __device__ inline float med3f(float x, float lo, float hi) { return __builtin_am
 //      +-50 m; else the clear colour), shading once per distinct primitive at the pixel centre (GL semantics:
 //      simulator.py:1932-1934, graphics.py:172-251): a tile is shaded with ITS texture at the centre hit -- outside the
 //      tile the coordinate wraps (GL_REPEAT), which the quad records encode -- times the centre's lit factor.
-__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I, uint32_t bias) {
-  const float axI = ax * I, azI = az * I;
-  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
-  uint32_t WA, WB;
-  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-  // three 24-bit sums  sum(tap * w16)  packed as bytes 2 of (vr, vg, vb) when bias = 32768; callers that need the
-  // unrounded value pass bias = 0 and use quad_filter3
-  const uint32_t vr = (__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, bias, false);
-  const uint32_t vg = (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, bias, false);
-  const uint32_t vb = (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, bias, false);
-  const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
-  return __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
+// ---- the quad-record filter ("dtsim8") -------------------------------------------------------------------
+// GL's own filter (llvmpipe: gl_linear_rgb above) works with 8-bit weights and 8-bit intermediates, so nothing is gained by filtering
+// finer than that; the quad pipeline filters in ONE v_dot4_u32_u8 per channel: the four bilinear weights, times the lit factor
+// where it is the same for the three channels (shared camera), times 256, rounded to bytes (v_cvt_pk_u8_f32); colour =
+// (sum(texel * weight) + 128) >> 8.  Measured against the GL goldens it differs from llvmpipe by +-1/255 on about a quarter of the
+// textured pixels -- what the 16-bit filter it replaces did too (tests/test_gl_golden.py::test_quad_filter_distance_to_gl).
+// I256 = 256 * lit (256 for an unlit filter).  Byte order = the record's texel order: (x0,z0) (x1,z0) (x0,z1) (x1,z1).
+__device__ inline uint32_t quad_weights8(float ax, float az, float I256) {
+  const float u = ax * I256, v = I256 - u;
+  const float w11 = u * az, w01 = v * az, w10 = u - w11, w00 = v - w01;
+  uint32_t W = __builtin_amdgcn_cvt_pk_u8_f32(w00, 0, 0u);
+  W = __builtin_amdgcn_cvt_pk_u8_f32(w10, 1, W);
+  W = __builtin_amdgcn_cvt_pk_u8_f32(w01, 2, W);
+  return __builtin_amdgcn_cvt_pk_u8_f32(w11, 3, W);
 }
-__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats
-  const float axI = ax * I, azI = az * I;
-  const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (I - axI) - w01;
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
-  uint32_t WA, WB;
-  __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-  const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-  const uint32_t v[3] = {(__builtin_amdgcn_udot4(q.x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.x, wl, 0u, false),
-                         (__builtin_amdgcn_udot4(q.y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.y, wl, 0u, false),
-                         (__builtin_amdgcn_udot4(q.z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q.z, wl, 0u, false)};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) out[k] = (float)v[k] * (1.f / 65535.f);
+// one-ray colour 0x00BBGGRR of a record (I = lit factor, 0..1)
+__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I) {
+  const uint32_t W = quad_weights8(ax, az, I * 256.f);
+  const uint32_t vr = __builtin_amdgcn_udot4(q.x, W, 128u, false), vg = __builtin_amdgcn_udot4(q.y, W, 128u, false),
+                 vb = __builtin_amdgcn_udot4(q.z, W, 128u, false);                 // the channel is byte 1 of each sum
+  const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0501u);
+  return __builtin_amdgcn_perm(vb, rg, 0x0c050100u);
+}
+__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats, unrounded
+  const uint32_t W = quad_weights8(ax, az, I * 256.f);
+  out[0] = (float)__builtin_amdgcn_udot4(q.x, W, 0u, false) * (1.f / 256.f);
+  out[1] = (float)__builtin_amdgcn_udot4(q.y, W, 0u, false) * (1.f / 256.f);
+  out[2] = (float)__builtin_amdgcn_udot4(q.z, W, 0u, false) * (1.f / 256.f);
 }
 
 #define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
@@ -1727,7 +1736,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!skip[u]) {                                // wave-uniform
-          const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit, 32768u);
+          const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit);
           if (interior[u]) store_rgb(env[u], pix[u], rgb);
         }
         const bool msaa = have[u] && !interior[u];
@@ -1789,17 +1798,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const uint32_t xic = (uint32_t)flr_i32(Xu), zic = (uint32_t)flr_i32(Zu);
         const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
         const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
-        uint32_t wl, wh;
-        {
-          const float axI = ax * lit, azI = az * lit;
-          const float w11 = axI * az, w10 = axI - w11, w01 = azI - w11, w00 = (lit - axI) - w01;
-          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-          const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(w00, w10), wb = __builtin_amdgcn_cvt_pknorm_u16(w01, w11);
-          uint32_t WA, WB;
-          __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-          wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u); wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-        }
-        uint32_t aH[3] = {0u, 0u, 0u}, aL[3] = {0u, 0u, 0u};
+        const uint32_t W8 = quad_weights8(ax, az, lit * 256.f);
+        uint32_t aS[3] = {0u, 0u, 0u};                 // sum over the samples of the byte-weight filter of each sample's record
         int n_sky = 0, n_gnd = 0;
         float gX = 0.f, gZ = 0.f;                      // ground hit (quad coordinates) of the lowest-index ground sample
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
@@ -1829,16 +1829,16 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
           const uint32_t raddr = is_tile ? tb + (cell << 4) : 0u;
           if (s == 3 || raddr != raddr_prev) rec = *reinterpret_cast<const uint4*>(qtex + raddr);
           raddr_prev = raddr;
-          aH[0] = __builtin_amdgcn_udot4(rec.x, wh, aH[0], false); aL[0] = __builtin_amdgcn_udot4(rec.x, wl, aL[0], false);
-          aH[1] = __builtin_amdgcn_udot4(rec.y, wh, aH[1], false); aL[1] = __builtin_amdgcn_udot4(rec.y, wl, aL[1], false);
-          aH[2] = __builtin_amdgcn_udot4(rec.z, wh, aH[2], false); aL[2] = __builtin_amdgcn_udot4(rec.z, wl, aL[2], false);
+          aS[0] = __builtin_amdgcn_udot4(rec.x, W8, aS[0], false);
+          aS[1] = __builtin_amdgcn_udot4(rec.y, W8, aS[1], false);
+          aS[2] = __builtin_amdgcn_udot4(rec.z, W8, aS[2], false);
         }
         float acc[3];
         float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (__ballot(n_sky > 0)) hc = c4[2];           // wave-uniform: the horizon colour only where some sample sees the sky
-        acc[0] = fmaf((float)n_sky, hc.y, (float)((aH[0] << 8) + aL[0]) * (1.f / 65535.f));
-        acc[1] = fmaf((float)n_sky, hc.z, (float)((aH[1] << 8) + aL[1]) * (1.f / 65535.f));
-        acc[2] = fmaf((float)n_sky, hc.w, (float)((aH[2] << 8) + aL[2]) * (1.f / 65535.f));
+        acc[0] = fmaf((float)n_sky, hc.y, (float)aS[0] * (1.f / 256.f));
+        acc[1] = fmaf((float)n_sky, hc.z, (float)aS[1] * (1.f / 256.f));
+        acc[2] = fmaf((float)n_sky, hc.w, (float)aS[2] * (1.f / 256.f));
         if (__ballot(n_gnd > 0)) {                     // wave-uniform: shade the ground quad (lit at its corners, bilinear)
           if (pt.lit > 0.f && (pt.lr != 0.f || pt.lf != 0.f)) { gX = fmaf(kg, Xu - Cx, Cx); gZ = fmaf(kg, Zu - Cz, Cz); }   // the centre ray hits the planes
           const float hs = 0.5f / ghalf;
@@ -1935,9 +1935,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 //     (texture, angle), as S x S "quad" records of 16 B -- the four GL_LINEAR taps around one cell, channel-planar,
 //     plus a meta dword -- and the hit goes from the yaw-local frame straight to padded quad coordinates (EnvQ);
 //     the only table read is the block offset of the cell's tile (LDS, 4 B per tile incl. an off-grid ring);
-//   * the bilinear filter is integer: weights -> u16 (v_cvt_pknorm_u16_f32, light folded in), split into hi / lo
-//     byte planes (v_perm_b32), 2 x v_dot4_u32_u8 per channel against the planar taps, (H << 8) + L, bits 16..23
-//     are the output byte.  Against the float filter the result differs by < 0.01 LSB before rounding;
+//   * the bilinear filter is integer, at the precision GL's own filter has (round 6: the byte-weight filter of quad_weights8 /
+//     quad_filter -- one v_dot4_u32_u8 per channel against the planar taps, light folded into the weights);
 //   * interior / edge classification is one compare: meta.lo = cells to the nearest tile boundary (0 for anything
 //     that is not a textured tile) against the pixel's MSAA reach in cells, computed once per pixel (Mi).  Cell 0 of
 //     each axis straddles the seam (half of it belongs to the neighbour tile) and is always an edge;
@@ -2213,12 +2212,11 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
       if (j) __builtin_amdgcn_sched_barrier(0);      // one pixel pair at a time: fewer live temporaries
-      // bilinear weights with the lit factor folded in, two pixels per packed op
-      const f2 I2 = lit2[j];
-      const f2 axI = ax2[j] * I2, azI = az2[j] * I2;
-      const f2 w11 = axI * az2[j];
-      const f2 w10 = axI - w11, w01 = azI - w11;
-      const f2 w00 = (I2 - axI) - w01;
+      // bilinear weights with the lit factor folded in (x 256: the byte weights of quad_weights8), two pixels per packed op
+      const f2 I2 = lit2[j] * 256.f;
+      const f2 u = ax2[j] * I2, v = I2 - u;
+      const f2 w11 = u * az2[j], w01 = v * az2[j];
+      const f2 w10 = u - w11, w00 = v - w01;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 2 * j + h;
@@ -2226,17 +2224,14 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         fastm[k] = fm;
         slow |= candm[k] & ~fm;
         edge[k] = false;
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const us2 wa = __builtin_amdgcn_cvt_pknorm_u16(h ? w00.y : w00.x, h ? w10.y : w10.x);
-        const us2 wb = __builtin_amdgcn_cvt_pknorm_u16(h ? w01.y : w01.x, h ? w11.y : w11.x);
-        uint32_t WA, WB;
-        __builtin_memcpy(&WA, &wa, 4); __builtin_memcpy(&WB, &wb, 4);
-        const uint32_t wl = __builtin_amdgcn_perm(WB, WA, 0x06040200u), wh = __builtin_amdgcn_perm(WB, WA, 0x07050301u);
-        const uint32_t vr = (__builtin_amdgcn_udot4(q[k].x, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].x, wl, 32768u, false);
-        const uint32_t vg = (__builtin_amdgcn_udot4(q[k].y, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].y, wl, 32768u, false);
-        const uint32_t vb = (__builtin_amdgcn_udot4(q[k].z, wh, 0u, false) << 8) + __builtin_amdgcn_udot4(q[k].z, wl, 32768u, false);
-        const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0602u);
-        const uint32_t rgb = __builtin_amdgcn_perm(vb, rg, 0x0c060100u);
+        uint32_t W = __builtin_amdgcn_cvt_pk_u8_f32(h ? w00.y : w00.x, 0, 0u);
+        W = __builtin_amdgcn_cvt_pk_u8_f32(h ? w10.y : w10.x, 1, W);
+        W = __builtin_amdgcn_cvt_pk_u8_f32(h ? w01.y : w01.x, 2, W);
+        W = __builtin_amdgcn_cvt_pk_u8_f32(h ? w11.y : w11.x, 3, W);
+        const uint32_t vr = __builtin_amdgcn_udot4(q[k].x, W, 128u, false), vg = __builtin_amdgcn_udot4(q[k].y, W, 128u, false),
+                       vb = __builtin_amdgcn_udot4(q[k].z, W, 128u, false);          // the channel is byte 1 of each sum (quad_filter)
+        const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0501u);
+        const uint32_t rgb = __builtin_amdgcn_perm(vb, rg, 0x0c050100u);
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(px[k]) : "v"(hor_v), "v"(rgb), "s"(fm));   // not a one-ray tile pixel: clear colour
       }
     }
@@ -2715,7 +2710,7 @@ __global__ __launch_bounds__(256) void k_overlay_lines(RenderParams R, const Env
     sxp = (l.x + 1.f) * 0.5f * (float)R.W; syp = (1.f - l.y) * 0.5f * (float)R.H;       // centre of the source pixel
   }
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
   float acc[3] = {0.f, 0.f, 0.f};
   uint32_t covered = 0u;
   for (int base = 0; base < count; base += 256) {
@@ -2820,7 +2815,7 @@ __global__ __launch_bounds__(256) void k_overlay_leds(RenderParams R, const EnvC
     sxp = (l.x + 1.f) * 0.5f * (float)R.W; syp = (1.f - l.y) * 0.5f * (float)R.H;       // centre of the source pixel
   }
   const float ox[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
-  const float oy[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+  const float oy[4] = {0.375f, 0.125f, -0.125f, -0.375f};   // GL_SAMPLE_POSITION of Mesa llvmpipe, rows flipped (+y down the image)
   const float sxn = 2.f / (float)R.W, syn = 2.f / (float)R.H;
   float add[3] = {0.f, 0.f, 0.f};
   float depth[4] = {0.f, 0.f, 0.f, 0.f};

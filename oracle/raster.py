@@ -114,29 +114,17 @@ def _tile_uv(angle, fx, fz):
     return u, v
 
 
-FILTER = "llvmpipe"      # "llvmpipe": Mesa's fixed-point GL_LINEAR (what the GL goldens were rendered with); "exact": float64 weights
+def _gl_linear(tex, u, v):
+    """GL_LINEAR / GL_REPEAT fetch as the reference's renderer computes it; tex [h,w,4] uint8 with row 0 = v=0; returns the
+    sampler's 8-bit result as float [...,3].
 
-
-def _bilinear_repeat(tex, u, v):
-    """GL_LINEAR / GL_REPEAT fetch; tex [h,w,4] uint8 with row 0 = v=0.
-
-    GL leaves the precision of the filter to the implementation.  FILTER = "llvmpipe" is the arithmetic of Mesa's llvmpipe for
-    8-bit unorm textures, MEASURED on Mesa 23.2.1 (oracle/gl/measure_filter.py: bit-identical on 786 432 random cases; it is
-    gallivm's AoS sampling path, lp_bld_sample_aos.c): the texel coordinate times 256, rounded, minus 128 (half a texel) --
-    the integer part addresses the texels, the low 8 bits are the weight; lerp(w, p, q) = p + ((w (q - p) + 128) >> 8),
-    first along s for both rows, THEN along t on the 8-bit results; the sampler hands an 8-bit colour to the (float)
-    texture environment.  FILTER = "exact": float64 bilinear (the oracle before the GL goldens existed)."""
+    GL leaves the precision of the filter to the implementation.  This is the arithmetic of Mesa's llvmpipe for 8-bit unorm
+    textures, MEASURED on Mesa 23.2.1 (oracle/gl/measure_filter.py -> profiles/r06_gl_filter_precision.txt: bit-identical on
+    786 432 random cases; it is gallivm's AoS sampling path, lp_bld_sample_aos.c): the texel coordinate times 256, rounded,
+    minus 128 (half a texel) -- the integer part addresses the texels, the low 8 bits are the weight;
+    lerp(w, p, q) = p + ((w (q - p) + 128) >> 8), first along s for both rows, THEN along t on the 8-bit results; the sampler
+    hands an 8-bit colour to the (float) texture environment."""
     h, w = tex.shape[:2]
-    if FILTER == "exact":
-        x, y = u * w - 0.5, v * h - 0.5
-        x0f, y0f = np.floor(x), np.floor(y)
-        ax, ay = (x - x0f)[..., None], (y - y0f)[..., None]
-        x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
-        x1, y1 = (x0 + 1) % w, (y0 + 1) % h
-        t = tex[..., :3].astype(np.float64)
-        top = t[y0, x0] + ax * (t[y0, x1] - t[y0, x0])
-        bot = t[y1, x0] + ax * (t[y1, x1] - t[y1, x0])
-        return top + ay * (bot - top)
     f32 = np.float32
     xs = np.floor((np.asarray(u, dtype=f32) * f32(w)) * f32(256) + f32(0.5)).astype(np.int64) - 128
     ys = np.floor((np.asarray(v, dtype=f32) * f32(h)) * f32(256) + f32(0.5)).astype(np.int64) - 128
@@ -147,6 +135,65 @@ def _bilinear_repeat(tex, u, v):
     top = t[y0, x0] + ((ax * (t[y0, x1] - t[y0, x0]) + 128) >> 8)
     bot = t[y1, x0] + ((ax * (t[y1, x1] - t[y1, x0]) + 128) >> 8)
     return (top + ((ay * (bot - top) + 128) >> 8)).astype(np.float64)
+
+
+def _exact_linear(tex, u, v):
+    """Float64 bilinear (no implementation's filter: the oracle before the GL goldens existed)."""
+    h, w = tex.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    x0f, y0f = np.floor(x), np.floor(y)
+    ax, ay = (x - x0f)[..., None], (y - y0f)[..., None]
+    x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
+    x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+    t = tex[..., :3].astype(np.float64)
+    top = t[y0, x0] + ax * (t[y0, x1] - t[y0, x0])
+    bot = t[y1, x0] + ax * (t[y1, x1] - t[y1, x0])
+    return top + ay * (bot - top)
+
+
+def _dtsim8_shade(tex, u, v, I, folded):
+    """Tile colour (0..255 float, unrounded) of the product's quad-record pipeline (csrc/render.hip quad_weights8 / quad_filter,
+    DESIGN.md section 5): ONE multiply-accumulate per texel and channel at the precision GL's own filter has -- the four
+    bilinear weights, times 256, rounded to bytes (float32 arithmetic, round-to-nearest-even as v_cvt_pk_u8_f32 does);
+    sum(texel * weight) / 256.  `folded` (shared camera, k_raster_v3 / k_raster_q: the lit factor I [...,3] is the same for the
+    three channels): it is folded into the weights; otherwise (k_raster_v3dr: per-env, per-channel light) the weights are unlit
+    and the sum is multiplied by I.
+    Not llvmpipe's arithmetic (which rounds to 8 bits between its two lerps): it differs from _gl_linear(...) * I by +-1/255 on
+    about a quarter of the textured pixels, never systematically (tests/test_gl_golden.py measures it on the GL frames)."""
+    h, w = tex.shape[:2]
+    f32 = np.float32
+    x = np.asarray(u, dtype=np.float64) * w - 0.5
+    y = np.asarray(v, dtype=np.float64) * h - 0.5
+    x0f, y0f = np.floor(x), np.floor(y)
+    ax, az = (x - x0f).astype(f32), (y - y0f).astype(f32)
+    x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
+    x1, y1 = (x0 + 1) % w, (y0 + 1) % h
+    I = np.asarray(I, dtype=np.float64)
+    I256 = (I[..., 0].astype(f32) * f32(256)) if folded else np.full(ax.shape, 256, f32)
+    uu = ax * I256
+    vv = I256 - uu
+    w11, w01 = uu * az, vv * az
+    w10, w00 = uu - w11, vv - w01
+    W = [np.clip(np.rint(wgt), 0, 255).astype(np.int64)[..., None] for wgt in (w00, w10, w01, w11)]
+    t = tex[..., :3].astype(np.int64)
+    S = t[y0, x0] * W[0] + t[y0, x1] * W[1] + t[y1, x0] * W[2] + t[y1, x1] * W[3]
+    out = S.astype(np.float64) / 256.0
+    return out if folded else out * I
+
+
+def _tile_shade(tex, u, v, I, tile_filter):
+    if tile_filter in ("dtsim8", "dtsim8-dr"):
+        return _dtsim8_shade(tex, u, v, I, tile_filter == "dtsim8" and bool(np.all(I[..., 0] == I[..., 1]) and np.all(I[..., 0] == I[..., 2])))
+    return (_gl_linear(tex, u, v) if tile_filter == "llvmpipe" else _exact_linear(tex, u, v)) * I
+
+
+# `lighting` argument of render_obs / render_rectilinear -> (where the tile light is evaluated, the tile texture filter)
+#   "gouraud"   GL itself: the light at the tile's 8 x 8 vertices, llvmpipe's filter -- what the GL goldens pin
+#   "pixel"     the product's quad-record pipeline: per-fragment light, the byte-weight filter -- lit factor folded into the weights when it
+#               is one number for the three channels (k_raster_v3 / k_raster_q), applied per channel otherwise (k_raster_v3dr)
+#   "pixel-dr"  the same with the per-channel form forced (k_raster_v3dr through per_env_camera, whatever the light's colour)
+#   "pixel-gl"  the product's generic raster and exact paths (k_raster / k_resolve): per-fragment light, llvmpipe's filter
+MODES = {"gouraud": ("gouraud", "llvmpipe"), "pixel": ("pixel", "dtsim8"), "pixel-dr": ("pixel", "dtsim8-dr"), "pixel-gl": ("pixel", "llvmpipe"), "pixel-exact": ("pixel", "exact")}
 
 
 class Scene:
@@ -226,18 +273,18 @@ def _shade_planes(cam, scene, lighting, cls, ti, tj, t_s, wx_s, wz_s, rc):
         wz = np.where(centre_down, wz_c, wz_s)[tl]
         i, j = ti[tl], tj[tl]
         ts = scene.m.tile_size
-        I = _tile_light(cam, scene, lighting, i, j, t, xe_c[tl], ye_c[tl], wx, wz)
+        light_mode, tile_filter = MODES[lighting]
+        I = np.broadcast_to(_tile_light(cam, scene, light_mode, i, j, t, xe_c[tl], ye_c[tl], wx, wz), (i.size, 3))
         fx, fz = wx / ts - i, wz / ts - j
         u, v = _tile_uv(scene.angle[j, i], fx, fz)
-        col = np.empty((i.size, 3))
-        col[:] = 255.0
+        col = 255.0 * I
         flat_kind = np.array([hash(scene.kinds[jj][ii]) for ii, jj in zip(i.tolist(), j.tolist())]) if i.size else np.zeros(0)
         for kind in {scene.kinds[jj][ii] for ii, jj in zip(i.tolist(), j.tolist())}:
             sel = flat_kind == hash(kind)
             tex = scene.textures.get(kind)
             if tex is not None:
-                col[sel] = _bilinear_repeat(tex, u[sel], v[sel])
-        out[tl] = col * I
+                col[sel] = _tile_shade(tex, u[sel], v[sel], I[sel], tile_filter)
+        out[tl] = col
     return out
 
 
@@ -372,7 +419,7 @@ def render_rectilinear(cam, scene, lighting="gouraud", obj_states=None, return_d
                     vc = (c0 * uv[0, 1] / w[0] + c1 * uv[1, 1] / w[1] + c2 * uv[2, 1] / w[2]) / iwc
                 uc, vc = np.nan_to_num(uc, nan=0.0, posinf=0.0, neginf=0.0), np.nan_to_num(vc, nan=0.0, posinf=0.0, neginf=0.0)
                 uc, vc = np.where(win, uc, 0.0), np.where(win, vc, 0.0)
-                colc = colc * (_bilinear_repeat(timg, uc, vc) / 255.0)
+                colc = colc * (_gl_linear(timg, uc, vc) / 255.0)
             sub[win] = d[win]
             csub = col[y0:y1 + 1, x0:x1 + 1]
             csub[win] = colc[win]

