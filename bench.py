@@ -64,27 +64,112 @@ def _oracle_env_steps(job):
     return time.perf_counter() - t0
 
 
+def _glport_env_steps(job):
+    """n env-steps of one env through the reference's CPU path as it can travel: oracle/sim.py physics (restated reference step) + the
+    reference's OpenGL call stream on Mesa llvmpipe (oracle/gl/glport.py, byte-identical to the reference's frames on the GL goldens) +
+    the fisheye remap.  One core: LP_NUM_THREADS=1.  Returns the seconds the stepping took."""
+    n_steps, seed, fisheye = job
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "LP_NUM_THREADS"):
+        os.environ.setdefault(var, "1")
+    from dtsim import assets
+    from dtsim import distortion as pdist
+    from oracle import raster, sim as osim
+    from oracle.gl import glport
+    ext = assets.mesh_extents(("duckie",))
+    o = osim.OracleSim(assets.get_map("small_loop"), ext, domain_rand=False, seed=seed)
+    kinds = {t["kind"] for t in o.map.grid if t is not None}
+    scene = raster.Scene(o.map, {k: assets.get_texture(k) for k in kinds}, {"duckie": assets.get_mesh("duckie"), "*": assets.get_mesh("*")})
+    r = glport.GLRenderer(scene, W, H)
+    r.set_light(list(o.light_pos) + [0.0] * (4 - len(o.light_pos)), o.light_ambient, o.light_diffuse)
+    take = None
+    if fisheye:                                                          # cv2.remap(INTER_NEAREST, BORDER_CONSTANT 0) as one gather (raster.distort, indices precomputed)
+        rmap = pdist.distortion_maps(W, H)
+        sx, sy = np.rint(rmap[0].astype(np.float64)).astype(np.int64), np.rint(rmap[1].astype(np.float64)).astype(np.int64)
+        ok = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+        take = np.where(ok, sy * W + sx, W * H).reshape(-1)              # index W * H = one black pixel appended to the frame
+    rng = np.random.default_rng(1234 + seed)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        _, done, _ = o.step_vel_steer(rng.uniform(-1, 1, 2))
+        img = r.render(o.cur_pos, o.cur_angle, horizon=o.horizon_color, ground=o.ground_color)
+        if take is not None:
+            img = np.concatenate([img.reshape(-1, 3), np.zeros((1, 3), np.uint8)])[take].reshape(H, W, 3)
+        if done:
+            o.reset()
+            r.set_light(list(o.light_pos) + [0.0] * (4 - len(o.light_pos)), o.light_ambient, o.light_diffuse)
+    return time.perf_counter() - t0
+
+
+def _pool_rate(fn, jobs, steps_each):
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:                # spawn: the parent holds a HIP context
+        spent = pool.map(fn, jobs)
+    return len(jobs) * steps_each / max(spent), time.perf_counter() - t0
+
+
 def cpu_baseline(n_steps: int, all_cores_steps: int = 8):
-    """The oracle (kind "port") on the host: ONE core for `n_steps` env-steps (the headline `value`), and --
-    SURVEY 8(d) -- on all cores, one env per process, the only scaling the reference supports
-    (`all_cores`).  Same map / resolution / action distribution as the GPU workload, bounded samples."""
-    dt = _oracle_env_steps((n_steps, 1000))
-    out = {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{n_steps} env-steps of small_loop 640x480 + fisheye on the numpy oracle (oracle/sim.py + oracle/raster.py); "
-                     "the reference's Pyglet/OpenGL path is not runnable on this host (no pyglet/duckietown_world/GL)"}
+    """The reference's CPU path on the bench box's host cores, kind "port" (the reference itself -- Python under /root/reference -- does not
+    exist here): the reference's OpenGL call stream on Mesa llvmpipe, the reference CI's renderer (oracle/gl/glport.py; pinned
+    byte-identical to the reference's own frames by tests/test_gl_golden.py), with oracle/sim.py's physics -- ONE core (`value`) and, SURVEY
+    8(d), all cores with one env per process, the only scaling the reference supports (`all_cores`).  `numpy_port`: the software-rasteriser
+    oracle of the earlier rounds (oracle/raster.py), for continuity.  `reference_recorded`: the unmodified reference's own step loop, timed
+    in the build container (profiles/reference_render_timings.json).  Same map / resolution / action distribution as the GPU workload."""
+    out = {}
     procs = min(os.cpu_count() or 1, 64)
-    if all_cores_steps > 0 and procs > 1:
+    gl_reason = None
+    try:
+        from oracle.gl import glport, glshim
+        if not glport.available():
+            gl_reason = "Mesa's swrast_dri.so / GL headers are not on this host"
+    except Exception as ex:                                              # pragma: no cover
+        gl_reason = repr(ex)[:200]
+    if gl_reason is None:
         try:
-            import multiprocessing as mp
-            t0 = time.perf_counter()
-            with mp.get_context("spawn").Pool(procs) as pool:           # spawn: the parent holds a HIP context
-                spent = pool.map(_oracle_env_steps, [(all_cores_steps, 2000 + i) for i in range(procs)])
-            wall = time.perf_counter() - t0
-            out["all_cores"] = {"value": procs * all_cores_steps / max(spent), "unit": "env-steps/s", "cores": procs,
-                                "sample": f"{procs} processes x {all_cores_steps} env-steps, one env per process; "
-                                          f"stepping time of the slowest process (pool start-up excluded; wall {wall:.1f} s)"}
+            import subprocess
+            # the single-core sample in a child process: llvmpipe's context must not live in the process that holds the HIP context
+            n_gl = max(60, 12 * n_steps)
+            code = ("import sys, json; sys.path[:0] = [%r, %r]; import bench; from oracle.gl import glshim; "
+                    "dt = bench._glport_env_steps((%d, 1000, True)); print(json.dumps({'dt': dt, 'renderer': glshim.renderer()}))" % (ROOT, os.path.join(ROOT, "gym-duckietown_amd"), n_gl))
+            res = subprocess.run([sys.executable, "-W", "ignore", "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, LP_NUM_THREADS="1"))
+            rec = json.loads(res.stdout.strip().splitlines()[-1])
+            out = {"value": n_gl / rec["dt"], "unit": "env-steps/s", "cores": 1, "kind": "port", "renderer": rec["renderer"],
+                   "sample": f"{n_gl} env-steps of small_loop 640x480 + fisheye: oracle/sim.py physics + the reference's OpenGL call stream "
+                             "(simulator.py:1707-1951 restated in oracle/gl/glport.py, byte-identical to the reference's frames on the GL goldens) on Mesa "
+                             "llvmpipe with LP_NUM_THREADS=1 + a numpy remap; /root/reference itself (Python) does not exist on this host"}
+            if all_cores_steps > 0 and procs > 1:
+                per = max(40, 5 * all_cores_steps)
+                rate, wall = _pool_rate(_glport_env_steps, [(per, 2000 + i, True) for i in range(procs)], per)
+                out["all_cores"] = {"value": rate, "unit": "env-steps/s", "cores": procs,
+                                    "sample": f"{procs} processes x {per} env-steps, one env and one llvmpipe context per process (LP_NUM_THREADS=1); "
+                                              f"stepping time of the slowest process (pool start-up excluded; wall {wall:.1f} s)"}
         except Exception as ex:
-            out["all_cores"] = {"error": repr(ex)[:200]}
+            gl_reason = "the GL port failed here: " + repr(ex)[:200]
+            out = {}
+    dt = _oracle_env_steps((n_steps, 1000))
+    numpy_port = {"value": n_steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                  "sample": f"{n_steps} env-steps of small_loop 640x480 + fisheye on the numpy oracle (oracle/sim.py + the software rasteriser oracle/raster.py)"}
+    if not out:
+        out = dict(numpy_port)
+        out["renderer"] = None
+        out["gl_port_skipped"] = gl_reason
+        if all_cores_steps > 0 and procs > 1:
+            try:
+                rate, wall = _pool_rate(_oracle_env_steps, [(all_cores_steps, 2000 + i) for i in range(procs)], all_cores_steps)
+                out["all_cores"] = {"value": rate, "unit": "env-steps/s", "cores": procs,
+                                    "sample": f"{procs} processes x {all_cores_steps} env-steps, one env per process; stepping time of the slowest process (wall {wall:.1f} s)"}
+            except Exception as ex:
+                out["all_cores"] = {"error": repr(ex)[:200]}
+    else:
+        out["numpy_port"] = numpy_port
+    try:
+        with open(os.path.join(ROOT, "profiles", "reference_render_timings.json")) as f:
+            rr = json.load(f)
+        out["reference_recorded"] = {"status": "recorded in the build container, not measured in this run", "what": rr["what"], "where": rr["where"],
+                                     "renderer": rr["renderer"], "env_steps_per_s": {k: v["env_steps_per_s"] for k, v in rr["cases"].items()},
+                                     "glport_same_host": rr.get("glport_same_host"), "recipe": "oracle/time_reference_render.py"}
+    except Exception:
+        pass
     return out
 
 

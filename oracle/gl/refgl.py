@@ -127,6 +127,10 @@ def load(transform_uses_width: bool = False):
     class _Env:
         metadata = {}
 
+        @property
+        def unwrapped(self):
+            return self
+
         def close(self):
             pass
 
