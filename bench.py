@@ -588,7 +588,7 @@ def main():
                 sync_all()
                 tg = time.perf_counter()
                 for t in range(kp):
-                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True)
+                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True, what="frames")
                 ss.flush_gather(dst=0)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg

@@ -763,6 +763,7 @@ int dtsim_reset_done(dtsim_t* h) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
   if (!h->have_reset) return fail(DTSIM_E_STATE, "dtsim_reset_done before the first dtsim_reset");
   if (!h->d_sampler) return fail(DTSIM_E_STATE, "dtsim_reset_done needs dtsim_set_reset_sampler");
+  h->rendered = false;
   HIPCHK(hipSetDevice(h->cfg.device));
   {
     ProfScope ps(h, DTSIM_KERNEL_RESET);
@@ -775,6 +776,7 @@ int dtsim_reset_done(dtsim_t* h) {
 int dtsim_reset(dtsim_t* h, const uint8_t* mask, const dtsim_init_state* states) {
   if (!h) return fail(DTSIM_E_INVALID, "null argument");
   if (!h->have_maps) return fail(DTSIM_E_STATE, "dtsim_reset before dtsim_set_maps");
+  h->rendered = false;                               // the state moves on: the post-passes (dtsim_draw_lines / dtsim_draw_leds) need a new dtsim_render
   if (!states) {                                     // device-side sampling
     if (!h->d_sampler) return fail(DTSIM_E_STATE, "dtsim_reset(states = NULL) needs dtsim_set_reset_sampler");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -827,6 +829,7 @@ int dtsim_step_ex(dtsim_t* h, const void* actions, int n_steps, int actions_on_d
   if (!h || !actions || n_steps <= 0) return fail(DTSIM_E_INVALID, "bad argument");
   if (flags & ~(uint32_t)(DTSIM_STEP_ONE_UPDATE | DTSIM_STEP_POSE_ONLY)) return fail(DTSIM_E_INVALID, "unknown step flags 0x%x", flags);
   if (!h->have_maps || !h->have_reset) return fail(DTSIM_E_STATE, "dtsim_step before dtsim_set_maps/dtsim_reset");
+  h->rendered = false;                               // the cameras / projected triangles of the last render pass describe the state before this step
   HIPCHK(hipSetDevice(h->cfg.device));
   const size_t esz = (h->cfg.flags & DTSIM_F_ACTIONS_F64) ? 8 : 4;
   const size_t bytes = (size_t)n_steps * h->N * 2 * esz;
@@ -1431,6 +1434,7 @@ int dtsim_read_agent(dtsim_t* h, int env, dtsim_agent_info* out) {
 
 int dtsim_read(dtsim_t* h, int field, void* dst, size_t bytes) { return field_xfer(h, field, dst, bytes, true); }
 int dtsim_write(dtsim_t* h, int field, const void* src, size_t bytes) {
+  if (h) h->rendered = false;                        // (any field may move the scene: the post-passes wait for the next dtsim_render)
   return field_xfer(h, field, const_cast<void*>(src), bytes, false);
 }
 

@@ -80,6 +80,11 @@ class BatchedSimulator:
         # per_env_camera: render through the per-env camera / light path (the device flag of domain randomisation) while the reset draws stay
         # those of domain_rand=False -- for callers that write a per-env light or camera themselves (the gym facade's GL light capture)
         self.per_env_camera = bool(per_env_camera)
+        if self.per_env_camera and not domain_rand and (device_reset or auto_reset):
+            # the device sampler (physics.hip sample_init) always draws a camera_noise, and the per-env render path applies it: with
+            # domain_rand off the frames after a device-side reset would be jittered while the reference's are not
+            raise ValueError("per_env_camera with domain_rand=False needs host-side resets (device_reset / auto_reset draw a camera noise "
+                             "that this render path would apply)")
         flags |= _ffi.F_DOMAIN_RAND if (domain_rand or per_env_camera) else 0
         flags |= _ffi.F_AUTO_RESET if auto_reset else 0
         flags |= _ffi.F_ACTIONS_F64 if actions_f64 else 0

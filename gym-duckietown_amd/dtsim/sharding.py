@@ -198,7 +198,19 @@ class ShardedSimulator:
     # Round 5: THREE slots rotate (a batch handed out survives the next call: a learner may keep obs_t next to obs_t+1), and
     # the ordering between the simulator's stream and the exchange is by EVENTS, not host waits: the simulator can run ahead of
     # the host while a transfer is in flight.  On gloo (no device transport) the payload is staged through pinned host memory.
-    N_SLOTS = 3
+    N_SLOTS = 3                                          # default number of rotating slots (step_render_gather(slots=2) for two)
+    ROOT_MEMORY_FRACTION = 0.8                           # of the root device's FREE memory the receive tensors of all slots may take
+    DEFAULT_OBS = (120, 160)                             # what = "observe" without obs=: the 160 x 120 observation of the reference's wrappers
+
+    @staticmethod
+    def exchange_root_bytes(slots: int, world: int, shape, itemsize: int) -> int:
+        """Bytes of receive tensors the ROOT of the overlapped exchange allocates: slots x world x this rank's payload.  At the north
+        star's size (8 ranks x 4096 envs x 640 x 480 x 3 B) that is 30.2 GB per slot -- 90.6 GB for three slots of what="frames";
+        what="observe" at 160 x 120 is 16 x smaller."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return int(slots) * int(world) * n * int(itemsize)
 
     def _produce(self, slot, what: str, obs):
         """This rank's payload of the current step into the slot's send buffer.  Device path: enqueued on the simulator's stream;
@@ -238,13 +250,17 @@ class ShardedSimulator:
         shape = (n, 3, obs[0], obs[1]) if kw.get("chw") else (n, obs[0], obs[1], 3)
         return shape, (torch.float32 if kw.get("normalize") else torch.uint8), dev
 
-    def _exchange_state(self, what: str, obs, dst: int, group):
-        """Buffers of the overlapped exchange, made once per (payload, root, group).  `dst` is a GLOBAL rank (as in
-        torch.distributed.gather); slices of the root's tensor are in GROUP-rank order."""
+    def _exchange_state(self, what: str, obs, dst: int, group, n_slots: int = None):
+        """Buffers of the overlapped exchange, made once per (payload, root, group, slots).  `dst` is a GLOBAL rank (as in
+        torch.distributed.gather); slices of the root's tensor are in GROUP-rank order.  The root's memory need is checked BEFORE
+        anything is allocated (exchange_root_bytes against ROOT_MEMORY_FRACTION of the device's free memory): MemoryError with the numbers."""
         import torch
         import torch.distributed as dist
+        n_slots = self.N_SLOTS if n_slots is None else int(n_slots)
+        if n_slots not in (2, 3):
+            raise ValueError("slots = 2 (a handed-out batch is valid until the next call) or 3 (through the next call)")
         okw = tuple(sorted((obs[2] if obs and len(obs) > 2 else {}).items()))
-        key = (what, tuple(obs[:2]) if obs else None, okw, dst, group)
+        key = (what, tuple(obs[:2]) if obs else None, okw, dst, group, n_slots)
         gx = getattr(self, "_gx", None)
         if gx is not None and gx["key"] == key:
             return gx
@@ -259,8 +275,15 @@ class ShardedSimulator:
         staged = bool(multi and dev.type == "cuda" and dist.get_backend(group) == "gloo")
         xdev = torch.device("cpu") if staged else dev
         n = shape[0]
+        if is_root and xdev.type == "cuda":
+            need = self.exchange_root_bytes(n_slots, self.world, shape, torch.empty((), dtype=dtype).element_size())
+            free, _total = torch.cuda.mem_get_info(xdev)
+            if need > self.ROOT_MEMORY_FRACTION * free:
+                raise MemoryError(f"the overlapped gather of what={what!r} needs {need / 2**30:.1f} GiB of receive tensors on the root ({n_slots} slots x "
+                                  f"{self.world} ranks x {need / n_slots / self.world / 2**20:.0f} MiB) but the device has {free / 2**30:.1f} GiB free: use "
+                                  "slots=2, what='observe', or fewer envs per rank")
         slots = []
-        for _ in range(self.N_SLOTS):
+        for _ in range(n_slots):
             if is_root:
                 recv = torch.empty((self.world * n,) + tuple(shape[1:]), dtype=dtype, device=xdev, pin_memory=staged)
                 send = recv[grank * n:(grank + 1) * n]     # the root produces in place
@@ -304,29 +327,34 @@ class ShardedSimulator:
             slot["works"] = None                         # only now: nothing reads or writes the slot's buffers any more
 
     def step_render_gather(self, global_actions, n_steps: int = 1, *, overlap: bool = True, dst: int = 0, group=None,
-                           local_actions: bool = False, what: str = "frames", obs=None, copy: bool = False):
+                           local_actions: bool = False, what: str = "observe", obs=None, copy: bool = False, slots: int = None):
         """One learner iteration: step this rank's envs, render them, and gather the batch to (global) rank `dst`.
 
-        what="frames": the [n, H, W, 3] uint8 frame batch (3.77 GB per rank at the BASELINE size: xGMI-link bound, DESIGN.md 6);
-        what="observe", obs=(h, w[, observe() keywords]): the dtsim_observe output of the step instead (57.6 KB per env at
-        160 x 120: the exchange the north star's learner can actually keep up with).
+        what="observe" (the default), obs=(h, w[, observe() keywords]) (default DEFAULT_OBS = 120 x 160): the dtsim_observe output of the step --
+        57.6 KB per env at 160 x 120: the exchange a learner can keep up with over xGMI;
+        what="frames": the full [n, H, W, 3] uint8 frame batch (3.77 GB per rank at the BASELINE size: xGMI-link bound; and
+        slots x world x 3.77 GB of receive tensors on the root -- checked against the free device memory before allocating).
+        slots=2 | 3 (default N_SLOTS = 3): rotating receive buffers on the root, see "Lifetime" below.
         overlap=False: blocking; returns (t, batch) -- batch = [world*n, ...] of THIS step on `dst`, None elsewhere.
         overlap=True: the gather of step t runs while step t+1 is simulated and rendered; the call returns the batch
         of step t-1 (the learner runs one step behind the simulator; `flush_gather()` hands out the last one), or (None, None) on
         the first call.
-        Lifetime of the returned tensor: it is one of THREE rotating slots' preallocated receive tensor itself (no copy).  It stays
-        valid through the NEXT call and is overwritten by the one after: a learner can hold obs_t while it receives obs_t+1, no
-        longer -- pass copy=True (or clone it) for a replay buffer.  A slot is produced into again only after the simulator's stream
+        Lifetime of the returned tensor: it is one of the rotating slots' preallocated receive tensor itself (no copy).  With three slots it
+        stays valid through the NEXT call and is overwritten by the one after: a learner can hold obs_t while it receives obs_t+1, no
+        longer; with slots=2 (a third less memory on the root) it is valid only until the next call -- pass copy=True (or clone it) for a
+        replay buffer.  A slot is produced into again only after the simulator's stream
         has been ordered behind the end of the transfer that read it; consumers must run on torch's current stream (or synchronise
         with it) -- the ordering of a handed-out batch is stream-level, not host-level."""
-        if what not in ("frames", "observe") or (what == "observe" and not obs):
-            raise ValueError("what = 'frames' or 'observe' (with obs=(height, width[, keywords]))")
+        if what not in ("frames", "observe"):
+            raise ValueError("what = 'observe' (with obs=(height, width[, keywords]); default 120 x 160) or 'frames'")
+        if what == "observe" and not obs:
+            obs = self.DEFAULT_OBS
         if local_actions:                                # already this rank's slice (e.g. a device tensor)
             self.sim.step(global_actions, n_steps)
         else:
             self.step(global_actions, n_steps)
-        gx = self._exchange_state(what, obs, dst, group)
-        S = self.N_SLOTS
+        gx = self._exchange_state(what, obs, dst, group, slots)
+        S = len(gx["slots"])
         t = gx["t"]
         slot = gx["slots"][t % S]
         self._wait(slot, reuse=True)                     # the transfer of step t-3 read / wrote this slot
@@ -350,7 +378,7 @@ class ShardedSimulator:
         if gx is None or gx["t"] == 0:
             return None, None
         t = gx["t"] - 1
-        last = gx["slots"][t % self.N_SLOTS]
+        last = gx["slots"][t % len(gx["slots"])]
         self._wait(last, reuse=False)
         for sl in gx["slots"]:
             self._wait(sl, reuse=True)

@@ -110,6 +110,8 @@ class Simulator(_EnvBase):
             raise NotImplementedError("camera_rand (carnivalmirror calibration sampling) is outside the path this backend implements")
         self.enable_leds = bool(enable_leds)
         self.gl_light_capture = bool(env_kwargs.pop("gl_light_capture", True))   # reset()'s light through the last frame's model-view, as GL does (False: as given)
+        if not domain_rand and (env_kwargs.get("device_reset") or env_kwargs.get("auto_reset")):
+            self.gl_light_capture = False                # device-side resets do not come back through reset(): nothing to capture (and the per-env path would apply the sampler's camera noise)
         self._gl_modelview = None        # what the last frame left (None: the identity -- nothing drawn yet)
         self.seed_value = seed
         self.num_tris_distractors = num_tris_distractors
@@ -443,6 +445,10 @@ class Simulator(_EnvBase):
             v.draw_leds(self._led_spheres())
         if self.draw_curve or self.draw_bbox:
             v.draw_lines(self._overlay_lines())
+        # (Every mode but "rgb_array" goes on, in the reference, to blit the image into a pyglet WINDOW -- its own GL context, with glOrtho left on
+        # that context's model-view stack (simulator.py:2007-2022) -- and leaves that context current: a reset() called before the next frame sets
+        # its light THERE, not in the context the frames are drawn in.  There is no window here; the capture goes through the camera as after
+        # any frame.  DESIGN.md section 4 lists it with the deviations.)
         return v.frames_host()[0]
 
     def _note_modelview(self, top_down: bool, bbox: bool):
@@ -455,7 +461,7 @@ class Simulator(_EnvBase):
         vp, va, vh, vdeg = viewer_camera(top_down, bbox, pos, float(self.cur_angle), self.grid_width, self.grid_height, self.road_tile_size, st.cam_fov_y_deg)
         h = st.cam_height if vh is None else vh
         deg = st.cam_angle_deg if vdeg is None else vdeg
-        y0 = 0.0 if (top_down or bbox) else float(pos[1])
+        y0 = 0.0 if top_down else float(pos[1])       # (gluLookAt ignores the agent only in the top-down view; the bbox view sits 0.8 m above pos, simulator.py:1776-1778)
         sa, ca = math.sin(va), math.cos(va)
         self._gl_modelview = dict(C=np.array([vp[0] + CAMERA_FORWARD_DIST * ca, y0 + h, vp[2] - CAMERA_FORWARD_DIST * sa]), sa=sa, ca=ca,
                                   sth=math.sin(math.radians(deg)), cth=math.cos(math.radians(deg)))

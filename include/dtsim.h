@@ -344,7 +344,9 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags);
  * (ax, ay, az, bx, by, bz) + colour (r, g, b in 0..1, the glColor3f of the line); env_idx[i] = the env segment i is drawn into (NULL: all
  * into env 0; must be non-decreasing).  Each segment goes through the env's camera, is clipped at the near plane and rasterised as a
  * 1-pixel line under 4x multisampling (coverage per sample, first line wins a sample); the colour is the glColor lit as a surface with
- * normal +y.  Lines are not depth-tested against mesh objects (they lie above the tile plane).  Synchronous (host segments). */
+ * normal +y.  Lines are not depth-tested against mesh objects (they lie above the tile plane).  Synchronous (host segments).
+ * Both post-passes (this and dtsim_draw_leds) use the cameras / projected triangles of THE LAST dtsim_render: dtsim_step, dtsim_reset,
+ * dtsim_reset_done and dtsim_write invalidate them -- the call then fails with DTSIM_E_STATE until the state has been rendered again. */
 int dtsim_draw_lines(dtsim_t* h, const float* lines, const int32_t* env_idx, int n);
 /* The LED spheres of enable_leds (objects.py:68-121: per LED of a duckiebot-kind object a 1 cm gluSphere at alpha 1 and a halo at alpha 0.2,
  * additively blended -- glBlendFunc(GL_SRC_ALPHA, GL_ONE) -- with depth test and depth writes, lit, untextured) as a post-pass on the frames

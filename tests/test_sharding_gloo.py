@@ -114,7 +114,7 @@ def _worker(rank, world, port, total, q):
         got_steps = []
         T = 7
         for t in range(T):
-            tt, fr = ss2.step_render_gather(a1, overlap=True, dst=0)
+            tt, fr = ss2.step_render_gather(a1, overlap=True, dst=0, what="frames")
             if t == 0:
                 ok = ok and tt is None and fr is None
                 continue
@@ -152,7 +152,7 @@ def _worker(rank, world, port, total, q):
         # blocking variant: the frames of this very step
         ss3 = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
         for t in range(3):
-            tt, fr = ss3.step_render_gather(a1, overlap=False, dst=0)
+            tt, fr = ss3.step_render_gather(a1, overlap=False, dst=0, what="frames")
             ok = ok and tt == t and ((rank == 0 and bool(torch.equal(fr, _step_frames(0, total, t + 1)))) or (rank != 0 and fr is None))
         q.put((rank, ok))
     finally:
@@ -171,7 +171,7 @@ def _worker_lifetime_and_groups(rank, world, port, total, q):
             ss = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
             held = None                                  # (step, tensor) of the call before
             for t in range(8):
-                tt, fr = ss.step_render_gather(a1, overlap=overlap, dst=0)
+                tt, fr = ss.step_render_gather(a1, overlap=overlap, dst=0, what="frames")
                 if rank == 0 and held is not None:       # obs_t kept next to obs_t+1: still step held[0]'s bytes, whole
                     assert torch.equal(held[1], _step_frames(0, total, held[0] + 1)), (overlap, t, held[0])
                     assert fr is None or fr.data_ptr() != held[1].data_ptr()
@@ -183,7 +183,7 @@ def _worker_lifetime_and_groups(rank, world, port, total, q):
             if rank == 0:
                 assert torch.equal(fr, _step_frames(0, total, 8))
             # copy=True: a private tensor, not a slot
-            tt, fr = ss.step_render_gather(a1, overlap=False, dst=0, copy=True)
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=0, copy=True, what="frames")
             if rank == 0:
                 assert all(fr.data_ptr() != sl["recv"].data_ptr() for sl in ss._gx["slots"]) and torch.equal(fr, _step_frames(0, total, 9))
             # another payload on the same object: the pending transfers are drained, new buffers of the new shape
@@ -193,18 +193,31 @@ def _worker_lifetime_and_groups(rank, world, port, total, q):
                     assert tuple(ob.shape) == (total, 4, 5, 3)
                     assert torch.equal(ob, _fake_frames(0, total, 4, 5) + torch.tensor(((tt + 10) * 13 + 4) % 256, dtype=torch.uint8))   # the new exchange counts from 0; 9 steps were made before
             ss.flush_gather(dst=0)
+            # two slots: a third less memory on the root; the batch handed out is whole until the next call
+            for t in range(5):
+                tt, fr = ss.step_render_gather(a1, overlap=True, dst=0, what="frames", slots=2)
+                assert len(ss._gx["slots"]) == 2
+                if rank == 0 and fr is not None:
+                    assert torch.equal(fr, _step_frames(0, total, tt + 13)), (t, tt)       # 12 steps were made before; the new exchange counts from 0
+            ss.flush_gather(dst=0)
+            with pytest.raises(ValueError):
+                ss.step_render_gather(a1, slots=4)
+            # the default payload is the observation (DEFAULT_OBS), not the full frames
+            tt, ob = ss.step_render_gather(a1, overlap=False, dst=0)
+            if rank == 0:
+                assert tuple(ob.shape) == (total,) + sharding.ShardedSimulator.DEFAULT_OBS + (3,)
             # and back, to the OTHER root
-            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1)
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1, what="frames")
             assert (fr is not None) == (rank == 1)
             if rank == 1:
-                assert torch.equal(fr, _step_frames(0, total, 13))
+                assert torch.equal(fr, _step_frames(0, total, 20))
         # an explicit group: `dst` stays a GLOBAL rank and the peers of the point-to-point transfers are translated with
         # dist.get_global_rank (torch sorts the ranks of a new group, so at world_size 2 group rank == global rank: the
         # translation is the identity here, what is exercised is the group argument on every call of the exchange)
         g = dist.new_group(ranks=[0, 1])
         ss = sharding.ShardedSimulator("small_loop", total, seed=base, sim_factory=_FakeSim, device=0)
         for t in range(3):
-            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1, group=g)
+            tt, fr = ss.step_render_gather(a1, overlap=False, dst=1, group=g, what="frames")
             assert (fr is not None) == (rank == 1)
             if rank == 1:
                 assert torch.equal(fr, _step_frames(0, total, t + 1)), t
@@ -257,3 +270,12 @@ def test_shard_range_properties():
     with pytest.raises(ValueError):
         sharding.shard_range(0, 3, 10)
     assert sharding.env_seed(None, 5) is None
+
+
+def test_root_memory_of_the_overlapped_gather_is_stated():
+    """three slots of what="frames" at the north star's size are 90.6 GB of receive tensors on rank 0; the observation
+    payload is 16 x smaller; _exchange_state checks the number against the device's free memory before allocating (CUDA only)."""
+    S = sharding.ShardedSimulator
+    assert S.exchange_root_bytes(3, 8, (4096, 480, 640, 3), 1) == 3 * 8 * 4096 * 480 * 640 * 3 == 90_596_966_400
+    assert S.exchange_root_bytes(2, 8, (4096, 120, 160, 3), 1) * 24 == S.exchange_root_bytes(3, 8, (4096, 480, 640, 3), 1)
+    assert 0 < S.ROOT_MEMORY_FRACTION < 1 and S.N_SLOTS == 3 and S.DEFAULT_OBS == (120, 160)
