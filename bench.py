@@ -296,13 +296,14 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="timed regions of --steps steps each; value = the median one")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL frame all-gather measurement")
     ap.add_argument("--gather-timeout", type=float, default=120.0, help="give up on the frame exchange after this many seconds")
-    ap.add_argument("--config", default="c3", choices=["c3", "c1", "c2", "c4", "c5"],
+    ap.add_argument("--config", default="c3", choices=["c3", "c1", "c2", "c4", "c5", "c3dr"],
                     help="c3 (default, the headline): raster + fisheye; c1: ONE env through the gym facade, 84x84 observations, "
                          "random actions, with the CPU oracle beside it (BASELINE.json configs[0], the plumbing case); "
                          "c2: dynamics+collision only, render off "
                          "(BASELINE.json configs[1]); a step is then `--fuse` physics steps in one launch; "
                          "c4: loop_pedestrians + domain randomisation (configs[3]); c5: MultiMap, two maps alternating "
-                         "per env slot (configs[4])")
+                         "per env slot (configs[4]); c3dr: what gym.make('Duckietown-small_loop-v0') runs -- the registered defaults "
+                         "domain_rand=True, distortion=False (simulator.py:213,223) -- at N = 4096: context for users, not a BASELINE config")
     ap.add_argument("--fuse", type=int, default=32, help="c2: physics steps fused per dtsim_step launch")
     args = ap.parse_args()
     if args.config == "c2":
@@ -343,8 +344,11 @@ def main():
         "c5": dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, label="MultiMap-v0 (loop_only_duckies / "
                    "small_loop_only_duckies alternating per env slot, multimap_env.py:17,44-49)", ref="configs[4]",
                    kern="k_obj_setup + k_raster_v3<OBJ=1> + k_resolve_obj", extra=dict(map_cycle=True)),
+        "c3dr": dict(maps="small_loop", dr=True, distortion=False, label="Duckietown-small_loop-v0 (fixture) with the registered defaults of "
+                     "gym.make: domain_rand on, NO fisheye", ref="none: the gym.make defaults, simulator.py:213,223",
+                     kern="k_raster_v3dr<OBJ=0> + k_resolve_dr", extra={}),
     }[args.config]
-    sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=True, camera_width=W, camera_height=H,
+    sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=variant.get("distortion", True), camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
                            device=local_rank, do_reset=False, **variant["extra"])
     t_setup = time.perf_counter()
@@ -483,10 +487,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 raster -> u8 frames; f64 physics",
             "data": "synthetic",
-            "config": {"workload": f"{variant['label']}, {N} batched envs per GPU, 640x480 RGB raster + fisheye "
-                                   f"distortion, domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
+            "config": {"workload": f"{variant['label']}, {N} batched envs per GPU, 640x480 RGB raster{' + fisheye distortion' if variant.get('distortion', True) else ''}"
+                                   f", domain_rand {'on' if variant['dr'] else 'off'}, random (vel, steer) actions, "
                                    f"auto-reset from spawn pool [BASELINE.json {variant['ref']}]",
-                       "envs_per_gpu": N, "camera": [W, H], "distortion": True, "domain_rand": variant["dr"],
+                       "envs_per_gpu": N, "camera": [W, H], "distortion": bool(variant.get("distortion", True)), "domain_rand": variant["dr"],
                        "parallelism": f"env-sharded x{world}, no data-path collective", **cfg_extra},
             "roofline": {"bound": "hbm", "kernel": f"dtsim_render pass = k_cam_setup + {variant['kern']} (HIP events around the launches)", "achieved": achieved / 1e9, "peak": PEAK_HBM / 1e9,
                          "unit": "GB/s", "frac": achieved / PEAK_HBM, "traffic": traffic, "traffic_source": traffic_source,

@@ -3,24 +3,25 @@
 TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  Follows
 src/gym_duckietown/simulator.py:1707-1951 (scene order, camera, lighting state),
 :386-526 (tile / ground vertex lists), objects.py:123-148, objmesh.py:181-293,
-graphics.py:172-251 (4x MSAA float FBO + resolve) and distortion.py:85-125, per the
-render spec of SURVEY.md Appendix B.  OpenGL itself cannot run here: PARITY UNPINNED
-against real GL; this file fixes ONE documented interpretation of the fixed-function
-pipeline, in float64, evaluating all four MSAA samples of every pixel (no fast path).
+graphics.py:172-251 (4x MSAA float FBO + resolve) and distortion.py:85-125, in float64, evaluating all four MSAA samples
+of every pixel (no fast path).
 
-Interpretation choices (also in DESIGN.md "Render spec"):
-  * 4 samples at the standard rotated-grid offsets; coverage/depth per sample, shading
-    once per primitive at the pixel centre (attributes extrapolated) -- GL MSAA semantics.
-  * lighting: C = clamp01(m * (0.3 + A + D max(0, N.L))), unit normals (GL_NORMALIZE is
-    off in the reference and mesh units are unknown, so the 1/scale gain is not modelled);
-    light position is fixed in eye space (modelview = identity when reset() calls glLightfv).
-  * tiles: `lighting="gouraud"` evaluates the lit colour at the 8x8 vertex grid of the tile
-    (simulator.py:386-433) and interpolates bilinearly inside each quad (the driver's
-    triangle split is unknown); `lighting="pixel"` evaluates it at the fragment -- what the
-    HIP raster does (difference < 1/255, tests/test_gpu_render.py measures it).
-  * ground quad: lit at its 4 corners, bilinear over the quad, unit normal +y.
-  * objects: per-vertex lighting, perspective-correct barycentric interpolation; triangles
-    with a vertex closer than the near plane are dropped (no near clipping).
+PINNED against the reference's own frames on real OpenGL (round 6): tests/test_gl_golden.py holds the GL-faithful mode
+(lighting="gouraud") to tests/golden/ref_gl_*.npz -- 120 frames the UNMODIFIED reference Simulator rendered on Mesa 23.2.1
+llvmpipe, the renderer of its own CI (oracle/gl/, oracle/make_gl_golden.py) -- at >= 99.6 % of the pixels bit-identical,
+<= 0.12 % beyond +-1/255.  What GL does where the reference's calls leave room (all measured there):
+  * 4 samples at GL_SAMPLE_POSITION, rows flipped; coverage/depth per sample, shading once per primitive at the pixel
+    centre (attributes extrapolated) -- GL MSAA semantics.
+  * lighting: C = clamp01(m * (0.3 + A + D max(0, N.L))) per vertex; normals go through the inverse transpose of the
+    model-view and are NOT renormalised (GL_NORMALIZE is off): object normals are divided by the object's scale, the ground
+    quad -- which has no normals -- is lit with GL's current normal (0, 0, 1) through glScalef(50, 0.01, 50).
+    The light position is fixed in eye space (whatever model-view was current when reset() called glLightfv).
+  * tiles: lighting="gouraud" evaluates the lit colour at the 8x8 vertex grid of the tile (simulator.py:386-433) and
+    interpolates bilinearly inside each quad; the "pixel*" modes evaluate it at the fragment -- what the HIP raster does.
+  * GL_LINEAR: llvmpipe's 8-bit integer filter (_gl_linear); the "pixel" / "pixel-dr" modes restate the product's
+    byte-weight filter instead (_dtsim8_shade); see MODES.
+  * objects: per-vertex lighting, perspective-correct barycentric interpolation; triangles with a vertex closer than the
+    near plane are dropped (no near clipping).
   * readback: round(255 * clamp01(mean of the 4 samples)).
 """
 from __future__ import annotations

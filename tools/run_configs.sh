@@ -11,6 +11,7 @@ python bench.py --config c2 --envs 1048576 --fuse 1 --steps 20 --warmup 3 2>/dev
 python bench.py --config c3 --steps 30 --warmup 5 --cpu-steps 0 2>/dev/null | tail -1 >> $OUT
 python bench.py --config c4 --steps 20 --warmup 3 --cpu-steps 0 2>/dev/null | tail -1 >> $OUT
 python bench.py --config c5 --steps 20 --warmup 3 --cpu-steps 0 2>/dev/null | tail -1 >> $OUT
+python bench.py --config c3dr --steps 20 --warmup 3 --cpu-steps 0 --no-gather 2>/dev/null | tail -1 >> $OUT   # the gym.make defaults (domain_rand on, no fisheye): context, not a BASELINE config
 python - <<'PY'
 import json, sys, os
 tag = os.environ.get("TAG", "r02")
@@ -25,7 +26,7 @@ PY
 export TMPDIR=/tmp
 KOUT=$PWD/gpurun_out/${TAG}_configs_kernels.txt
 : > $KOUT
-for c in c4 c5; do
+for c in c4 c5 c3dr; do
   D=/tmp/cfgtrace_$c; rm -rf $D; mkdir -p $D
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $D -o t -- python $GRAFT_REPO_ROOT/bench.py --config $c --steps 10 --warmup 3 --cpu-steps 0 > $D/log 2>&1)
   echo "== bench.py --config $c --steps 10 --warmup 3 (N = 4096, 640x480 + fisheye): kernels of the timed loop" >> $KOUT
