@@ -62,3 +62,29 @@ def test_frames_match_reference_gl(case):
           f"beyond +-8 {worst['gt8']:.5f}, mean abs {worst['mean']:.4f} / 255")
     for k, s in enumerate(all_stats):
         assert s["gt1"] <= TOL["gt1"] and s["gt2"] <= TOL["gt2"] and s["mean"] <= TOL["mean"], (case, k, s)
+
+
+@pytest.mark.parametrize("case,seeds", [("small_loop_t256_160", list(range(10, 26))), ("small_loop_dr_t256_160", list(range(30, 46))),
+                                        ("loop_dr_t256_160", list(range(70, 86)))])
+def test_drop_in_facade_reproduces_the_reference_s_first_frames(case, seeds):
+    """End to end, nothing uploaded by the test: `gym_duckietown.Simulator(map_name, seed=s, ...)` of THIS package (the HIP library behind
+    the reference's constructor) against `Simulator(map_name, seed=s, ...)` of the REFERENCE on Mesa llvmpipe -- same seed, same asset files.
+    The reset draws must land on the same pose and randomisation (bit-exact: compared with the state the golden recorded from the reference
+    instance) and the observation `reset()` returns must be the reference's frame within the tolerance of this file."""
+    from gym_duckietown.simulator import Simulator
+    d = G.load(case)
+    m = d["meta"]
+    assert len(seeds) == len(d["frame"])
+    worst = dict(gt1=0.0, gt2=0.0, mean=0.0)
+    for k, seed in enumerate(seeds):
+        env = Simulator(map_name=m["map_name"], domain_rand=bool(m["dr"]), seed=seed, camera_width=int(m["W"]), camera_height=int(m["H"]),
+                        max_steps=100000, distortion=False, asset_root=asset_trees.tree(m["tree"]))
+        assert np.array_equal(np.asarray(env.cur_pos, dtype=np.float64), d["pos"][k]) and float(env.cur_angle) == float(d["angle"][k]), (case, seed)
+        assert np.allclose(np.asarray(env.horizon_color, dtype=np.float64)[:3], d["horizon"][k], rtol=0, atol=0), (case, seed)
+        obs = env.render_obs()
+        s = G.stats(obs, d["frame"][k])
+        for key in worst:
+            worst[key] = max(worst[key], s[key])
+        assert s["gt1"] <= TOL["gt1"] and s["gt2"] <= TOL["gt2"] and s["mean"] <= TOL["mean"], (case, seed, s)
+        env.close()
+    print(f"\n{case}: facade vs reference, worst of {len(seeds)} seeds: beyond +-1 {worst['gt1']:.5f}, beyond +-2 {worst['gt2']:.5f}, mean abs {worst['mean']:.4f} / 255")
