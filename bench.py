@@ -592,7 +592,7 @@ def main():
                 sync_all()
                 tg = time.perf_counter()
                 for t in range(kp):
-                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True, what="frames")
+                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True, what="frames", slots=2)   # (2 x world x 3.77 GB on the root)
                 ss.flush_gather(dst=0)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
@@ -600,8 +600,9 @@ def main():
                 tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
                 dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
                 gather["to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
-                                                "collective": "ShardedSimulator.step_render_gather(overlap=True): gather(uint8 frames, dst=0), "
-                                                              "three buffers rotating through dtsim_bind_frames, the exchange of step t behind step t+1, stream-ordered by events"}
+                                                "collective": "ShardedSimulator.step_render_gather(what='frames', slots=2, overlap=True): gather(uint8 frames, dst=0), "
+                                                              "two buffers rotating through dtsim_bind_frames, the exchange of step t behind step t+1, stream-ordered by events",
+                                                "root_receive_bytes": ShardedSimulator.exchange_root_bytes(2, world, (N, H, W, 3), 1)}
                 del ss
             except Exception as ex:
                 sim.bind_frames(None)
@@ -636,14 +637,16 @@ def main():
                 sync_all()
                 tg = time.perf_counter()
                 for t in range(kp):
-                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True, what="observe", obs=(120, 160))
+                    ss.step_render_gather(acts[Wm + t], overlap=True, dst=0, local_actions=True)
                 ss.flush_gather(dst=0)
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - tg
                 tgt = torch.tensor([tg], device=rdev, dtype=torch.float64)
                 dist.all_reduce(tgt, op=dist.ReduceOp.MAX)
                 gather["observations_to_root_overlapped"] = {"value": world * N * kp / float(tgt.item()), "unit": "env-steps/s", "steps": kp,
-                                                             "collective": "ShardedSimulator.step_render_gather(what='observe', obs=(120, 160), overlap=True, dst=0)"}
+                                                             "collective": "ShardedSimulator.step_render_gather(overlap=True, dst=0) with its defaults: what='observe', obs=(120, 160), three slots",
+                                                             "root_receive_bytes": ShardedSimulator.exchange_root_bytes(3, world, (N, 120, 160, 3), 1)}
+                gather["learner_path"] = "observations_to_root_overlapped (the default payload of step_render_gather: what a learner can keep up with over xGMI; the full-frame legs are context)"
                 del ss
             except Exception as ex:
                 gather["observations_to_root_overlapped"] = {"error": repr(ex)[:200]}

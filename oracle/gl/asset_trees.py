@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import os
 import shutil
+
+import numpy as np
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -41,8 +43,9 @@ def tree(name: str) -> str:
     for m, md in assets.MAPS.items():
         with open(os.path.join(base, "maps", f"{m}.yaml"), "w") as f:
             yaml.safe_dump(md, f)
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(os.path.join(base, "textures", "black_tile.png")) if os.makedirs(os.path.join(base, "textures"), exist_ok=True) is None else None   # objmesh.py:285: the texture untextured chunks get in the segmentation view
     if name == "t128":
-        shutil.copytree(os.path.join(ASSETS, "textures"), os.path.join(base, "textures"))
+        shutil.copytree(os.path.join(ASSETS, "textures"), os.path.join(base, "textures"), dirs_exist_ok=True)
     elif name == "t256":
         for kind in KINDS:
             d = os.path.join(base, "textures", "tiles-processed", "photos", kind)
@@ -50,6 +53,13 @@ def tree(name: str) -> str:
             Image.fromarray(assets.make_texture(kind, 256)[..., :3]).save(os.path.join(d, "texture.png"))
     else:
         raise KeyError(name)
+    # Texture.bind(segment=True) (graphics.py:52-57) asks duckietown_world for a texture named after the tile KIND ("grass", "straight", ...):
+    # the package's legacy per-kind images.  Stand-ins: the same image under that name (only the reference's resource lookup sees them).
+    os.makedirs(os.path.join(base, "textures", "legacy"))
+    for kind in KINDS:
+        src = os.path.join(base, "textures", "tiles-processed", "photos", kind, "texture.png")
+        if os.path.isfile(src):
+            shutil.copyfile(src, os.path.join(base, "textures", "legacy", f"{kind}.png"))
     _built[name] = base
     return base
 

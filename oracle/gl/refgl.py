@@ -17,8 +17,8 @@ What is real and what is a stand-in when the reference runs here:
               unpinned, see there: it moves the robot between frames and has no part in how a frame is drawn), get_transform
               (README.md:239 semantics, as oracle/refstub.py), PyGeometry's three SE2 closed forms,
               get_duckiebot_color_from_colorname (a colour table).
-  absent      cv2 / carnivalmirror (the fisheye remap and the lane-marking branch of load_texture(segment=True)): frames
-              are produced with distortion=False; segment=True works for every texture should_segment_out() fills.
+  absent      cv2 / carnivalmirror: no fisheye remap (frames are produced with distortion=False).  The eight cv2 calls of
+              load_texture(segment=True) are stood in for by _cv2_stand_in (the restated 8-bit BGR <-> HSV conversions).
 """
 from __future__ import annotations
 
@@ -94,6 +94,55 @@ class AssetDir:
         return out
 
 
+def _cv2_stand_in():
+    """The eight cv2 calls of load_texture(segment=True)'s lane-marking branch (graphics.py:100-126), so that the reference's segmentation
+    render can run: imread / cvtColor(BGR2HSV, HSV2BGR) / inRange / bitwise_not / morphologyEx(MORPH_ERODE) / bitwise_and.  The 8-bit
+    colour conversions are the restatement of OpenCV's integer algorithm the product uses too (dtsim.assets.bgr2hsv_u8 / hsv2bgr_u8;
+    pinned against cv2 where it is installed, tests/test_thirdparty_pins.py): what the segmentation goldens pin is what GL does with the
+    textures, not OpenCV."""
+    from dtsim import assets as A
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_UNCHANGED, cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR, cv2.MORPH_ERODE = -1, 40, 54, 0
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.BORDER_CONSTANT, cv2.CV_32FC1 = 0, 1, 2, 3, 0, 5   # (default arguments of distortion.py / wrappers.py)
+
+    def imread(path, flags=None):
+        from PIL import Image
+        with Image.open(path) as im:
+            a = np.asarray(im.convert("RGBA" if im.mode in ("RGBA", "LA", "P") else "RGB"), dtype=np.uint8)
+        return np.ascontiguousarray(a[..., [2, 1, 0] + ([3] if a.shape[-1] == 4 else [])])
+
+    def cvtColor(img, code):
+        if code == cv2.COLOR_BGR2HSV:
+            return A.bgr2hsv_u8(img[..., :3])
+        if code == cv2.COLOR_HSV2BGR:
+            return A.hsv2bgr_u8(img)
+        raise NotImplementedError(code)
+
+    def inRange(img, lo, hi):
+        return (np.all((img >= np.asarray(lo)) & (img <= np.asarray(hi)), axis=-1) * 255).astype(np.uint8)
+
+    def morphologyEx(src, op, kernel):                     # erode: minimum over the kernel's support, the border never lowers it
+        assert op == cv2.MORPH_ERODE and kernel.shape == (3, 3)
+        pad = np.pad(src, 1, constant_values=255)
+        out = np.full_like(src, 255)
+        H, W = src.shape
+        for dy in range(3):
+            for dx in range(3):
+                if kernel[dy, dx]:
+                    out = np.minimum(out, pad[dy:dy + H, dx:dx + W])
+        return out
+
+    def bitwise_and(a, b, mask=None):
+        r = a & b
+        if mask is not None:
+            r = np.where((mask != 0)[..., None] if r.ndim == 3 else (mask != 0), r, 0).astype(a.dtype)
+        return r
+
+    cv2.imread, cv2.cvtColor, cv2.inRange, cv2.morphologyEx, cv2.bitwise_and = imread, cvtColor, inRange, morphologyEx, bitwise_and
+    cv2.bitwise_not = lambda a: (255 - a).astype(a.dtype)
+    return cv2
+
+
 BOT_COLORS = {"red": (1.0, 0.0, 0.0), "green": (0.0, 0.5, 0.0), "blue": (0.0, 0.0, 1.0), "yellow": (1.0, 1.0, 0.0),
               "grey": (0.3, 0.3, 0.3), "gray": (0.3, 0.3, 0.3), "white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0),
               "orange": (1.0, 0.5, 0.0), "purple": (0.5, 0.0, 0.5), "pink": (1.0, 0.4, 0.7), "cyan": (0.0, 1.0, 1.0)}   # = dtsim.assets.AssetLibrary.BOT_COLORS
@@ -123,6 +172,7 @@ def load(transform_uses_width: bool = False):
              "zuper_commons", "zuper_commons.logs", "zuper_commons.types", "geometry", "carnivalmirror", "zmq"]
     shim = {n: mock(n) for n in names}
     shim.update(mods)
+    shim["cv2"] = _cv2_stand_in()
 
     class _Env:
         metadata = {}

@@ -77,13 +77,15 @@ def _stack(recs):
     return {k: np.stack([np.asarray(r[k]) for r in recs]) for k in keys}
 
 
-def case_reset_poses(map_name, tree, dr, W, H, seeds, **kw):
-    """One NEW Simulator per seed (a fresh GL context each, as every pyglet Window is): the frame its constructor's reset() ends with."""
+def case_reset_poses(map_name, tree, dr, W, H, seeds, segment=False, **kw):
+    """One NEW Simulator per seed (a fresh GL context each, as every pyglet Window is): the frame its constructor's reset() ends with.
+    segment=True: render_obs(segment=True), the segmentation view (only maps without mesh objects: with one in the scene the reference
+    raises TypeError -- load_texture is an lru_cache and objmesh.py:268-292 hands it a LIST as segment_into_color)."""
     recs = []
     for seed in seeds:
         sim, ns = refgl.make_simulator(map_name, asset_trees.roots(tree), domain_rand=dr, seed=seed, camera_width=W, camera_height=H,
                                        max_steps=100000, **kw)
-        recs.append(snapshot(sim, ns, sim.render_obs()))
+        recs.append(snapshot(sim, ns, sim.render_obs(segment=segment)))
     return recs
 
 
@@ -145,6 +147,9 @@ CASES = {
     "town_t128_320": (case_placed, dict(map_name="test_town", tree="t128", dr=False, W=320, H=240, seed=3, poses="town")),
     "town_dr_t128_320": (case_placed, dict(map_name="test_town", tree="t128", dr=True, W=320, H=240, seed=4, poses="town")),
     "town_t128_640": (case_placed, dict(map_name="test_town", tree="t128", dr=False, W=640, H=480, seed=3, poses="town2")),
+    "segment_small_loop_t256_320": (case_reset_poses, dict(map_name="small_loop", tree="t256", dr=False, W=320, H=240, seeds=[90, 91, 92, 93, 94, 95], segment=True)),
+    # (segment=True with domain_rand: Texture.bind calls rng.randint, which the numpy Generator the reference's own reset() needs -- it calls
+    #  .integers -- does not have: AttributeError in the reference itself; no golden)
     "episode2_t256_160": (case_second_episode, dict(map_name="small_loop_only_duckies", tree="t256", dr=False, W=160, H=120, seed=9, n_steps=200, n_resets=4)),
     "episode2_dr_t256_160": (case_second_episode, dict(map_name="loop_only_duckies", tree="t256", dr=True, W=160, H=120, seed=11, n_steps=200, n_resets=4)),
 }

@@ -62,8 +62,12 @@ def obj_states(d, k):
 
 
 def oracle_frame(d, k, lighting="gouraud"):
-    scene, _md, _lib = scene_for(d["meta"])
-    return raster.render_obs(camera(d, k), scene, lighting, obj_states=obj_states(d, k))
+    scene, _md, lib = scene_for(d["meta"])
+    cam = camera(d, k)
+    if d["meta"].get("segment"):                      # render_obs(segment=True): textures through load_texture(segment=True), lighting off, magenta clear / ground
+        seg_tex = {kind: assets.segment_texture(t, lib.tile_texture_file(kind)) for kind, t in scene.textures.items()}
+        cam, scene = raster.segment_view(cam, scene, seg_tex, {key: (0, 0, 0) for key in scene.meshes})
+    return raster.render_obs(cam, scene, lighting, obj_states=obj_states(d, k))
 
 
 def stats(a, b):

@@ -45,7 +45,7 @@ def render_case(d, per_env_camera=None):
         vis = sim.read(_ffi.FIELD_OBJ_VISIBLE)
         vis[:, :nobj] = d["obj_visible"].astype(np.uint8)
         sim.write(_ffi.FIELD_OBJ_VISIBLE, vis)
-    sim.render()
+    sim.render(segment=bool(m.get("segment")))
     frames = sim.frames_host().copy()
     sim.close()
     return frames
