@@ -269,7 +269,7 @@ def main_c1(args):
             if dn:
                 o.reset()
         cpu = {"value": n / (time.perf_counter() - t1), "unit": "env-steps/s", "cores": 1, "kind": "port",
-               "sample": f"{n} env-steps of small_loop at 84x84 on the numpy oracle (the reference's Pyglet path is not runnable here)"}
+               "sample": f"{n} env-steps of small_loop at 84x84 on the numpy oracle (the software rasteriser; bench.py --config c3 times the reference's GL call stream on llvmpipe)"}
     k_ms = 1e3 * dt / K
     print(json.dumps({
         "metric": "env-steps/sec (1 env, 84x84 obs, gym loop)", "value": K / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": K,

@@ -387,7 +387,8 @@ def _gl_floats(gl, kind):
 
 @pytest.mark.parametrize("dr", [False, True])
 def test_frame_gl_arguments_are_the_oracle_s_camera_and_scene(dr):
-    """The GL raster itself cannot run here, but every ARGUMENT the reference hands to it can be read: reset() (simulator.py:565-584) and
+    """(Written when GL was believed absent; since round 6 the frames themselves are pinned on real GL, tests/test_gl_golden.py -- this test stays because
+    it LOCALISES a failure.)  Every ARGUMENT the reference hands to GL can be read: reset() (simulator.py:565-584) and
     _render_img (:1707-1951) run UNMODIFIED against a recording gl mock -- projection, model-view, clear colour, light, ground quad, per-tile
     and per-object transforms -- and are compared with what oracle/raster.py renders from (Camera, Scene): what is left unpinned of the
     raster is what fixed-function GL does with these numbers, not which numbers it is given."""
