@@ -166,3 +166,19 @@ def test_bench_cpu_baseline_worker_runs():
     spec.loader.exec_module(bench)
     dt = bench._oracle_env_steps((1, 1000))
     assert 0 < dt < 120
+
+
+def test_bench_gl_port_worker_runs():
+    """The other cpu_baseline worker: the reference's GL call stream on Mesa llvmpipe (oracle/gl/glport.py) -- three env-steps with the fisheye
+    remap, in a child process as bench.py runs it (the GL context must not live in the process that holds the HIP context).  Skipped where the
+    swrast driver is missing: bench.py then falls back to the numpy port and says so (`gl_port_skipped`)."""
+    import json, subprocess, sys
+    from oracle.gl import glport
+    if not glport.available():
+        pytest.skip("no swrast_dri.so / GL headers here")
+    code = ("import sys, json; sys.path[:0] = [%r, %r]; import bench; from oracle.gl import glshim; "
+            "print(json.dumps({'dt': bench._glport_env_steps((3, 1000, True)), 'renderer': glshim.renderer()}))" % (ROOT, os.path.join(ROOT, "gym-duckietown_amd")))
+    res = subprocess.run([sys.executable, "-W", "ignore", "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, LP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stderr[-800:]
+    rec = json.loads(res.stdout.strip().splitlines()[-1])
+    assert 0 < rec["dt"] < 120 and "llvmpipe" in rec["renderer"]
