@@ -20,7 +20,7 @@
 //                 and kept in REGISTERS across the env loop; per env only the 64-B EnvFast
 //                 changes (one wave-uniform scalar load) and a pixel costs one 2-D rotation +
 //                 tile lookup (LDS) + one bilinear fetch (two 8-byte loads from the L2-resident
-//                 padded texture) with the lighting folded into the filter weights.
+//                 padded texture, llvmpipe's integer GL_LINEAR: gl_linear_rgb), times the lit factor.
 //                 MSAA: pixels whose 4 samples may see different primitives (horizon, map
 //                 border, tile seams, mesh boxes; conservative test) are appended (ballot +
 //                 mbcnt, no atomics) to a per-wavefront global queue region.
@@ -48,8 +48,10 @@
 //
 // Roofline: algorithmic bytes per env-step = W*H*3 (921 600 B at 640x480), written once (+ the ~1.3 % edge
 // pixels a second time); LUT / textures / tables are shared by all envs and stay in registers / LDS / L2.
-// Measured (profiles/): the pass is co-limited by vector issue and the texture path -- 36.9 vector instructions per pixel
-// (round 1: 64.8), vector ALUs 74 % and texture unit 73 % busy -- at 25 - 26 % of the HBM roofline; float32 / integer-filter shading, uint8 output.
+// Measured (profiles/): the pass is co-limited by vector issue and the texture path -- 33.2 vector instructions per pixel
+// (round 1: 64.8; round 5: 36.9), vector ALUs 72 % and texture unit 73 % busy -- at 27 - 29 % of the HBM roofline; float32 geometry, byte-weight
+// filter at the precision GL's own GL_LINEAR has on the reference's renderer, uint8 output.
+// Parity: every pipeline is held to frames the unmodified reference rendered on Mesa llvmpipe (tests/test_gpu_gl_golden.py).
 #include "dtsim_dev.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -352,8 +354,8 @@ __global__ void k_cam_setup(SimArrays A, int domain_rand, int segment, float asp
 
 // ---- mesh objects -> per-env screen-space triangles ------------------------------------
 // One workgroup per env.  WorldObj.render (objects.py:123-148): T(pos) S(scale) Ry(y_rot), mesh
-// chunks with per-vertex Kd colour (objmesh.py:241-293), GL per-vertex lighting (unit normals,
-// DESIGN.md "Render spec"), projected to rectilinear pixel coordinates.
+// chunks with per-vertex Kd colour (objmesh.py:241-293), GL per-vertex lighting (normals through the inverse transpose of the
+// model-view, NOT renormalised: divided by the scale -- DESIGN.md "Render spec"), projected to rectilinear pixel coordinates.
 // order-preserving float <-> int map (for integer atomics on floats)
 __device__ inline int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ inline float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
