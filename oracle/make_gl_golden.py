@@ -120,6 +120,22 @@ def case_second_episode(map_name, tree, dr, W, H, seed, n_steps, n_resets):
     return recs
 
 
+def case_views(map_name, tree, W, H, seeds, view):
+    """The two other views of _render_img, one new Simulator per seed: view = "top_down" (render(mode="top_down")'s image: the map from above with the
+    agent's own mesh drawn at its pose, simulator.py:1786-1798, 1920-1927; W x H = the window size) or "bbox" (draw_bbox=True: the debugging camera
+    0.8 m above the robot looking down, :1776-1778, with the collision rectangles as GL_LINE_LOOPs)."""
+    recs = []
+    for seed in seeds:
+        kw = dict(draw_bbox=True, camera_width=W, camera_height=H) if view == "bbox" else {}
+        sim, ns = refgl.make_simulator(map_name, asset_trees.roots(tree), domain_rand=False, seed=seed, max_steps=100000, **kw)
+        if view == "bbox":
+            frame = sim.render_obs()
+        else:
+            frame = sim._render_img(W, H, sim.multi_fbo_human, sim.final_fbo_human, sim.img_array_human, top_down=True, segment=False)
+        recs.append(snapshot(sim, ns, frame))
+    return recs
+
+
 def town_poses():
     """(x, z, angle) looking at each object of test_town from 0.45 m, as tests/test_gpu_render.py places its envs."""
     import yaml
@@ -150,6 +166,8 @@ CASES = {
     "segment_small_loop_t256_320": (case_reset_poses, dict(map_name="small_loop", tree="t256", dr=False, W=320, H=240, seeds=[90, 91, 92, 93, 94, 95], segment=True)),
     # (segment=True with domain_rand: Texture.bind calls rng.randint, which the numpy Generator the reference's own reset() needs -- it calls
     #  .integers -- does not have: AttributeError in the reference itself; no golden)
+    "view_top_down_t256_800": (case_views, dict(map_name="small_loop_only_duckies", tree="t256", W=800, H=600, seeds=[4, 5], view="top_down", dr=False)),
+    "view_bbox_t256_320": (case_views, dict(map_name="small_loop_only_duckies", tree="t256", W=320, H=240, seeds=[4, 5, 6, 7], view="bbox", dr=False)),
     "episode2_t256_160": (case_second_episode, dict(map_name="small_loop_only_duckies", tree="t256", dr=False, W=160, H=120, seed=9, n_steps=200, n_resets=4)),
     "episode2_dr_t256_160": (case_second_episode, dict(map_name="loop_only_duckies", tree="t256", dr=True, W=160, H=120, seed=11, n_steps=200, n_resets=4)),
 }
@@ -162,8 +180,9 @@ def build(name):
         kw["poses"] = town_poses()
     elif kw.get("poses") == "town2":
         kw["poses"] = town_poses()[:2]
+    meta = {k: v for k, v in CASES[name][1].items() if k not in ("poses",)}
+    kw.pop("dr", None) if fn is case_views else None
     recs = fn(**kw)
-    meta = {k: v for k, v in CASES[name][1].items() if k not in ("seeds", "poses")}
     meta["renderer"] = refgl.glshim.renderer()
     out = _stack(recs)
     out["meta"] = np.array(json.dumps(meta))

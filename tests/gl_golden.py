@@ -61,7 +61,49 @@ def obj_states(d, k):
                  light_pattern=int(d["obj_pattern"][k][i])) for i in range(d["obj_pos"].shape[1])]
 
 
-def oracle_frame(d, k, lighting="gouraud"):
+def view_scene(d, k):
+    """(Camera, Scene, object states, lines) of a record of the "top_down" / "bbox" views (meta["view"]): the cameras through
+    gym_duckietown.simulator.viewer_camera (what the facade gives this backend's camera model), the agent's own mesh as one more object in the
+    top-down view (self.mesh.render(): the red duckiebot, unscaled), the collision rectangles as line segments in the bbox view."""
+    import copy, math
+    from gym_duckietown.simulator import agent_bbox_angle, viewer_camera
+    m = d["meta"]
+    scene, md, lib = scene_for(m)
+    om = scene.m
+    st = obj_states(d, k)
+    top = m["view"] == "top_down"
+    vp, va, vh, vdeg = viewer_camera(top, not top, d["pos"][k], float(d["angle"][k]), om.grid_width, om.grid_height, om.tile_size, float(d["cam_fov_y"][k]))
+    cam = raster.Camera(vp, va, cam_height=vh, cam_angle_deg=vdeg, cam_fov_y_deg=float(d["cam_fov_y"][k]), width=int(m["W"]), height=int(m["H"]),
+                        horizon_color=list(d["horizon"][k]), ground_color=list(d["ground"][k]), light_pos=list(d["light_eye"][k]),
+                        light_ambient=list(d["light_ambient"][k]), light_diffuse=list(d["light_diffuse"][k]))
+    lines = None
+    if top:
+        key = ("view", m["map_name"], m["tree"])
+        if key not in _scenes:
+            md2 = copy.deepcopy(md)
+            md2["objects"] = list(md2["objects"]) + [{"kind": "duckiebot", "pos": [0.5, 0.5], "rotate": 0, "static": False, "scale": 1.0, "color": "red"}]
+            meshes = dict(scene.meshes)
+            meshes["duckiebot"] = lib.object_mesh(md2["objects"][-1])[1]
+            om2 = osim.OracleMap(md2, {kk: (mm.min_coords, mm.max_coords) for kk, mm in meshes.items()})
+            _scenes[key] = raster.Scene(om2, scene.textures, meshes)
+        scene = _scenes[key]
+        st = st + [dict(pos=d["pos"][k], y_rot=math.degrees(float(d["angle"][k])), visible=True)]
+    else:
+        segs = []
+        for o, s_ in zip(om.objects, st):
+            if s_["visible"]:
+                c = o.obj_corners                                            # [4, 2]
+                segs += [[c[i][0], 0.01, c[i][1], c[(i + 1) % 4][0], 0.01, c[(i + 1) % 4][1], 1.0, 0.0, 0.0] for i in range(4)]
+        c = osim.get_agent_corners(d["pos"][k], agent_bbox_angle(om.grid, om.grid_width, om.grid_height, float(d["angle"][k])))
+        segs += [[c[i][0], 0.01, c[i][1], c[(i + 1) % 4][0], 0.01, c[(i + 1) % 4][1], 1.0, 0.0, 0.0] for i in range(4)]
+        lines = np.asarray(segs, dtype=np.float64)
+    return cam, scene, st, lines
+
+
+def oracle_frame(d, k, lighting="gouraud", with_lines=True):
+    if d["meta"].get("view"):
+        cam, scene, st, lines = view_scene(d, k)
+        return raster.render_obs(cam, scene, lighting, obj_states=st, lines=lines if with_lines else None)
     scene, _md, lib = scene_for(d["meta"])
     cam = camera(d, k)
     if d["meta"].get("segment"):                      # render_obs(segment=True): textures through load_texture(segment=True), lighting off, magenta clear / ground
@@ -72,5 +114,25 @@ def oracle_frame(d, k, lighting="gouraud"):
 
 def stats(a, b):
     e = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    m = e.max(axis=-1)
+    return dict(mean=float(e.mean()), gt1=float((m > 1).mean()), gt2=float((m > 2).mean()), gt8=float((m > 8).mean()), max=int(m.max()))
+
+
+def line_mask(d, k, grow=1):
+    """Pixels of a "bbox" record that the GL_LINE_LOOPs may touch (the oracle with its lines against the oracle without, grown by `grow` pixels):
+    the reference leaves texturing and lighting on while it draws them, so their COLOUR is not something dtsim
+    reproduces; everything else in the view is compared."""
+    a, b = oracle_frame(d, k, "gouraud", True), oracle_frame(d, k, "gouraud", False)
+    m = (a != b).any(axis=-1)
+    for _ in range(grow):
+        g = m.copy()
+        g[1:] |= m[:-1]; g[:-1] |= m[1:]; g[:, 1:] |= m[:, :-1]; g[:, :-1] |= m[:, 1:]
+        m = g
+    return m
+
+
+def stats_masked(a, b, mask):
+    keep = ~mask
+    e = np.abs(a.astype(np.int32) - b.astype(np.int32))[keep]
     m = e.max(axis=-1)
     return dict(mean=float(e.mean()), gt1=float((m > 1).mean()), gt2=float((m > 2).mean()), gt8=float((m > 8).mean()), max=int(m.max()))
