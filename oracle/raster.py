@@ -7,7 +7,7 @@ graphics.py:172-251 (4x MSAA float FBO + resolve) and distortion.py:85-125, in f
 of every pixel (no fast path).
 
 PINNED against the reference's own frames on real OpenGL (round 6): tests/test_gl_golden.py holds the GL-faithful mode
-(lighting="gouraud") to tests/golden/ref_gl_*.npz -- 120 frames the UNMODIFIED reference Simulator rendered on Mesa 23.2.1
+(lighting="gouraud") to tests/golden/ref_gl_*.npz -- 116 frames the UNMODIFIED reference Simulator rendered on Mesa 23.2.1
 llvmpipe, the renderer of its own CI (oracle/gl/, oracle/make_gl_golden.py) -- at >= 99.6 % of the pixels bit-identical,
 <= 0.12 % beyond +-1/255.  What GL does where the reference's calls leave room (all measured there):
   * 4 samples at GL_SAMPLE_POSITION, rows flipped; coverage/depth per sample, shading once per primitive at the pixel
