@@ -1699,7 +1699,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         qa[u] = make_float4(0.f, 0.f, 0.f, 0.f); qb[u] = make_uint4(0u, 0u, 0u, 0u); env[u] = 0;
         pt[u] = PixTab{0.f, 0.f, 0.f, 0xFFFFu};
         if (skip[u]) continue;                       // wave-uniform
+#ifdef DT_ABL_P1_NOPIXTAB                              // ablation (wrong frames): what phase 1's per-entry table gather costs
+        pt[u] = PixTab{0.3f + 1e-3f * (float)lane, 0.4f, 0.7f, 0x3c000001u};
+#else
         pt[u] = pixtab[pix[u]];
+#endif
         uint4 qd;
         if (V3 && s_envq) {
           const uint4* fl = s_envq + el[u] * 4;
@@ -1734,12 +1738,21 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       }
       uint4 qc[U];
 #pragma unroll
+#ifdef DT_Q_P1_LOAD_ALL                                // A/B aid (round 5 behaviour): every lane gathers its record, interior or not
       for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u]) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]); }   // always in bounds (record 0 / 1 for non-tiles)
+#else
+      // only the INTERIOR entries (~ 30 %) use the record: the gather runs under their lanes -- its cost on the texture path is per distinct line
+      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u] && interior[u]) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]); }
+#endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!skip[u]) {                                // wave-uniform
           const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit);
+#ifdef DT_ABL_P1_NOSTORE
+          if (interior[u] && rgb == 0x12345678u) store_rgb(env[u], pix[u], rgb);
+#else
           if (interior[u]) store_rgb(env[u], pix[u], rgb);
+#endif
         }
         const bool msaa = have[u] && !interior[u];
         const unsigned long long mm = __ballot(msaa);
@@ -1764,7 +1777,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       const bool have = l0 + lane < n_list;
       const uint32_t le = have ? w_list[l0 + lane] : 0u;
       const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
+#ifdef DT_ABL_P2_NOSAMPTAB                             // ablation (wrong frames): what phase 2's per-entry table gathers cost
+      SampTab sp = samptab[lane];
+#else
       const SampTab sp = samptab[pix];
+#endif
       PixTab pt;
       if constexpr (V3) { pt.lr = __uint_as_float(sp.pad[0]); pt.lf = __uint_as_float(sp.pad[1]); pt.lit = __uint_as_float(sp.pad[2]); pt.mi = 0u; }   // (one table, two 16-byte loads)
       else pt = pixtab[pix];
@@ -1854,7 +1871,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
           acc[2] += ng * (q3.z * fminf(q4.y + q5.x * ndl, 1.f));
         }
         const float o[3] = {0.25f * acc[0], 0.25f * acc[1], 0.25f * acc[2]};
+#ifdef DT_ABL_P2_NOSTORE
+        if (have && o[0] < -1.f) store_rgb(e, pix, pack_rgb(o));
+#else
         if (have) store_rgb(e, pix, pack_rgb(o));
+#endif
         continue;
       }
       const float A = fq->A, B = fq->B, Cx = fq->Cx, Cz = fq->Cz, Xhi = fq->Xhi, Zhi = fq->Zhi;
