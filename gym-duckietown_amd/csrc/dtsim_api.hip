@@ -861,7 +861,7 @@ int dtsim_render(dtsim_t* h) { return dtsim_render_ex(h, 0u); }
 
 int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
   if (!h) return fail(DTSIM_E_INVALID, "null handle");
-  if (flags & ~(uint32_t)DTSIM_RENDER_SEGMENT) return fail(DTSIM_E_INVALID, "unknown render flags 0x%x", flags);
+  if (flags & ~(uint32_t)(DTSIM_RENDER_SEGMENT | DTSIM_RENDER_GL_FILTER)) return fail(DTSIM_E_INVALID, "unknown render flags 0x%x", flags);
   const bool segment = (flags & DTSIM_RENDER_SEGMENT) != 0;
   if (segment && !h->d_texels_seg) return fail(DTSIM_E_STATE, "DTSIM_RENDER_SEGMENT before dtsim_set_segment_assets");
   if (!h->frames) return fail(DTSIM_E_STATE, "handle created without DTSIM_F_RENDER");
@@ -897,7 +897,8 @@ int dtsim_render_ex(dtsim_t* h, uint32_t flags) {
     HIPCHK(hipMemsetAsync(R.dbg, 0, 8 * sizeof(int32_t), h->stream));
   }
   R.tile_recs = h->d_tilerecs; R.n_tile_recs = h->n_tilerecs; R.tex_w = h->tex_w; R.tex_h = h->tex_h;
-  R.qtex = h->d_qtex; R.qtiles = h->d_qtiles; R.n_qtiles = h->n_qtiles; R.qlog2 = h->qlog2; R.q_per_m = h->q_per_m;
+  R.qtex = (flags & DTSIM_RENDER_GL_FILTER) ? nullptr : h->d_qtex;   // no quad records: the generic raster (llvmpipe's GL_LINEAR arithmetic) takes the pass
+  R.qtiles = h->d_qtiles; R.n_qtiles = h->n_qtiles; R.qlog2 = h->qlog2; R.q_per_m = h->q_per_m;
   R.pixtab = h->d_pixtab;
   R.q3_rows = h->q3_rows;
   R.envpos = reinterpret_cast<int32_t*>((char*)h->d_envcam + (size_t)h->N * (128 + 64 + 64));

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdtsim.so")
 
 # ---- constants (mirror include/dtsim.h) -------------------------------------
-ABI_VERSION = 10
+ABI_VERSION = 11
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 32, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
@@ -33,7 +33,7 @@ TILE_OTHER = 10
  FIELD_WHEEL_DIST, FIELD_RENDER_POS) = range(28)
 KERNEL_STEP, KERNEL_RENDER, KERNEL_RESET, KERNEL_QUERY, KERNEL_OBSERVE = range(5)
 OBS_HWC, OBS_CHW, OBS_F32 = 0, 1, 2
-RENDER_SEGMENT = 1
+RENDER_SEGMENT, RENDER_GL_FILTER = 1, 2
 STEP_ONE_UPDATE, STEP_POSE_ONLY = 1, 2        # dtsim_step_ex flags
 MAP_RELOAD = 0x40000000
 

@@ -109,6 +109,7 @@ class Simulator(_EnvBase):
         if camera_rand:
             raise NotImplementedError("camera_rand (carnivalmirror calibration sampling) is outside the path this backend implements")
         self.enable_leds = bool(enable_leds)
+        self.gl_filter = bool(env_kwargs.pop("gl_filter", False))          # render with the reference renderer's GL_LINEAR arithmetic (DTSIM_RENDER_GL_FILTER: bit-faithful frames, slower)
         self.gl_light_capture = bool(env_kwargs.pop("gl_light_capture", True))   # reset()'s light through the last frame's model-view, as GL does (False: as given)
         if not domain_rand and (env_kwargs.get("device_reset") or env_kwargs.get("auto_reset")):
             self.gl_light_capture = False                # device-side resets do not come back through reset(): nothing to capture (and the per-env path would apply the sampler's camera noise)
@@ -373,12 +374,12 @@ class Simulator(_EnvBase):
         if self.draw_bbox:
             v = self._viewer(False, (self.camera_width, self.camera_height))
             self._sync_viewer(v, top_down=False, bbox=True)
-            v.render(segment=bool(segment))
+            v.render(segment=bool(segment), gl_filter=self.gl_filter)
             if self.enable_leds and not segment:
                 v.draw_leds(self._led_spheres())
             v.draw_lines(self._overlay_lines())
             return v.frames_host()[0]
-        self._sim.render(segment=bool(segment))
+        self._sim.render(segment=bool(segment), gl_filter=self.gl_filter)
         if self.enable_leds and not segment:
             self._sim.draw_leds(self._led_spheres())
         if self.draw_curve:
@@ -440,7 +441,7 @@ class Simulator(_EnvBase):
         v = self._viewer(self.distortion and mode != "free_cam")
         self._sync_viewer(v, top_down=(mode == "top_down"), bbox=self.draw_bbox and mode != "top_down")
         self._note_modelview(mode == "top_down", self.draw_bbox and mode != "top_down")
-        v.render(segment=bool(segment))
+        v.render(segment=bool(segment), gl_filter=self.gl_filter)
         if self.enable_leds and not segment:             # (the stand-in for self.mesh in the top-down view is not a WorldObj: no LEDs, as in the reference)
             v.draw_leds(self._led_spheres())
         if self.draw_curve or self.draw_bbox:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DTSIM_ABI_VERSION 10
+#define DTSIM_ABI_VERSION 11
 
 /* error codes */
 #define DTSIM_OK 0
@@ -336,8 +336,12 @@ int dtsim_render(dtsim_t* h);
  * mirror the dtsim_set_assets list entry for entry (same count, same sizes); mesh_rgb is [n_meshes][3]. */
 int dtsim_set_segment_assets(dtsim_t* h, const dtsim_texture* textures, int n_textures,
                              const uint8_t* mesh_rgb, int n_meshes);
-enum { DTSIM_RENDER_SEGMENT = 1u };
-/* dtsim_render with flags (DTSIM_RENDER_*); dtsim_render(h) == dtsim_render_ex(h, 0). */
+enum { DTSIM_RENDER_SEGMENT = 1u, DTSIM_RENDER_GL_FILTER = 2u };
+/* dtsim_render with flags (DTSIM_RENDER_*); dtsim_render(h) == dtsim_render_ex(h, 0).
+ * DTSIM_RENDER_GL_FILTER (ABI v11): this pass filters tile textures with the arithmetic of the reference's renderer -- Mesa llvmpipe's 8-bit
+ * GL_LINEAR: two lerps with an 8-bit intermediate (csrc/render.hip gl_linear_rgb) -- instead of the quad-record kernels' one-pass byte-weight
+ * filter: the generic raster runs, 2 - 4 x slower, and the frames are bit-identical to the reference's on 99.2 - 99.96 % of the pixels instead of
+ * within +-1/255 on all but 0.25 % (tests/test_gpu_gl_golden.py).  For validation against reference frames, not for throughput. */
 int dtsim_render_ex(dtsim_t* h, uint32_t flags);
 /* GL_LINE overlays of the reference -- draw_curve (simulator.py:1886-1904, graphics.py:336-349) and draw_bbox (simulator.py:1907-1918,
  * objects.py:131-146) -- as a post-pass on the frames the last dtsim_render made: `lines` = [n][9] floats, world-space segment
