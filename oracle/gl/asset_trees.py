@@ -43,7 +43,8 @@ def tree(name: str) -> str:
     for m, md in assets.MAPS.items():
         with open(os.path.join(base, "maps", f"{m}.yaml"), "w") as f:
             yaml.safe_dump(md, f)
-    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(os.path.join(base, "textures", "black_tile.png")) if os.makedirs(os.path.join(base, "textures"), exist_ok=True) is None else None   # objmesh.py:285: the texture untextured chunks get in the segmentation view
+    os.makedirs(os.path.join(base, "textures"), exist_ok=True)
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(os.path.join(base, "textures", "black_tile.png"))   # objmesh.py:285: what untextured chunks are given in the segmentation view
     if name == "t128":
         shutil.copytree(os.path.join(ASSETS, "textures"), os.path.join(base, "textures"), dirs_exist_ok=True)
     elif name == "t256":

@@ -181,7 +181,8 @@ def build(name):
     elif kw.get("poses") == "town2":
         kw["poses"] = town_poses()[:2]
     meta = {k: v for k, v in CASES[name][1].items() if k not in ("poses",)}
-    kw.pop("dr", None) if fn is case_views else None
+    if fn is case_views:
+        kw.pop("dr")                                    # (carried for the meta record only: the views are rendered without domain randomisation)
     recs = fn(**kw)
     meta["renderer"] = refgl.glshim.renderer()
     out = _stack(recs)
