@@ -90,3 +90,22 @@ def test_gl_port_reproduces_the_reference_s_frames(case):
                        cam_fov_y_deg=float(d["cam_fov_y"][k]), camera_noise=d["camera_noise"][k], domain_rand=bool(d["meta"]["dr"]),
                        horizon=d["horizon"][k], ground=d["ground"][k], obj_states=G.obj_states(d, k))
         assert np.array_equal(got, d["frame"][k]), (case, k, G.stats(got, d["frame"][k]))
+
+
+@pytest.mark.parametrize("case", ["small_loop_dr_t256_160", "episode2_t256_160", "town_t128_320", "view_bbox_t256_320"])
+def test_committed_goldens_are_what_the_recipe_produces(case):
+    """Build container only (needs /root/reference): oracle/make_gl_golden.py re-run NOW -- the unmodified reference on llvmpipe -- gives the
+    committed frames and states byte for byte.  (The goldens are data produced by a committed recipe, not hand-edited; and llvmpipe with
+    LP_NUM_THREADS=1 is deterministic.)"""
+    from oracle.gl import refgl
+    if not refgl.available():
+        pytest.skip("reference tree or swrast driver not present")
+    import warnings
+    from oracle import make_gl_golden as MG
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fresh = MG.build(case)
+    d = G.load(case)
+    for key in fresh:
+        if key != "meta":
+            assert np.array_equal(np.asarray(fresh[key]), d[key]), (case, key)
