@@ -136,6 +136,33 @@ def case_views(map_name, tree, W, H, seeds, view):
     return recs
 
 
+def case_trajectory(map_name, tree, dr, W, H, seed, n_steps, keep):
+    """The reference's DuckietownEnv driven for `n_steps` with random (vel, steer) actions: per step the pose, reward and done flag its own step()
+    returns (lane pose, collision, reward, done: the reference's code; the DB18 integrator: oracle/sim.py's restatement, see oracle/gl/refgl.py),
+    and the observation of the steps in `keep` with the state that produced it.  Record k of the frame arrays is step keep[k] (0 = the reset frame)."""
+    env, ns = refgl.make_simulator(map_name, asset_trees.roots(tree), env_class="DuckietownEnv", domain_rand=dr, seed=seed, camera_width=W, camera_height=H,
+                                   max_steps=100000, distortion=False)
+    rng = np.random.default_rng(seed + 77)
+    actions = rng.uniform(-1, 1, (n_steps, 2))
+    actions[:, 0] = np.abs(actions[:, 0]) * 0.6 + 0.2            # forward, so that the robot leaves the spawn tile
+    recs = [snapshot(env, ns, env.render_obs())] if 0 in keep else []
+    traj = dict(pos=[], angle=[], reward=[], done=[], speed=[])
+    for t in range(n_steps):
+        obs, reward, done, _info = env.step(actions[t])
+        traj["pos"].append(np.asarray(env.cur_pos, dtype=np.float64)); traj["angle"].append(float(env.cur_angle))
+        traj["reward"].append(float(reward)); traj["done"].append(bool(done)); traj["speed"].append(float(env.speed))
+        if (t + 1) in keep:
+            recs.append(snapshot(env, ns, obs))
+        if done:
+            break
+    out = recs
+    for r in out:
+        r["traj_actions"] = actions
+        for k_, v in traj.items():
+            r["traj_" + k_] = np.asarray(v)
+    return out
+
+
 def town_poses():
     """(x, z, angle) looking at each object of test_town from 0.45 m, as tests/test_gpu_render.py places its envs."""
     import yaml
@@ -168,6 +195,8 @@ CASES = {
     #  .integers -- does not have: AttributeError in the reference itself; no golden)
     "view_top_down_t256_800": (case_views, dict(map_name="small_loop_only_duckies", tree="t256", W=800, H=600, seeds=[4, 5], view="top_down", dr=False)),
     "view_bbox_t256_320": (case_views, dict(map_name="small_loop_only_duckies", tree="t256", W=320, H=240, seeds=[4, 5, 6, 7], view="bbox", dr=False)),
+    "trajectory_t256_160": (case_trajectory, dict(map_name="small_loop_only_duckies", tree="t256", dr=False, W=160, H=120, seed=21, n_steps=80, keep=[0, 20, 40, 60, 80])),
+    "trajectory_dr_t256_160": (case_trajectory, dict(map_name="loop_only_duckies", tree="t256", dr=True, W=160, H=120, seed=22, n_steps=80, keep=[0, 20, 40, 60, 80])),
     "episode2_t256_160": (case_second_episode, dict(map_name="small_loop_only_duckies", tree="t256", dr=False, W=160, H=120, seed=9, n_steps=200, n_resets=4)),
     "episode2_dr_t256_160": (case_second_episode, dict(map_name="loop_only_duckies", tree="t256", dr=True, W=160, H=120, seed=11, n_steps=200, n_resets=4)),
 }
