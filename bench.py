@@ -350,7 +350,8 @@ def main():
     }[args.config]
     sim = BatchedSimulator(variant["maps"], N, domain_rand=variant["dr"], distortion=variant.get("distortion", True), camera_width=W, camera_height=H,
                            seed=1000 + rank * N, action_mode="vel_steer", auto_reset=True, profile=True,
-                           device=local_rank, do_reset=False, **variant["extra"])
+                           device=local_rank, do_reset=False, light_capture=bool(variant["dr"]),   # (DR: resets light the new episode as GL does; free)
+                           **variant["extra"])
     t_setup = time.perf_counter()
     sim.make_spawn_pool(N)                     # reference-order resets, geometry evaluated on the GPU
     sim.reset(states=sim._pool)                # start from the first pool entry of each env

@@ -188,6 +188,8 @@ StepParams step_params(const dtsim* h, int n_steps) {
   P.robot_speed = h->cfg.robot_speed;
   P.gain = h->cfg.gain; P.trim = h->cfg.trim; P.radius = h->cfg.radius; P.k = h->cfg.k; P.limit = h->cfg.limit;
   P.lanes = h->step_lanes;
+  P.light_capture = (h->cfg.flags & DTSIM_F_LIGHT_CAPTURE) ? 1 : 0;
+  P.domain_rand = (h->cfg.flags & DTSIM_F_DOMAIN_RAND) ? 1 : 0;
   return P;
 }
 

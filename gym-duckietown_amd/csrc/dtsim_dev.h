@@ -88,6 +88,7 @@ struct StepParams {
   int32_t n_steps, frame_skip, max_steps, delay_steps;
   int32_t action_mode, actions_f64, auto_reset, n_pool;
   uint32_t step_flags;                  // DTSIM_STEP_*
+  int32_t light_capture, domain_rand;   // DTSIM_F_LIGHT_CAPTURE (device-side resets take the new light through the last frame's camera); DTSIM_F_DOMAIN_RAND (that camera carries its noise)
   int32_t lanes;                        // lanes of a wavefront that share one env in k_step (1, 2, 4, 8; physics.hip Coop)
   const dtsim_reset_sampler* sampler;   // device copy, or null: device-side reset sampling (N2)
   double delta_time, robot_speed;

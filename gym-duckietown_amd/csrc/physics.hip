@@ -518,6 +518,28 @@ __device__ inline void dyn_integrate(Dyn& q, double dt, double L_, double R_, do
   q.u = u; q.w = w;
 }
 
+// DTSIM_F_LIGHT_CAPTURE: the model-view the env's last frame left behind -- _render_img's Rx(cam_angle) T(0, 0, forward) LookAt (simulator.py:1758-1803) at the
+// pose the episode ended at -- as eye C, yaw (sa, ca), pitch (sth, cth); read BEFORE the reset overwrites the pose.  gl_light_to_eye of the gym facade, on the device.
+struct LightMV { double Cx, Cy, Cz, sa, ca, sth, cth; };
+__device__ inline LightMV light_mv(const SimArrays& A, int e, int domain_rand) {
+  const size_t N = A.N;
+  const double a = A.angle[e], sa = sin(a), ca = cos(a), th = (double)A.cam[1 * N + e];
+  double px = A.pos_x[e], py = 0.0, pz = A.pos_z[e];
+  if (domain_rand) { px += (double)A.cam[3 * N + e]; py += (double)A.cam[4 * N + e]; pz += (double)A.cam[5 * N + e]; }   // simulator.py:1768-1769
+  return LightMV{px + DT_CAMERA_FORWARD_DIST * ca, py + (double)A.cam[0 * N + e], pz - DT_CAMERA_FORWARD_DIST * sa, sa, ca, sin(th), cos(th)};
+}
+__device__ inline void light_through(const SimArrays& A, int e, const LightMV& mv) {   // the light apply_init just wrote -> eye space of `mv`
+  const size_t N = A.N;
+  const double w = (double)A.colors[15 * N + e];
+  double rx = (double)A.colors[12 * N + e], ry = (double)A.colors[13 * N + e], rz = (double)A.colors[14 * N + e];
+  if (w != 0.0) { rx = rx / w - mv.Cx; ry = ry / w - mv.Cy; rz = rz / w - mv.Cz; }
+  const double xla = rx * mv.sa + rz * mv.ca, zla = -(rx * mv.ca - rz * mv.sa);
+  A.colors[12 * N + e] = (float)xla;
+  A.colors[13 * N + e] = (float)(ry * mv.cth - zla * mv.sth);
+  A.colors[14 * N + e] = (float)(ry * mv.sth + zla * mv.cth);
+  A.colors[15 * N + e] = w != 0.0 ? 1.f : 0.f;
+}
+
 // Simulator.reset()'s hand-over of one env (simulator.py:740-755) from a host-drawn state.
 __device__ inline void apply_init(const SimArrays& A, const MapSet& M, int e, const dtsim_init_state& st,
                                   int delay_steps, const dtsim_reset_sampler* rs = nullptr) {
@@ -760,6 +782,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
     // ---- auto reset (DTSIM_F_AUTO_RESET): the caller's reset() after a done=True
     if (P.auto_reset && !pose_only && A.done[e]) {
       const int ep = A.episode[e] + 1;
+      const LightMV mv = light_mv(A, e, P.domain_rand);          // (the pose the episode ended at: what the last frame was drawn from)
       A.episode[e] = ep;
       if (SAMPLER) {                                 // device-side sampling (takes precedence over the pool)
         const int cur = A.map_id[e];
@@ -773,6 +796,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(SimArrays A, MapSet M, Step
         const long long slot = ((long long)e + (long long)ep * N) % P.n_pool;
         apply_init(A, M, e, pool[slot], P.delay_steps);
       }
+      if (P.light_capture) light_through(A, e, mv);
     }
     const int mid = A.map_id[e];
     const MapView m = map_view(blobs + M.blob_off[mid]);
@@ -877,6 +901,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, Ste
   if (mask != nullptr && !mask[e]) return;
   if (states == nullptr) {                           // device sampler (dtsim_reset(h, mask, NULL))
     const int ep = A.episode[e] + 1;
+    const bool had_frame = A.map_id[e] >= 0;          // (the env's very first reset: nothing drawn yet, the model-view is the identity)
+    const LightMV mv = had_frame ? light_mv(A, e, P.domain_rand) : LightMV{};
     A.episode[e] = ep;
     const int cur = A.map_id[e] < 0 ? (P.sampler->map_cycle ? e % M.n_maps : 0) : A.map_id[e];
     const bool reload = P.sampler->map_cycle == 2;
@@ -886,6 +912,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_reset(SimArrays A, MapSet M, Ste
     if (A.map_id[e] != nm || reload) { dtsim_init_state z{}; z.map_id = nm | (reload ? DTSIM_MAP_RELOAD : 0); z.wheel_dist = 0.102; apply_init(A, M, e, z, P.delay_steps, P.sampler); }
     const dtsim_init_state st = sample_init(A, M, blobs, *P.sampler, e, ep, nm);
     apply_init(A, M, e, st, P.delay_steps, P.sampler);
+    if (P.light_capture && had_frame) light_through(A, e, mv);
   } else
   apply_init(A, M, e, states[e], P.delay_steps);
   const int mid = A.map_id[e];

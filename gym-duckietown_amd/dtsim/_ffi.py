@@ -17,7 +17,7 @@ ABI_VERSION = 11
 OK, E_INVALID, E_HIP, E_NOGPU, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5
 MAX_MAPS, MAX_TILES, MAX_CURVES, MAX_STATIC, MAX_DYNAMIC, MAX_OBJECTS = 32, 1024, 1024, 56, 8, 64
 MAX_DELAY, MAX_TEXTURES, MAX_MESHES = 16, 96, 64
-F_RENDER, F_DISTORTION, F_DOMAIN_RAND, F_AUTO_RESET, F_ACTIONS_F64, F_PROFILE = 1, 2, 4, 8, 16, 32
+F_RENDER, F_DISTORTION, F_DOMAIN_RAND, F_AUTO_RESET, F_ACTIONS_F64, F_PROFILE, F_LIGHT_CAPTURE = 1, 2, 4, 8, 16, 32, 64
 ACTION_WHEELS, ACTION_VEL_STEER = 0, 1
 DONE_IN_PROGRESS, DONE_INVALID_POSE, DONE_MAX_STEPS = 0, 1, 2
 DONE_CODES = ["in-progress", "invalid-pose", "max-steps-reached"]  # simulator.py:1691,1699,1704

@@ -42,7 +42,7 @@ class BatchedSimulator:
                  map_cycle: bool = False, map_random: bool = False, transform_uses_width: bool = False,
                  map_data: Optional[dict] = None,
                  asset_root: Optional[str] = None, style: str = "photos", device_reset: bool = False,
-                 undistort: bool = False, per_env_camera: bool = False,
+                 undistort: bool = False, per_env_camera: bool = False, light_capture: bool = False,
                  do_reset: bool = True):
         self._lib = _ffi.load()
         self._h = C.c_void_p()
@@ -87,6 +87,12 @@ class BatchedSimulator:
                              "that this render path would apply)")
         flags |= _ffi.F_DOMAIN_RAND if (domain_rand or per_env_camera) else 0
         flags |= _ffi.F_AUTO_RESET if auto_reset else 0
+        # light_capture (DTSIM_F_LIGHT_CAPTURE): device-side resets take the new episode's light through the camera of the pose the previous
+        # episode ended at, as GL does with reset()'s glLightfv (simulator.py:565-584).  Only the per-env render path has a per-env light.
+        self.light_capture = bool(light_capture)
+        if self.light_capture and not domain_rand:
+            raise ValueError("light_capture needs domain_rand=True: the shared-camera render path lights every env alike (DESIGN.md section 5)")
+        flags |= _ffi.F_LIGHT_CAPTURE if self.light_capture else 0
         flags |= _ffi.F_ACTIONS_F64 if actions_f64 else 0
         flags |= _ffi.F_PROFILE if profile else 0
         cfg = _ffi.Config()

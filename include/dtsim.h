@@ -58,6 +58,12 @@ extern "C" {
 #define DTSIM_F_AUTO_RESET 8u    /* envs whose done flag is set restart from the spawn pool at the next step */
 #define DTSIM_F_ACTIONS_F64 16u  /* dtsim_step actions are double[...] instead of float[...] */
 #define DTSIM_F_PROFILE 32u      /* bracket every kernel launch with HIP events (dtsim_profile_read) */
+#define DTSIM_F_LIGHT_CAPTURE 64u /* (ABI v11) device-side resets -- DTSIM_F_AUTO_RESET and dtsim_reset(states = NULL) -- position the new episode's light as GL
+                                  * does: reset() calls glLightfv(GL_POSITION) with whatever model-view the LAST FRAME left (simulator.py:565-584), so from the
+                                  * second episode on the light given in the init state is taken through the camera of the pose the previous episode ended at
+                                  * (a direction is rotated, a position also translated) before it becomes the env's eye-space light.  Honoured by the per-env
+                                  * render path (DTSIM_F_DOMAIN_RAND); dtsim_reset(states) takes the light as given (the caller's business, as the gym facade
+                                  * does it on the host). */
 
 /* dtsim_config.action_mode */
 #define DTSIM_ACTION_WHEELS 0    /* Simulator.step: [left, right] duty, clipped to [-1,1] (simulator.py:1669-1672) */

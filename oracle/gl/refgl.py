@@ -272,4 +272,7 @@ def make_simulator(map_name: str, roots, *, env_class: str = "Simulator", **kw):
     with open(ns.state.assets.get_resource_path(f"{map_name}.yaml")) as f:
         ns.state.H = len(yaml.safe_load(f)["tiles"])
     cls = ns.simulator.Simulator if env_class == "Simulator" else ns.duckietown_env.DuckietownEnv
+    # the reference draws the domain-randomised parameters of its objects (TrafficLightObj's frequency and pattern, DuckiebotObj's gains) from
+    # numpy's GLOBAL generator (objects.py:180-228, 434-463), which nothing seeds: seed it here so that a recipe run is reproducible
+    np.random.seed(20_000 + int(kw.get("seed") or 0))
     return cls(map_name=map_name, **kw), ns

@@ -54,6 +54,7 @@ def snapshot(sim, ns, frame):
         camera_noise=np.asarray(rs["camera_noise"], dtype=np.float64) if dr else np.zeros(3),
         horizon=np.asarray(sim.horizon_color, dtype=np.float64)[:3], ground=np.asarray(sim.ground_color, dtype=np.float64)[:3],
         light_eye=np.asarray(light_eye(ns), dtype=np.float64),
+        light_raw=np.asarray((list(rs["light_pos"]) + [0.0]) if dr else [0.0, 3.0, 0.0, 1.0], dtype=np.float64),   # what reset() handed to glLightfv (a 3-vector under DR: w = 0)
         light_ambient=np.asarray(_gl_light(ns, "GL_AMBIENT"))[:3], light_diffuse=np.asarray(_gl_light(ns, "GL_DIFFUSE"))[:3],
         obj_pos=np.asarray([np.asarray(o.pos, dtype=np.float64) for o in objs]).reshape(len(objs), 3),
         obj_yrot=np.asarray([float(o.y_rot) for o in objs]), obj_visible=np.asarray([bool(o.visible) for o in objs]),

@@ -92,7 +92,7 @@ def test_gl_port_reproduces_the_reference_s_frames(case):
         assert np.array_equal(got, d["frame"][k]), (case, k, G.stats(got, d["frame"][k]))
 
 
-@pytest.mark.parametrize("case", ["small_loop_dr_t256_160", "episode2_t256_160", "town_t128_320", "view_bbox_t256_320"])
+@pytest.mark.parametrize("case", ["small_loop_dr_t256_160", "episode2_t256_160", "town_dr_t128_320", "view_bbox_t256_320"])
 def test_committed_goldens_are_what_the_recipe_produces(case):
     """Build container only (needs /root/reference): oracle/make_gl_golden.py re-run NOW -- the unmodified reference on llvmpipe -- gives the
     committed frames and states byte for byte.  (The goldens are data produced by a committed recipe, not hand-edited; and llvmpipe with

@@ -8,6 +8,8 @@ Tolerance vs Mesa 23.2.1 llvmpipe (DESIGN.md section 4 derives it; measured valu
   the HIP raster folds the lit factor into 8-bit weights and rounds once -> a +-1/255 difference on a fraction of the textured
   pixels, nothing systematic:  >= 99 % of pixels within +-1/255, <= 0.4 % beyond +-2/255, mean abs error <= 0.35 / 255.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,49 @@ def test_drop_in_env_follows_the_reference_s_trajectory(case):
         print(f"\n{case} step {step}: beyond +-1 {s['gt1']:.5f}, beyond +-2 {s['gt2']:.5f}, mean abs {s['mean']:.4f} / 255")
         assert s["gt1"] <= TOL["gt1"] and s["gt2"] <= TOL["gt2"] and s["mean"] <= TOL["mean"], (case, step, s)
     env.close()
+
+
+def test_device_side_light_capture_matches_gl():
+    """DTSIM_F_LIGHT_CAPTURE: the vector API's device-side resets position the new episode's light as GL does -- through the camera of the pose the
+    previous episode ended at.  The `episode2_dr` golden holds, per episode, the last frame before the reference's reset() and the first after it:
+    env j is put at the former's state, given a spawn pool whose entry carries the RAW light reset() handed to glLightfv, and auto-reset; the light the
+    device then holds must be GL's eye-space light (glGetLightfv) and the frame the reference's first frame of that episode."""
+    d = G.load("episode2_dr_t256_160")
+    m = d["meta"]
+    n = len(d["frame"]) // 2
+    before, after = list(range(0, 2 * n, 2)), list(range(1, 2 * n, 2))
+    sim = BatchedSimulator(m["map_name"], n, asset_root=asset_trees.tree(m["tree"]), camera_width=int(m["W"]), camera_height=int(m["H"]), distortion=False,
+                           domain_rand=True, seed=1, max_steps=1000000, auto_reset=True, light_capture=True)
+
+    def state(st, k, light):
+        st.pos[:] = [float(v) for v in d["pos"][k]]
+        st.angle = float(d["angle"][k])
+        st.cam_height, st.cam_angle_deg, st.cam_fov_y_deg = float(d["cam_height"][k]), float(d["cam_angle"][k]), float(d["cam_fov_y"][k])
+        st.camera_noise[:] = [float(v) for v in d["camera_noise"][k]]
+        st.horizon_color[:] = [float(v) for v in d["horizon"][k]]
+        st.ground_color[:] = [float(v) for v in d["ground"][k]]
+        st.light_pos[:] = [float(v) for v in light[k]]
+        st.light_ambient[:] = [float(v) for v in d["light_ambient"][k]]
+        st.light_diffuse[:] = [float(v) for v in d["light_diffuse"][k]]
+        return st
+
+    for j in range(n):
+        state(sim.init_states[j], before[j], d["light_eye"])                      # (dtsim_reset(states) takes the light as given: eye space)
+    sim.reset(states=sim.init_states)
+    pool = (_ffi.InitState * n)()
+    for j in range(n):
+        C.memmove(C.byref(pool[j]), C.byref(sim.init_states[j]), C.sizeof(_ffi.InitState))
+        state(pool[j], after[j], d["light_raw"])                                  # the new episode as reset() drew it: the light NOT yet through any model-view
+    _ffi.check(sim._lib, sim._lib.dtsim_set_spawn_pool(sim._h, pool, n))
+    sim.write(_ffi.FIELD_DONE, np.ones(n, np.uint8))
+    sim.step(np.zeros((1, n, 2), np.float32))                                    # auto-reset: env e, episode 1 -> pool slot (e + n) % n = e; then one step at rest
+    light = sim.read(_ffi.FIELD_COLORS)[:, 12:16]
+    want = d["light_eye"][after]
+    assert np.allclose(light, want, rtol=2e-6, atol=2e-4), (light, want)
+    assert not np.allclose(want[:, :3], d["light_raw"][after][:, :3], atol=1.0)   # (and it did move: this is not the raw light)
+    sim.render()
+    frames = sim.frames_host()
+    for j in range(n):
+        s = G.stats(frames[j], d["frame"][after[j]])
+        assert s["gt1"] <= TOL["gt1"] and s["gt2"] <= TOL["gt2"] and s["mean"] <= TOL["mean"], (j, s)
+    sim.close()
