@@ -1688,6 +1688,12 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         // QE_ALWAYS_EDGE (k_raster_v3, round 4): the pixel can never be a one-ray pixel (horizon band, near / far limits): it goes to
         // the list without the interior test -- and without its loads when the whole batch is such (these entries come in runs)
         tagged[u] = (ent & QE_ALWAYS_EDGE) != 0u;
+#ifndef DT_Q_V3_PHASE1                                // (A/B aid: -DDT_Q_V3_PHASE1 restores the interior test for k_raster_v3's entries)
+        // k_raster_v3 (round 6): NO interior test -- every entry takes the four samples.  The test resolved 30 % of the entries with one record but cost
+        // as much as the four-sample phase (a table gather, a record gather and two patches per entry, latency-bound): without it the exact path is
+        // 0.10 ms shorter (profiles/r06_variants_ab.txt block E); an interior pixel's four samples give the one-ray colour anyway.
+        if (V3) tagged[u] = true;
+#endif
         skip[u] = !__ballot(have[u] && !tagged[u]);    // wave-uniform
         const int lp = (int)(ent & 255u);
         pix[u] = (wave_y0 + ry + lp / WWc) * R.W + tile_x0 + rx + lp % WWc;
