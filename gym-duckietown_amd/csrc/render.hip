@@ -1767,22 +1767,40 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       }
     return n_list;
   };
+#ifdef DT_Q_V3_PHASE1
+  constexpr bool DIRECT = false;
+#else
+  constexpr bool DIRECT = V3 && !POOL;                 // k_raster_v3 (round 6): the queue entries ARE the list -- no interior test, no compaction, no LDS round trip
+#endif
   for (int r0 = 0; r0 < n; r0 += RQ_LIST) {          // wave-uniform: rounds of up to RQ_LIST entries
     const int rem = n - r0;
-    const int n_list = rem > 128 ? phase1(std::integral_constant<int, 4>{}, r0)
-                     : rem > 64 ? phase1(std::integral_constant<int, 2>{}, r0) : phase1(std::integral_constant<int, 1>{}, r0);
-    // ---- phase 2: the four samples of the listed pixels, on dense lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int n_list;
+    if constexpr (DIRECT) n_list = min(rem, RQ_LIST);
+    else {
+      n_list = rem > 128 ? phase1(std::integral_constant<int, 4>{}, r0)
+             : rem > 64 ? phase1(std::integral_constant<int, 2>{}, r0) : phase1(std::integral_constant<int, 1>{}, r0);
+      // ---- phase 2: the four samples of the listed pixels, on dense lanes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 #ifdef DT_Q_ABL_NOPHASE2
     for (int l0 = 0; l0 < 0; l0 += 64) {
 #else
     for (int l0 = 0; l0 < n_list; l0 += 64) {          // wave-uniform
 #endif
       const bool have = l0 + lane < n_list;
-      const uint32_t le = have ? w_list[l0 + lane] : 0u;
-      const int pix = (int)(le & 0xFFFFFFu), el = (int)(le >> 24);
+      int pix, el;
+      if constexpr (DIRECT) {
+        // the entries were written by this wavefront a moment ago: bypass the (possibly stale) L1 line
+        const uint32_t ent = have ? (uint32_t)__builtin_nontemporal_load(w_queue + r0 + l0 + lane) : 0u;
+        const int lp = (int)(ent & 255u);
+        el = (int)((ent >> 8) & 63u);
+        pix = have ? (wave_y0 + lp / WWc) * R.W + tile_x0 + lp % WWc : 0;
+      } else {
+        const uint32_t le = have ? w_list[l0 + lane] : 0u;
+        pix = (int)(le & 0xFFFFFFu); el = (int)(le >> 24);
+      }
 #ifdef DT_ABL_P2_NOSAMPTAB                             // ablation (wrong frames): what phase 2's per-entry table gathers cost
       SampTab sp = samptab[lane];
 #else
