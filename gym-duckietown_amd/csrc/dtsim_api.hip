@@ -613,7 +613,7 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     const uint32_t special[8] = {0u, 0u, 0u, 1u << 16, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};   // untextured: white vertex colour
     qblocks.assign(special, special + 8);
     const size_t block_bytes = (size_t)S * S * 16;
-    const uint32_t cell_sel = (qlog2 == 8) ? 0x0c0c0400u : (uint32_t)(S * S - 1);   // v_perm selector (S = 256) / cell mask
+    const uint32_t cell_sel = (qlog2 == 8) ? 0x0c0c0501u : (uint32_t)(S * S - 1);   // v_perm selector (S = 256: the cell bytes of the snapped coordinates' bit patterns, render.hip Q8_SNAP) / cell mask
     const uint32_t zero_sel = (qlog2 == 8) ? 0x0c0c0c0cu : 0u;
     int n_blocks = 0;
     for (int mi = 0; mi < n_maps; ++mi) {
@@ -640,6 +640,8 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
         }
     }
     if (32 + (size_t)n_blocks * block_bytes >= ((size_t)1 << 32)) qlog2 = -1;   // 32-bit block offsets
+    for (int mi = 0; mi < n_maps; ++mi)                                           // quad coordinates below 32768 (render.hip, Q8_SNAP): else the generic raster
+      if ((size_t)(std::max(maps[mi].grid_w, maps[mi].grid_h) + 2 * DT_QRING) * S >= 32768) qlog2 = -1;
   }
   M.total_words = (int32_t)blobs.size();
   if ((size_t)M.total_words * 8 > 60000)

@@ -1572,25 +1572,39 @@ __device__ inline float med3f(float x, float lo, float hi) { return __builtin_am
 // where it is the same for the three channels (shared camera), times 256, rounded to bytes (v_cvt_pk_u8_f32); colour =
 // (sum(texel * weight) + 128) >> 8.  Measured against the GL goldens it differs from llvmpipe by +-1/255 on about a quarter of the
 // textured pixels -- what the 16-bit filter it replaces did too (tests/test_gl_golden.py::test_quad_filter_distance_to_gl).
-// I256 = 256 * lit (256 for an unlit filter).  Byte order = the record's texel order: (x0,z0) (x1,z0) (x0,z1) (x1,z1).
-__device__ inline uint32_t quad_weights8(float ax, float az, float I256) {
-  const float u = ax * I256, v = I256 - u;
-  const float w11 = u * az, w01 = v * az, w10 = u - w11, w00 = v - w01;
+// The texture coordinate itself is snapped to 256ths of a texel first -- llvmpipe rounds its coordinates to 8 fractional bits before it
+// splits them into texel index and weight (gl_linear_rgb above) -- by ONE float add: X + 32768 (X in quad cells, 0 <= X < 32768; the host
+// checks the padded grid against it) rounds X to a multiple of 1/256 and leaves it in the sum's bit pattern: byte 0 = the fraction in
+// 256ths, bits 8..22 = the cell number (S = 256: byte 1 = the cell inside the tile, byte 2 = the tile).  A fraction that rounds up to 1
+// carries into the cell number, as in GL.  The hot loops take everything from these bits -- no v_cvt_flr, no v_fract.
+#define Q8_SNAP 32768.f
+#define Q8_LIT (1.f / 256.f)                         // the weights' light argument is lit / 256 (the fractions come as 0..255)
+__device__ inline uint32_t q8_bits(float X) { return __float_as_uint(X + Q8_SNAP); }
+__device__ inline uint32_t q8_cell(uint32_t b) { return (b >> 8) & 0x7FFFu; }      // the cell number (one v_bfe_u32)
+__device__ inline float q8_frac(uint32_t b) { return (float)(b & 255u); }          // the fraction x 256 (one v_cvt_f32_ubyte0)
+// a8, b8: the fractions x 256 (0..255); l = lit / 256 (1 / 256 for an unlit filter).  Byte order = the record's texel order:
+// (x0,z0) (x1,z0) (x0,z1) (x1,z1).  (The packed forms in the env loops of k_raster_q / k_raster_v3 are these operations, two pixels each.)
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ inline f2_t fma2(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }   // one v_pk_fma_f32, whatever the contraction mode
+__device__ inline uint32_t quad_weights8(float a8, float b8, float l) {
+#pragma clang fp contract(off)                       // which products are fused is part of the definition (the oracle restates it): u and the w*1 are rounded products
+  const float u = a8 * l, v = fmaf(l, 256.f, -u);
+  const float w11 = u * b8, w01 = v * b8, w10 = fmaf(u, 256.f, -w11), w00 = fmaf(v, 256.f, -w01);
   uint32_t W = __builtin_amdgcn_cvt_pk_u8_f32(w00, 0, 0u);
   W = __builtin_amdgcn_cvt_pk_u8_f32(w10, 1, W);
   W = __builtin_amdgcn_cvt_pk_u8_f32(w01, 2, W);
   return __builtin_amdgcn_cvt_pk_u8_f32(w11, 3, W);
 }
-// one-ray colour 0x00BBGGRR of a record (I = lit factor, 0..1)
-__device__ inline uint32_t quad_filter(const uint4& q, float ax, float az, float I) {
-  const uint32_t W = quad_weights8(ax, az, I * 256.f);
+// one-ray colour 0x00BBGGRR of a record (a8, b8 as above; I = lit factor, 0..1)
+__device__ inline uint32_t quad_filter(const uint4& q, float a8, float b8, float I) {
+  const uint32_t W = quad_weights8(a8, b8, I * Q8_LIT);
   const uint32_t vr = __builtin_amdgcn_udot4(q.x, W, 128u, false), vg = __builtin_amdgcn_udot4(q.y, W, 128u, false),
                  vb = __builtin_amdgcn_udot4(q.z, W, 128u, false);                 // the channel is byte 1 of each sum
   const uint32_t rg = __builtin_amdgcn_perm(vg, vr, 0x0c0c0501u);
   return __builtin_amdgcn_perm(vb, rg, 0x0c050100u);
 }
-__device__ inline void quad_filter3(const uint4& q, float ax, float az, float I, float out[3]) {   // 0..255 floats, unrounded
-  const uint32_t W = quad_weights8(ax, az, I * 256.f);
+__device__ inline void quad_filter3(const uint4& q, float a8, float b8, float I, float out[3]) {   // 0..255 floats, unrounded
+  const uint32_t W = quad_weights8(a8, b8, I * Q8_LIT);
   out[0] = (float)__builtin_amdgcn_udot4(q.x, W, 0u, false) * (1.f / 256.f);
   out[1] = (float)__builtin_amdgcn_udot4(q.y, W, 0u, false) * (1.f / 256.f);
   out[2] = (float)__builtin_amdgcn_udot4(q.z, W, 0u, false) * (1.f / 256.f);
@@ -1637,12 +1651,11 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
     ta = (ti << 3) + __umul24(tj, pitch4) + tab_b;
     return *reinterpret_cast<const uint2*>(qtb + ta);
   };
-  // quad record of block entry `te` at the cell the (unclamped) coordinates fall into, wrapped into the tile
-  auto tile_quad = [&](const uint2 te, float X, float Z) -> uint4 {
-    const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
+  // quad record of block entry `te` at the cell of the snapped (unclamped) coordinates xb, zb (q8_bits), wrapped into the tile
+  auto tile_quad = [&](const uint2 te, const uint32_t xb, const uint32_t zb) -> uint4 {
     uint32_t local;
-    if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);
-    else local = (((zi & SM) << LS) | (xi & SM)) & te.y;
+    if (S256) local = __builtin_amdgcn_perm(zb, xb, te.y);
+    else local = (((q8_cell(zb) & SM) << LS) | (q8_cell(xb) & SM)) & te.y;
     return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
   };
   auto store_rgb = [&](int e, int pix, uint32_t rgb) {
@@ -1745,15 +1758,15 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       uint4 qc[U];
 #pragma unroll
 #ifdef DT_Q_P1_LOAD_ALL                                // A/B aid (round 5 behaviour): every lane gathers its record, interior or not
-      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u]) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]); }   // always in bounds (record 0 / 1 for non-tiles)
+      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u]) qc[u] = tile_quad(te_c[u], q8_bits(Xu[u]), q8_bits(Zu[u])); }   // always in bounds (record 0 / 1 for non-tiles)
 #else
       // only the INTERIOR entries (~ 30 %) use the record: the gather runs under their lanes -- its cost on the texture path is per distinct line
-      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u] && interior[u]) qc[u] = tile_quad(te_c[u], Xu[u], Zu[u]); }
+      for (int u = 0; u < U; ++u) { qc[u] = make_uint4(0u, 0u, 0u, 0u); if (!skip[u] && interior[u]) qc[u] = tile_quad(te_c[u], q8_bits(Xu[u]), q8_bits(Zu[u])); }
 #endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!skip[u]) {                                // wave-uniform
-          const uint32_t rgb = quad_filter(qc[u], __builtin_amdgcn_fractf(Xu[u]), __builtin_amdgcn_fractf(Zu[u]), pt[u].lit);
+          const uint32_t rgb = quad_filter(qc[u], q8_frac(q8_bits(Xu[u])), q8_frac(q8_bits(Zu[u])), pt[u].lit);
 #ifdef DT_ABL_P1_NOSTORE
           if (interior[u] && rgb == 0x12345678u) store_rgb(env[u], pix[u], rgb);
 #else
@@ -1838,10 +1851,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const float qpm = __uint_as_float(qd.w);                           // quad cells per metre of the env's map
         const float goff = (float)DT_QRING * Sf + 0.5f, ghalf = GROUND_HALF * qpm;   // world 0 and 50 m in padded quad coordinates
         const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
-        const uint32_t xic = (uint32_t)flr_i32(Xu), zic = (uint32_t)flr_i32(Zu);
-        const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
+        const uint32_t xic = q8_bits(Xu), zic = q8_bits(Zu);              // the centre's snapped coordinates: the cell selectors work on these bits
         const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
-        const uint32_t W8 = quad_weights8(ax, az, lit * 256.f);
+        const uint32_t W8 = quad_weights8(q8_frac(xic), q8_frac(zic), lit * Q8_LIT);
         uint32_t aS[3] = {0u, 0u, 0u};                 // sum over the samples of the byte-weight filter of each sample's record
         int n_sky = 0, n_gnd = 0;
         float gX = 0.f, gZ = 0.f;                      // ground hit (quad coordinates) of the lowest-index ground sample
@@ -1909,7 +1921,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
       const float wCx = c->Cx, wCy = c->Cy, wCz = c->Cz, sa = c->sa, ca = c->ca;
       const float kg = (wCy - GROUND_Y) / wCy;
       const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
-      const float ax = __builtin_amdgcn_fractf(Xu), az = __builtin_amdgcn_fractf(Zu);
+      const uint32_t xub = q8_bits(Xu), zub = q8_bits(Zu);
+      const float ax = q8_frac(xub), az = q8_frac(zub);
       const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
       // coverage: per sample tile (tile plane hit within [near, far] on a present tile), else ground quad, else clear colour
       uint32_t key[4];                                 // 0 sky, 1 ground, else 2 + table address of the tile
@@ -1960,7 +1973,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         int cnt = 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) { const bool same = ((todo >> s) & 1u) && key[s] == k0; cnt += same; todo &= same ? ~(1u << s) : ~0u; }
-        const uint4 qt = tile_quad(t0, Xu, Zu);
+        const uint4 qt = tile_quad(t0, xub, zub);
         float col[3];
         quad_filter3(qt, ax, az, lit, col);
 #pragma unroll
@@ -2179,34 +2192,35 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
   struct QStage { uint4 q[PPT]; f2 ax2[PPT / 2], az2[PPT / 2]; };
   auto issue_t = [&](const EnvQ& f, QStage& st, auto clamp_tag) __attribute__((always_inline)) {
     constexpr bool CLAMP = decltype(clamp_tag)::value;
-    const f2 vA = f2{f.A, f.A}, vB = f2{f.B, f.B}, vCx = f2{f.Cx, f.Cx}, vCz = f2{f.Cz, f.Cz};
+    const f2 vA = f2{f.A, f.A}, vB = f2{f.B, f.B}, vCx = f2{f.Cx, f.Cx}, vCz = f2{f.Cz, f.Cz}, vK = f2{Q8_SNAP, Q8_SNAP};
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
       // two pixels per packed op: X = Cx + lr*A + lf*B, Z = Cz + lr*B - lf*A
-      const f2 X2 = lf2[j] * vB + (lr2[j] * vA + vCx);
-      const f2 Z2 = lr2[j] * vB + (vCz - lf2[j] * vA);
+      // (+ Q8_SNAP as a third, separate add: ONE rounding to 256ths of a texel; the sum's bits are the fixed-point coordinate, see quad_weights8)
+      const f2 X2 = fma2(lf2[j], vB, fma2(lr2[j], vA, vCx)) + vK;       // (explicit fused multiply-adds in resolve_region's order: the snap makes the last bit visible)
+      const f2 Z2 = fma2(lf2[j], -vA, fma2(lr2[j], vB, vCz)) + vK;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 2 * j + h;
         float X = h ? X2.y : X2.x, Z = h ? Z2.y : Z2.x;
-        if (CLAMP) { X = med3f(X, lo, f.Xhi); Z = med3f(Z, lo, f.Zhi); }
-        const uint32_t xi = (uint32_t)flr_i32(X), zi = (uint32_t)flr_i32(Z);
-        if (h) { st.ax2[j].y = __builtin_amdgcn_fractf(X); st.az2[j].y = __builtin_amdgcn_fractf(Z); }
-        else { st.ax2[j].x = __builtin_amdgcn_fractf(X); st.az2[j].x = __builtin_amdgcn_fractf(Z); }
+        if (CLAMP) { X = med3f(X, lo + Q8_SNAP, f.Xhi + Q8_SNAP); Z = med3f(Z, lo + Q8_SNAP, f.Zhi + Q8_SNAP); }
+        const uint32_t xb = __float_as_uint(X), zb = __float_as_uint(Z);
+        if (h) { st.ax2[j].y = q8_frac(xb); st.az2[j].y = q8_frac(zb); }
+        else { st.ax2[j].x = q8_frac(xb); st.az2[j].x = q8_frac(zb); }
         // block offset of the cell's tile: LDS table, byte address = tab_b + (zi >> LS) * pitch4 + ((xi >> LS) << 2)
         // The table entry is 8 bytes: the block's byte offset and how the cell index is formed -- for the two
         // one-record blocks (off-grid, untextured) every cell maps to record 0, so they do not occupy cache lines.
         uint32_t ta, local;
-        if (S256) {   // S = 256 and a padded grid under 256 tiles: tile = byte 1, cell = byte 0 of the coordinate
+        if (S256) {   // S = 256 and a padded grid under 128 tiles: tile = byte 2, cell = byte 1 of the snapped coordinate
           uint32_t t1, t2;
-          asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t1) : "v"(zi), "s"(f.pitch4));
-          asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t2) : "v"(xi));
+          asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(t1) : "v"(zb), "s"(f.pitch4));
+          asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t2) : "v"(xb));
           ta = t1 + t2 + f.tab_b;
-        } else ta = ((xi >> LS) << 3) + (__umul24(zi >> LS, f.pitch4) + f.tab_b);
+        } else ta = ((q8_cell(xb) >> LS) << 3) + (__umul24(q8_cell(zb) >> LS, f.pitch4) + f.tab_b);
         const uint2 te = *reinterpret_cast<const uint2*>(s_qtb + ta);
         const uint32_t tb = te.x;
-        if (S256) local = __builtin_amdgcn_perm(zi, xi, te.y);                 // te.y: v_perm selector (z0 << 8) | x0, or 0
-        else local = (((zi & SM) << LS) | (xi & SM)) & te.y;                   // te.y: cell mask
+        if (S256) local = __builtin_amdgcn_perm(zb, xb, te.y);                 // te.y: v_perm selector (cell byte of z) << 8 | cell byte of x, or 0
+        else local = (((q8_cell(zb) & SM) << LS) | (q8_cell(xb) & SM)) & te.y; // te.y: cell mask
 #ifdef DT_Q_NO_LOAD
         st.q[k] = make_uint4(tb + local, tb ^ local, local, 0x00000080u);
 #elif 0
@@ -2259,11 +2273,15 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
 #pragma unroll
     for (int j = 0; j < PPT / 2; ++j) {
       if (j) __builtin_amdgcn_sched_barrier(0);      // one pixel pair at a time: fewer live temporaries
-      // bilinear weights with the lit factor folded in (x 256: the byte weights of quad_weights8), two pixels per packed op
-      const f2 I2 = lit2[j] * 256.f;
-      const f2 u = ax2[j] * I2, v = I2 - u;
-      const f2 w11 = u * az2[j], w01 = v * az2[j];
-      const f2 w10 = u - w11, w00 = v - w01;
+      // bilinear weights with the lit factor folded in (quad_weights8's operations: fractions in 256ths, lit / 256), two pixels per packed op
+      f2 w00, w10, w01, w11;
+      {
+#pragma clang fp contract(off)
+        const f2 I2 = lit2[j] * Q8_LIT, c256 = f2{256.f, 256.f};
+        const f2 u = ax2[j] * I2, v = fma2(I2, c256, -u);
+        w11 = u * az2[j]; w01 = v * az2[j];
+        w10 = fma2(u, c256, -w11); w00 = fma2(v, c256, -w01);
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 2 * j + h;

@@ -154,31 +154,34 @@ def _exact_linear(tex, u, v):
 
 def _dtsim8_shade(tex, u, v, I, folded):
     """Tile colour (0..255 float, unrounded) of the product's quad-record pipeline (csrc/render.hip quad_weights8 / quad_filter,
-    DESIGN.md section 5): ONE multiply-accumulate per texel and channel at the precision GL's own filter has -- the four
-    bilinear weights, times 256, rounded to bytes (float32 arithmetic, round-to-nearest-even as v_cvt_pk_u8_f32 does);
-    sum(texel * weight) / 256.  `folded` (shared camera, k_raster_v3 / k_raster_q: the lit factor I [...,3] is the same for the
-    three channels): it is folded into the weights; otherwise (k_raster_v3dr: per-env, per-channel light) the weights are unlit
-    and the sum is multiplied by I.
+    DESIGN.md section 5), at the precision GL's own filter has:
+      * the texel coordinate is rounded to 256ths of a texel first (round-to-nearest-even: the product's one float add X + 32768),
+        as llvmpipe rounds its own (_gl_linear); the integer part addresses the texels -- a fraction that rounds up to 1 carries;
+      * ONE multiply-accumulate per texel and channel: the four bilinear weights, times 256, rounded to bytes (float32 arithmetic
+        in the product's order of operations, round-to-nearest-even as v_cvt_pk_u8_f32 does); sum(texel * weight) / 256.
+    `folded` (shared camera, k_raster_v3 / k_raster_q: the lit factor I [...,3] is the same for the three channels): it is folded
+    into the weights; otherwise (k_raster_v3dr: per-env, per-channel light) the weights are unlit and the sum is multiplied by I.
     Not llvmpipe's arithmetic (which rounds to 8 bits between its two lerps): it differs from _gl_linear(...) * I by +-1/255 on
     about a quarter of the textured pixels, never systematically (tests/test_gl_golden.py measures it on the GL frames)."""
     h, w = tex.shape[:2]
-    f32 = np.float32
-    x = np.asarray(u, dtype=np.float64) * w - 0.5
-    y = np.asarray(v, dtype=np.float64) * h - 0.5
-    x0f, y0f = np.floor(x), np.floor(y)
-    ax, az = (x - x0f).astype(f32), (y - y0f).astype(f32)
+    f32, f64 = np.float32, np.float64
+    xq = np.rint((np.asarray(u, dtype=f64) * w - 0.5) * 256.0)
+    yq = np.rint((np.asarray(v, dtype=f64) * h - 0.5) * 256.0)
+    x0f, y0f = np.floor(xq / 256.0), np.floor(yq / 256.0)
+    a8, b8 = (xq - 256.0 * x0f).astype(f32), (yq - 256.0 * y0f).astype(f32)      # the fractions x 256: 0..255
     x0, y0 = x0f.astype(np.int64) % w, y0f.astype(np.int64) % h
     x1, y1 = (x0 + 1) % w, (y0 + 1) % h
-    I = np.asarray(I, dtype=np.float64)
-    I256 = (I[..., 0].astype(f32) * f32(256)) if folded else np.full(ax.shape, 256, f32)
-    uu = ax * I256
-    vv = I256 - uu
-    w11, w01 = uu * az, vv * az
-    w10, w00 = uu - w11, vv - w01
+    I = np.asarray(I, dtype=f64)
+    l = (I[..., 0].astype(f32) * f32(1.0 / 256.0)) if folded else np.full(a8.shape, 1.0 / 256.0, f32)
+    fma = lambda a, b, c: (a.astype(f64) * f64(b) + c.astype(f64)).astype(f32)      # float32 fused multiply-add (the product is exact in float64)
+    uu = a8 * l
+    vv = fma(l, 256.0, -uu)
+    w11, w01 = uu * b8, vv * b8
+    w10, w00 = fma(uu, 256.0, -w11), fma(vv, 256.0, -w01)
     W = [np.clip(np.rint(wgt), 0, 255).astype(np.int64)[..., None] for wgt in (w00, w10, w01, w11)]
     t = tex[..., :3].astype(np.int64)
     S = t[y0, x0] * W[0] + t[y0, x1] * W[1] + t[y1, x0] * W[2] + t[y1, x1] * W[3]
-    out = S.astype(np.float64) / 256.0
+    out = S.astype(f64) / 256.0
     return out if folded else out * I
 
 
