@@ -457,7 +457,10 @@ static void build_quad_block(std::vector<uint32_t>& out, const uint32_t* pool, i
   for (int z0 = 0; z0 < S; ++z0)
     for (int x0 = 0; x0 < S; ++x0) {
       const uint32_t t00 = texel(x0 - 1, z0 - 1), t10 = texel(x0, z0 - 1), t01 = texel(x0 - 1, z0), t11 = texel(x0, z0);
-      uint32_t* q = &out[base + ((size_t)z0 * S + x0) * 4];
+      // S = 256: 4 x 2 cells per 128-byte line -- record number (x0 >> 2) << 10 | z0 << 2 | (x0 & 3) (render.hip, q8_rec256: a 32 x 2 pixel slot of the
+      // raster touches ~ 15 % fewer lines than with the rows of the texture laid end to end); other sizes: row-major
+      const size_t rec = (S == 256) ? ((size_t)(x0 >> 2) << 10) | ((size_t)z0 << 2) | (size_t)(x0 & 3) : (size_t)z0 * S + x0;
+      uint32_t* q = &out[base + rec * 4];
       for (int c = 0; c < 3; ++c)
         q[c] = ((t00 >> (8 * c)) & 255u) | (((t10 >> (8 * c)) & 255u) << 8) | (((t01 >> (8 * c)) & 255u) << 16) | (((t11 >> (8 * c)) & 255u) << 24);
       q[3] = (uint32_t)std::min(std::min(std::min(x0, S - x0), std::min(z0, S - z0)), 0xFFFF);
@@ -613,8 +616,11 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
     const uint32_t special[8] = {0u, 0u, 0u, 1u << 16, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};   // untextured: white vertex colour
     qblocks.assign(special, special + 8);
     const size_t block_bytes = (size_t)S * S * 16;
-    const uint32_t cell_sel = (qlog2 == 8) ? 0x0c0c0501u : (uint32_t)(S * S - 1);   // v_perm selector (S = 256: the cell bytes of the snapped coordinates' bit patterns, render.hip Q8_SNAP) / cell mask
-    const uint32_t zero_sel = (qlog2 == 8) ? 0x0c0c0c0cu : 0u;
+    // second dword of a table entry: the mask of the record's byte offset inside its block (S = 256, q8_rec256) / of the cell number (other sizes): 0 for the
+    // two one-record blocks.  S = 256: the blocks start at multiples of 1 MB (the offset is OR-ed in), the first one holds the two special records only.
+    const uint32_t cell_sel = (qlog2 == 8) ? 0xFFFFFu : (uint32_t)(S * S - 1);
+    const uint32_t zero_sel = 0u;
+    if (qlog2 == 8) qblocks.resize(block_bytes / 4, 0u);
     int n_blocks = 0;
     for (int mi = 0; mi < n_maps; ++mi) {
       const dtsim_map& mp = maps[mi];
@@ -632,14 +638,14 @@ int dtsim_set_maps(dtsim_t* h, const dtsim_map* maps, int n_maps) {
               else {
                 int& b = block_of[(size_t)tx * 4 + (mp.tile_angle[t] & 3)];
                 if (b < 0) { b = n_blocks++; build_quad_block(qblocks, h->h_pool.data() + h->h_tex[tx].off, S, mp.tile_angle[t] & 3); }
-                off = (uint32_t)(32 + (size_t)b * block_bytes); sel = cell_sel;
+                off = (qlog2 == 8) ? (uint32_t)((size_t)(b + 1) << 20) : (uint32_t)(32 + (size_t)b * block_bytes); sel = cell_sel;
               }
             }
           }
           qtiles.push_back(off); qtiles.push_back(sel);
         }
     }
-    if (32 + (size_t)n_blocks * block_bytes >= ((size_t)1 << 32)) qlog2 = -1;   // 32-bit block offsets
+    if (32 + (size_t)(n_blocks + 1) * block_bytes >= ((size_t)1 << 32)) qlog2 = -1;   // 32-bit block offsets
     for (int mi = 0; mi < n_maps; ++mi)                                           // quad coordinates below 32768 (render.hip, Q8_SNAP): else the generic raster
       if ((size_t)(std::max(maps[mi].grid_w, maps[mi].grid_h) + 2 * DT_QRING) * S >= 32768) qlog2 = -1;
   }

@@ -1582,6 +1582,17 @@ __device__ inline float med3f(float x, float lo, float hi) { return __builtin_am
 __device__ inline uint32_t q8_bits(float X) { return __float_as_uint(X + Q8_SNAP); }
 __device__ inline uint32_t q8_cell(uint32_t b) { return (b >> 8) & 0x7FFFu; }      // the cell number (one v_bfe_u32)
 __device__ inline float q8_frac(uint32_t b) { return (float)(b & 255u); }          // the fraction x 256 (one v_cvt_f32_ubyte0)
+// Byte offset of the record of the cell of snapped coordinates (xb, zb) inside a 256 x 256 block, masked by the tile's table entry (0 for the
+// one-record blocks): the records lie 4 x 2 cells to a 128-byte line -- offset = (cx >> 2) << 14 | cz << 6 | (cx & 3) << 4 -- because the texture
+// unit charges a gather per distinct line, and the footprint of a 32 x 2 pixel slot is a slanted strip: 12.0 lines per gather instead of 14.0 with
+// the texture's rows laid end to end (tools/gather_lines_model.py; profiles/r06_variants_ab.txt block H).  cx * 0x1010 puts cx at bits 12.. and
+// 4..; cz (byte 1 of zb, shifted to bits 6..13) goes over the middle: 3 instructions + the v_and_or that masks and adds the block's offset.
+__device__ inline uint32_t q8_rec256(uint32_t xb, uint32_t zb, uint32_t m) {
+  uint32_t P, Zs;                                    // (the byte selects written out: the compiler's SDWA peephole finds them for some of the four pixels only)
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(P) : "v"(xb), "s"(0x1010u));
+  asm("v_lshlrev_b32_sdwa %0, 6, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(Zs) : "v"(zb));
+  return ((P & 0xFC030u) | Zs) & m;
+}
 // a8, b8: the fractions x 256 (0..255); l = lit / 256 (1 / 256 for an unlit filter).  Byte order = the record's texel order:
 // (x0,z0) (x1,z0) (x0,z1) (x1,z1).  (The packed forms in the env loops of k_raster_q / k_raster_v3 are these operations, two pixels each.)
 typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -1653,9 +1664,8 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   };
   // quad record of block entry `te` at the cell of the snapped (unclamped) coordinates xb, zb (q8_bits), wrapped into the tile
   auto tile_quad = [&](const uint2 te, const uint32_t xb, const uint32_t zb) -> uint4 {
-    uint32_t local;
-    if (S256) local = __builtin_amdgcn_perm(zb, xb, te.y);
-    else local = (((q8_cell(zb) & SM) << LS) | (q8_cell(xb) & SM)) & te.y;
+    if (S256) return *reinterpret_cast<const uint4*>(qtex + (te.x | q8_rec256(xb, zb, te.y)));
+    const uint32_t local = (((q8_cell(zb) & SM) << LS) | (q8_cell(xb) & SM)) & te.y;
     return *reinterpret_cast<const uint4*>(qtex + (te.x + (local << 4)));
   };
   auto store_rgb = [&](int e, int pix, uint32_t rgb) {
@@ -1878,10 +1888,9 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
           const bool is_gnd = have & !is_tile & (((sp.flags >> (4 + s)) & 1u) != 0u) & (fabsf(Xg - goff) <= ghalf) & (fabsf(Zg - goff) <= ghalf);
           n_gnd += is_gnd; n_sky += !(is_tile | is_gnd);
           if (is_gnd) { gX = Xg; gZ = Zg; }
-          const uint32_t cell = __builtin_amdgcn_perm(zic, xic, sel);
           // one record per DISTINCT tile among the pixel's samples (round 4: the path is texture-unit heavy, its gathers fully divergent;
           // the samples of most edge pixels share a tile, or are not on a tile at all): a lane loads only when its address changes
-          const uint32_t raddr = is_tile ? tb + (cell << 4) : 0u;
+          const uint32_t raddr = is_tile ? (tb | q8_rec256(xic, zic, sel)) : 0u;
           if (s == 3 || raddr != raddr_prev) rec = *reinterpret_cast<const uint4*>(qtex + raddr);
           raddr_prev = raddr;
           aS[0] = __builtin_amdgcn_udot4(rec.x, W8, aS[0], false);
@@ -2219,7 +2228,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
         } else ta = ((q8_cell(xb) >> LS) << 3) + (__umul24(q8_cell(zb) >> LS, f.pitch4) + f.tab_b);
         const uint2 te = *reinterpret_cast<const uint2*>(s_qtb + ta);
         const uint32_t tb = te.x;
-        if (S256) local = __builtin_amdgcn_perm(zb, xb, te.y);                 // te.y: v_perm selector (cell byte of z) << 8 | cell byte of x, or 0
+        if (S256) local = q8_rec256(xb, zb, te.y) >> 4;                        // te.y: mask of the record's byte offset (4 x 2 cells per line), or 0
         else local = (((q8_cell(zb) & SM) << LS) | (q8_cell(xb) & SM)) & te.y; // te.y: cell mask
 #ifdef DT_Q_NO_LOAD
         st.q[k] = make_uint4(tb + local, tb ^ local, local, 0x00000080u);

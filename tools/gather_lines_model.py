@@ -36,6 +36,7 @@ def line_ids(X, Z):
         "col": (tile * S + cx) * 32 + (cz >> 3),
         "t42": (tile * 128 + (cz >> 1)) * 64 + (cx >> 2),
         "t24": (tile * 64 + (cz >> 2)) * 128 + (cx >> 1),
+        "zmerge": (tile * S + (cz & ~1)) * 32 + (cx >> 3),        # ablation -DDT_ABL_ZMERGE (wrong frames): two texture rows share their records
     }
 
 
@@ -50,8 +51,9 @@ def main():
     ny = 1 - 2 * (sy + 0.5) / H
     rng = np.random.default_rng(5)
     ts = o.map.tile_size
-    tot = {k: 0.0 for k in ("row", "col", "best", "t42", "t24")}
+    tot = {k: 0.0 for k in ("row", "col", "best", "t42", "t24", "zmerge")}
     n_instr = 0
+    shapes = {}
     hist = {k: np.zeros(65) for k in ("row", "best", "t42")}
     for k in range(n):
         o.reset()
@@ -69,6 +71,14 @@ def main():
         X = np.clip(X, 0, 40 * S); Z = np.clip(Z, 0, 40 * S)
         ids = line_ids(X, Z)
         per = {}
+        for sw, sh in ((64, 1), (16, 4), (8, 8)):            # other slot shapes (not built): lines per gather under the shipped and the tiled layout
+            for name in ("row", "t42", "t24"):
+                b = ids[name].reshape(H // sh, sh, W // sw, sw).transpose(0, 2, 1, 3).reshape(-1, 64)
+                okb = ok.reshape(H // sh, sh, W // sw, sw).transpose(0, 2, 1, 3).reshape(-1, 64)
+                bs = np.sort(b[okb.all(1)], axis=1)
+                key = f"{name}@{sw}x{sh}"
+                shapes.setdefault(key, [0.0, 0])
+                shapes[key][0] += float((1 + (np.diff(bs, axis=1) != 0).sum(1)).sum()); shapes[key][1] += len(bs)
         for name, idv in ids.items():
             # slots: 32 x 2 pixel sub-blocks of the 128 x 2 wavefront block
             b = idv.reshape(H // 2, 2, W // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
@@ -87,6 +97,8 @@ def main():
     print(f"{n} poses, {n_instr} full 32 x 2 slots on the tile plane ({n_instr / n / (H // 2 * (W // 32)) * 100:.1f} % of the slots)")
     for name, v in tot.items():
         print(f"  {name:5s} {v / n_instr:6.2f} distinct lines per load instruction")
+    for key, (tot_l, cnt) in shapes.items():
+        print(f"  {key:12s} {tot_l / max(cnt, 1):6.2f} distinct lines per load instruction")
     for name, h in hist.items():
         c = np.cumsum(h) / h.sum()
         print(f"  {name:5s} share of instructions with <= 8 / 16 / 32 lines: {c[8]:.2f} / {c[16]:.2f} / {c[32]:.2f};  with 64: {h[64] / h.sum():.3f}")
