@@ -51,7 +51,8 @@ def main():
     ny = 1 - 2 * (sy + 0.5) / H
     rng = np.random.default_rng(5)
     ts = o.map.tile_size
-    tot = {k: 0.0 for k in ("row", "col", "best", "t42", "t24", "zmerge")}
+    tot = {k: 0.0 for k in ("row", "col", "best", "t42", "t24", "zmerge", "t42nf")}
+    nf_tot = [0, 0]
     n_instr = 0
     shapes = {}
     hist = {k: np.zeros(65) for k in ("row", "best", "t42")}
@@ -70,6 +71,18 @@ def main():
         Z = np.where(ok, wz / ts * S + 0.5 + 4 * S, 0.0)
         X = np.clip(X, 0, 40 * S); Z = np.clip(Z, 0, 40 * S)
         ids = line_ids(X, Z)
+        # pixels whose MSAA reach (cells) exceeds what any record can grant (128 = half a tile): always resolved by the exact path, for every env --
+        # their gather in the env loop is wasted; "t42nf": those lanes read one shared record instead
+        reach = np.zeros_like(X)
+        for ox_, oy_ in ((0.375, 0.125), (-0.125, 0.375), (-0.375, -0.125), (0.125, -0.375)):
+            nxs, nys = nx + 2 * ox_ / W, ny + 2 * oy_ / H
+            xe2, ye2, yla2, fwd2 = raster._rays(cam, nxs, nys)
+            tt2, wx2, wz2 = raster._plane_hit(cam, xe2, fwd2, yla2, cam.C[1])
+            with np.errstate(invalid="ignore"):
+                reach = np.maximum(reach, np.where(yla2 < 0, np.hypot(wx2 - wx, wz2 - wz) / ts * S, 1e9))
+        never = ok & (1.05 * reach + 0.5 >= 128)
+        ids["t42nf"] = np.where(never, -1, ids["t42"])
+        nf_tot[0] += int(never.sum()); nf_tot[1] += int(ok.sum())
         per = {}
         for sw, sh in ((64, 1), (16, 4), (8, 8)):            # other slot shapes (not built): lines per gather under the shipped and the tiled layout
             for name in ("row", "t42", "t24"):
@@ -97,6 +110,7 @@ def main():
     print(f"{n} poses, {n_instr} full 32 x 2 slots on the tile plane ({n_instr / n / (H // 2 * (W // 32)) * 100:.1f} % of the slots)")
     for name, v in tot.items():
         print(f"  {name:5s} {v / n_instr:6.2f} distinct lines per load instruction")
+    print(f"  pixels on the tile plane that no record can make a one-ray pixel: {nf_tot[0] / max(nf_tot[1], 1) * 100:.2f} %")
     for key, (tot_l, cnt) in shapes.items():
         print(f"  {key:12s} {tot_l / max(cnt, 1):6.2f} distinct lines per load instruction")
     for name, h in hist.items():
