@@ -433,3 +433,24 @@ def test_a_state_renders_to_the_same_bytes_every_time(cfg):
     assert fr[0].std() > 10.0
     for i in range(1, 4):
         assert np.array_equal(fr[0], fr[i]), (cfg, i, int((fr[0] != fr[i]).any(axis=-1).sum()))
+
+
+@pytest.mark.gpu
+def test_k_raster_q_and_k_raster_v3_agree(monkeypatch):
+    """k_raster_q -- the quad-record raster of the other square texture sizes, and of 256 x 256 textures on grids beyond 32 x 24 tiles -- against
+    k_raster_v3 on the SAME batch (DTSIM_RASTER_OLD=1 at dtsim_create keeps k_raster_q for 256 x 256 textures): same records (4 x 2 cells to a
+    line), same snapped coordinates, same byte-weight filter; the exact paths differ in form (k_raster_q's gives interior entries the one-ray
+    colour, k_raster_v3's takes the four samples of every entry), which may move a rounding tie on a queued pixel."""
+    N, W, H = 64, 640, 480
+    out = []
+    for old in ("0", "1"):
+        monkeypatch.setenv("DTSIM_RASTER_OLD", old)
+        sim = BatchedSimulator("small_loop", N, camera_width=W, camera_height=H, distortion=True, domain_rand=False, seed=11, max_steps=100000)
+        acts = np.random.default_rng(3).uniform(0.2, 0.9, (4, N, 2)).astype(np.float32)
+        sim.step(acts, n_steps=4)
+        sim.render()
+        out.append(sim.frames_host().copy())
+        sim.close()
+    d = np.abs(out[0].astype(np.int32) - out[1].astype(np.int32)).max(axis=-1)
+    assert out[0].std() > 10.0
+    assert (d > 0).mean() <= 2e-3 and (d > 1).mean() <= 1e-5, ((d > 0).mean(), (d > 1).mean(), int(d.max()))

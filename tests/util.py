@@ -1,5 +1,6 @@
 """Shared helpers for the parity tests (oracle is the checker, never the product)."""
 import copy
+import os
 
 import numpy as np
 
@@ -58,5 +59,6 @@ def oracle_mode(sim, segment=False):
     side = sim.textures[0].shape[0] if sim.textures else 256
     quad_ok = sim.camera_width % 4 == 0 and not segment
     if sim.domain_rand or sim.per_env_camera:
-        return "pixel-dr" if (quad_ok and side == 256) else "pixel-gl"
+        v3dr = quad_ok and side == 256 and os.environ.get("DTSIM_RASTER_OLD", "0") != "1"   # (the A/B switch that keeps k_raster_q also keeps the generic per-env raster)
+        return "pixel-dr" if v3dr else "pixel-gl"
     return "pixel" if quad_ok else "pixel-gl"
