@@ -53,6 +53,7 @@ def main():
     ts = o.map.tile_size
     tot = {k: 0.0 for k in ("row", "col", "best", "t42", "t24", "zmerge", "t42nf")}
     nf_tot = [0, 0]
+    nf_blk = [0, 0, 0]
     n_instr = 0
     shapes = {}
     hist = {k: np.zeros(65) for k in ("row", "best", "t42")}
@@ -83,6 +84,12 @@ def main():
         never = ok & (1.05 * reach + 0.5 >= 128)
         ids["t42nf"] = np.where(never, -1, ids["t42"])
         nf_tot[0] += int(never.sum()); nf_tot[1] += int(ok.sum())
+        # 128 x 2 wavefront blocks whose tile-plane pixels are ALL such pixels (their env loop could skip loads and filter altogether)
+        okb2 = ok.reshape(H // 2, 2, W // 128, 128).transpose(0, 2, 1, 3).reshape(-1, 256)
+        nvb2 = never.reshape(H // 2, 2, W // 128, 128).transpose(0, 2, 1, 3).reshape(-1, 256)
+        full = okb2.any(1) & (nvb2 | ~okb2).all(1)
+        lines_blk = ids["t42"].reshape(H // 2, 2, W // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 64)
+        nf_blk[0] += int(full.sum()); nf_blk[1] += int(okb2.any(1).sum()); nf_blk[2] += int(nvb2[full].sum())
         per = {}
         for sw, sh in ((64, 1), (16, 4), (8, 8)):            # other slot shapes (not built): lines per gather under the shipped and the tiled layout
             for name in ("row", "t42", "t24"):
@@ -111,6 +118,7 @@ def main():
     for name, v in tot.items():
         print(f"  {name:5s} {v / n_instr:6.2f} distinct lines per load instruction")
     print(f"  pixels on the tile plane that no record can make a one-ray pixel: {nf_tot[0] / max(nf_tot[1], 1) * 100:.2f} %")
+    print(f"  128 x 2 blocks made of such pixels only: {nf_blk[0] / max(nf_blk[1], 1) * 100:.2f} % of the blocks with tile-plane pixels, holding {nf_blk[2] / max(nf_tot[0], 1) * 100:.0f} % of those pixels")
     for key, (tot_l, cnt) in shapes.items():
         print(f"  {key:12s} {tot_l / max(cnt, 1):6.2f} distinct lines per load instruction")
     for name, h in hist.items():
