@@ -222,7 +222,7 @@ struct RenderParams {
   const uint8_t* mesh_seg;      // [n_meshes][4] flat segmentation colour per mesh (segment renders only)
   // quad-layout fast path (null qtex: the generic k_raster is used)
   const uint8_t* qtex;          // quad blocks, 16 B records
-  const uint32_t* qtiles;       // [n_qtiles][2] per padded-table cell: byte offset of its block, cell selector; maps concatenated
+  const uint32_t* qtiles;       // [n_qtiles][2] per padded-table cell: byte offset of its block, mask of the record's offset inside it (cell mask for sizes other than 256); maps concatenated
   int32_t n_qtiles, qlog2;      // qlog2: log2(S), S = tile texture size
   float q_per_m;                // quad cells per metre (S / tile_size), max over maps: scales the MSAA margin
   int32_t qmax_tiles;           // largest padded grid extent over the maps (tiles)

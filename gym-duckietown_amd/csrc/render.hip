@@ -1623,7 +1623,7 @@ __device__ inline void quad_filter3(const uint4& q, float a8, float b8, float I,
 
 #define RQ_LIST 256                                  // MSAA entries compacted per round (the wavefront's 1 KB of LDS)
 // V3: the LDS tile table layout of k_raster_v3 (render_v3.inc: block offset at (tz << 10 | tx << 2) + the map's column
-// offset EnvQ.pad[0], the cell selector 512 bytes behind it) and its wavefront block shape; (tile_x0, wave_y0) is the
+// offset EnvQ.pad[0], the record-offset mask 512 bytes behind it) and its wavefront block shape; (tile_x0, wave_y0) is the
 // origin of the wavefront's block either way.
 // POOL (k_raster_v3, round 3): the four queue regions of a workgroup are drained as ONE list, an equal share per wavefront.
 // w_queue = region 0 of the workgroup, (tile_x0, wave_y0) = origin of the workgroup tile, the wavefront's share = entries
@@ -1647,7 +1647,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
   constexpr int WWc = V3 ? DT_V3_WW : WAVE_W;          // pixel columns of the wavefront block the entries index
   const uint32_t tex_min = 32u;                        // block offsets from here on are textured tiles
 
-  // Table entry (block byte offset, cell selector) of the tile that OWNS padded quad coordinates (X, Z): tile
+  // Table entry (block byte offset, record-offset mask) of the tile that OWNS padded quad coordinates (X, Z): tile
   // boundaries sit at k*S + 0.5 (the GL_LINEAR half-texel shift folded into the coordinates), so ownership is decided
   // on (X - 0.5, Z - 0.5) -- unlike the record lookup, which goes by whole cells.  (ox, oz): the tile's origin.
   auto tile_entry = [&](float X, float Z, const float Xhi, const float Zhi, const uint32_t tab_b, const uint32_t pitch4, uint32_t& ta,
@@ -1861,7 +1861,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
         const float qpm = __uint_as_float(qd.w);                           // quad cells per metre of the env's map
         const float goff = (float)DT_QRING * Sf + 0.5f, ghalf = GROUND_HALF * qpm;   // world 0 and 50 m in padded quad coordinates
         const float Xu = fmaf(pt.lf, B, fmaf(pt.lr, A, Cx)), Zu = fmaf(pt.lf, -A, fmaf(pt.lr, B, Cz));
-        const uint32_t xic = q8_bits(Xu), zic = q8_bits(Zu);              // the centre's snapped coordinates: the cell selectors work on these bits
+        const uint32_t xic = q8_bits(Xu), zic = q8_bits(Zu);              // the centre's snapped coordinates: q8_rec256 works on these bits
         const float lit = pt.lit > 0.f ? pt.lit : 0.55f;
         const uint32_t W8 = quad_weights8(q8_frac(xic), q8_frac(zic), lit * Q8_LIT);
         uint32_t aS[3] = {0u, 0u, 0u};                 // sum over the samples of the byte-weight filter of each sample's record
@@ -3082,7 +3082,7 @@ int dt_launch_render(hipStream_t s, const SimArrays& A, const RenderParams& R_in
   const bool v3dr = R.qtex && R.envd && R.domain_rand && !R.segment && !R.no_msaa && (R.W & 3) == 0 && R.qlog2 == 8 && R.q3_rows > 0 &&
                     R.q3_rows <= 24 && R.n_maps * 32 <= 128;
   // quad-layout fast path: shared camera, square power-of-two tile textures (else the generic k_raster)
-  // (S = 256 tables carry the v_perm cell selector of the S256 kernels, which need a padded grid under 256 tiles)
+  // (S = 256 tables carry the record-offset mask of the S256 kernels -- q8_rec256 --, which need a padded grid under 128 tiles: Q8_SNAP)
   const bool quad = R.qtex && !R.domain_rand && !R.segment && !R.no_msaa && (size_t)R.n_qtiles * 8 <= 32768 && (R.W & 3) == 0 &&
                     !(R.qlog2 == 8 && R.qmax_tiles >= 256);
   const bool obj = R.max_tris > 0;
