@@ -177,7 +177,7 @@ struct EnvD;                                          // render_v3dr.inc: per-en
 __device__ inline void fill_envd_at(EnvD* arr, int idx, const EnvCam& c, const EnvQ& q, const RenderMapDev& m, float q_cells, int H, int W);
 
 // Render order of the envs for the quad-layout path: envs standing on the same tile (and facing the same way) are
-// made neighbours, so that the 32 envs a raster workgroup loops over -- and, with the XCD-affine workgroup map of
+// made neighbours, so that the 64 envs a raster workgroup loops over -- and, with the XCD-affine workgroup map of
 // k_raster_q, all the envs one XCD's L2 serves -- look at the same few texture blocks.  A counting sort by
 // (tile under the camera, heading quadrant) in one workgroup; the order inside a bin is arbitrary (frames are
 // independent, so the order never changes a result).  pos[e] = position of env e.
@@ -1165,34 +1165,36 @@ __device__ inline size_t obj_items_cap(const RenderParams& R) {
   const int n_tiles = ((R.W + DT_TILE_W - 1) / DT_TILE_W) * ((R.H + DT_TILE_H - 1) / DT_TILE_H);
   return (size_t)((R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK) * n_tiles * (ENVS_PER_BLOCK / RES_ENVS);
 }
-__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg, uint32_t groups = ~0u, uint32_t heavy = 0u) {
+typedef unsigned long long envmask_t;                 // one bit per env group of a chunk (ENVS_PER_BLOCK / RES_ENVS <= 64)
+__device__ inline void push_obj_items(const RenderParams& R, uint32_t rwg, envmask_t groups = ~0ull, envmask_t heavy = 0ull) {
   const int ng = ENVS_PER_BLOCK / RES_ENVS;
-  if (ng < 32) groups &= (1u << ng) - 1u;
+  if (ng < 64) groups &= (1ull << ng) - 1ull;
   heavy &= groups;
-  const uint32_t light = groups & ~heavy;
-  const int nh = __popc(heavy), nl = __popc(light);
+  const envmask_t light = groups & ~heavy;
+  const int nh = __popcll(heavy), nl = __popcll(light);
   if (nh) {
     int pos = atomicAdd(R.work + 2, nh);
-    for (int i = 0; i < ng; ++i) if ((heavy >> i) & 1u) R.items2[pos++] = rwg * ITEMS_PER_WG + (uint32_t)i;
+    for (int i = 0; i < ng; ++i) if ((heavy >> i) & 1ull) R.items2[pos++] = rwg * ITEMS_PER_WG + (uint32_t)i;
   }
   if (nl) {
     size_t pos = obj_items_cap(R) - 1 - (size_t)atomicAdd(R.work + 6, nl);
-    for (int i = 0; i < ng; ++i) if ((light >> i) & 1u) R.items2[pos--] = rwg * ITEMS_PER_WG + (uint32_t)i;
+    for (int i = 0; i < ng; ++i) if ((light >> i) & 1ull) R.items2[pos--] = rwg * ITEMS_PER_WG + (uint32_t)i;
   }
 }
 #ifndef DT_RO_HEAVY
 #define DT_RO_HEAVY 128            // entries of one env in one 256-pixel wavefront region from which its unit counts as heavy
 #endif
 // which env groups of the chunk have entries in THIS wavefront's region: qend_v = the region's fill after each env (lane = position)
-__device__ inline uint32_t obj_groups_of(int qend_v, int lane, uint32_t* heavy = nullptr) {
+__device__ inline envmask_t obj_groups_of(int qend_v, int lane, envmask_t* heavy = nullptr) {
+  static_assert(ENVS_PER_BLOCK / RES_ENVS <= 64, "one bit per env group");
   const int up = __shfl_up(qend_v, 1);
   const int cnt = lane < ENVS_PER_BLOCK ? qend_v - (lane == 0 ? 0 : up) : 0;
   const unsigned long long m = __ballot(cnt != 0), mh = __ballot(cnt >= DT_RO_HEAVY);
-  uint32_t g = 0u, gh = 0u;
+  envmask_t g = 0ull, gh = 0ull;
 #pragma unroll
   for (int i = 0; i < ENVS_PER_BLOCK / RES_ENVS; ++i) {
-    g |= ((m >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
-    gh |= ((mh >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1u << i) : 0u;
+    g |= ((m >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1ull << i) : 0ull;
+    gh |= ((mh >> (i * RES_ENVS)) & ((1ull << RES_ENVS) - 1ull)) ? (1ull << i) : 0ull;
   }
   if (heavy) *heavy = gh;
   return g;
@@ -1637,7 +1639,7 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
                                       const uint16_t* w_queue, const int n, const int e0, const int tile_x0, const int wave_y0,
                                       const int lane, const int i0 = 0, const int p1 = 0, const int p2 = 0, const int p3 = 0,
                                       const uint4* s_envq = nullptr) {
-  // s_envq (V3): the EnvQ records of the chunk's 32 positions, staged in LDS by the workgroup -- an entry's constants are three
+  // s_envq (V3): the EnvQ records of the chunk's 64 positions, staged in LDS by the workgroup -- an entry's constants are three
   // ds_read_b128 instead of three 16-byte gathers through the texture unit (in both phases).
   const int npix = R.W * R.H;
   const int LS = R.qlog2;

@@ -32,7 +32,7 @@ OBJ_TOL = dict(frac_gt1=2e-3, frac_gt2=1e-3, mean=0.03)     # scenes with mesh o
 def _stratified_picks(sim, N, n_min, seed):
     """Env indices of an N-env batch that exercise the raster's work decomposition.  The decomposition goes by POSITION in the
     render order of the pass that just ran (DTSIM_FIELD_RENDER_POS: k_env_sort's order on the quad-record paths, the identity
-    elsewhere): 32 consecutive positions share a workgroup chunk, XCD x owns the x-th eighth of the chunks (render_v3.inc:
+    elsewhere): 64 consecutive positions (32 before round 6) share a workgroup chunk, XCD x owns the x-th eighth of the chunks (render_v3.inc:
     XCD-affine workgroup map).  Picked positions: the first / last of the order, both sides of chunk borders, the middle of
     every XCD's eighth (a chunk border there), the tail chunk -- mapped back to env indices -- plus envs 0 and N - 1."""
     pos = sim.read(_ffi.FIELD_RENDER_POS)
@@ -78,7 +78,7 @@ def test_c3_full_size_batch_matches_oracle_directly():
     assert sorted(rpos.tolist()) == list(range(N))
     env_at = np.argsort(rpos)
     assert (np.diff(key[env_at]) >= 0).mean() > 0.98       # sorted by the key (the device bins in float32: an env on a bin border may move)
-    picks += [int(env_at[0]), int(env_at[-1]), 0, N - 1, int(env_at[31]), int(env_at[32])]
+    picks += [int(env_at[0]), int(env_at[-1]), 0, N - 1, int(env_at[31]), int(env_at[32]), int(env_at[63]), int(env_at[64])]
     picks += [int(env_at[i]) for i in range(N // 16, N, N // 8)]    # the middle of each XCD's eighth of the order
     while len(set(picks)) < 64:
         picks.append(int(rng.integers(N)))
@@ -142,7 +142,7 @@ def test_c5_config_matches_oracle():
     scenes = [_scene(n) for n in names]
     rmap = pdist.distortion_maps(W, H)
     n_obj_px = 0
-    for e in (0, 1, 30, 31, 32, 33, 64, 71):               # both maps, chunk borders, the tail chunk
+    for e in (0, 1, 30, 31, 32, 33, 63, 64, 71):           # both maps, chunk borders (64 envs per chunk; 32 before round 6), the tail chunk
         scene = scenes[int(mid[e])]
         cam = _camera(sim, e, W, H, False)
         st = _obj_states(sim, e, scene)
@@ -224,8 +224,8 @@ def test_c5_full_size_batch_matches_oracle_directly():
 def test_render_parts_give_the_same_frames(cfg, monkeypatch):
     """DTSIM_RENDER_PARTS (read at dtsim_create): the chunks of the batch in ranges, the exact-path kernels of one range on a second stream
     beside the raster of the next -- every per-position array addressed relative to the range.  Same frames, bit for bit, as the one-part
-    launch: 512 envs = 16 chunks = two parts of 8 (k_raster_v3<OBJ> in the sorted render order for C5, k_raster_v3dr for C4)."""
-    N = 512
+    launch: 1024 envs = 16 chunks = two parts of 8 (k_raster_v3<OBJ> in the sorted render order for C5, k_raster_v3dr for C4)."""
+    N = 1024
     kw = dict(c5=dict(maps=["loop_only_duckies", "small_loop_only_duckies"], dr=False, extra=dict(map_cycle=True)),
               c4=dict(maps="loop_pedestrians", dr=True, extra={}))[cfg]
     out = []

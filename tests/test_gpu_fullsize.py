@@ -37,7 +37,7 @@ def test_full_size_batch_equals_small_batches():
     big.render()
     big.sync()
     frames = torch.as_tensor(big.frames_device(), device="cuda:0")
-    picks = np.array([0, 1, 31, 32, 1000, 2047, 2048, 4095])          # chunk borders included
+    picks = np.array([0, 1, 31, 32, 63, 64, 1000, 2047, 2048, 4095])  # chunk borders included
     sub = frames[torch.as_tensor(picks, device="cuda:0")].cpu().numpy()
     pos, ang = big.read(_ffi.FIELD_POS), big.read(_ffi.FIELD_ANGLE)
     rew, done = big.read(_ffi.FIELD_REWARD), big.read(_ffi.FIELD_DONE)

@@ -237,7 +237,7 @@ def test_traffic_light_pattern_follows_the_reference_clock():
 
 
 def test_render_is_deterministic_and_per_env():
-    N = 40   # > ENVS_PER_BLOCK: several env chunks
+    N = 72   # > ENVS_PER_BLOCK (64): several env chunks
     sim = BatchedSimulator("small_loop", N, camera_width=160, camera_height=120, domain_rand=False, seed=5)
     sim.render()
     a = sim.frames_host().copy()
@@ -392,7 +392,7 @@ def test_domain_rand_over_two_maps_in_the_render_order():
     """k_raster_v3dr / k_resolve_dr with more than one map resident (MultiMap slot alternation) and more than one chunk, so that the pass runs in
     k_env_sort's order: per-position records (EnvD, object masks, queue regions) against per-env ones (EnvCam, frames, triangles), the maps'
     column offsets in the LDS tile table.  Six envs -- both maps, both chunks, the partial tail chunk -- against the oracle."""
-    N, W, H = 40, 320, 240
+    N, W, H = 72, 320, 240                                 # (> 64 envs: two chunks of the render order, the second one partial)
     names = ["loop_only_duckies", "small_loop_only_duckies"]
     sim = BatchedSimulator(names, N, camera_width=W, camera_height=H, distortion=True, domain_rand=True, seed=23, map_cycle=True, max_steps=100000)
     sim.reset(mask=(np.arange(N) % 2 == 0))                # multimap_env.py:44-49: the two maps alternate over the slots
@@ -406,7 +406,7 @@ def test_domain_rand_over_two_maps_in_the_render_order():
     scenes = [_scene(n) for n in names]
     rmap = pdist.distortion_maps(W, H)
     env_at = np.argsort(rpos)
-    for e in sorted({0, 1, int(env_at[0]), int(env_at[31]), int(env_at[32]), int(env_at[N - 1])}):
+    for e in sorted({0, 1, int(env_at[0]), int(env_at[63]), int(env_at[64]), int(env_at[N - 1])}):
         scene = scenes[int(mid[e])]
         ref = raster.render_obs(_camera(sim, e, W, H, True), scene, "pixel", rmap, obj_states=_obj_states(sim, e, scene))
         s = _stats(frames[e], ref)

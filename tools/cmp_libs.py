@@ -1,4 +1,4 @@
-"""Frames of one batch through two builds of the library (A/B aid):  python tools/cmp_libs.py VARIANT [c3|c5]   (lib/libdtsim.so against lib/libdtsim_VARIANT.so, one process each)."""
+"""Frames of one batch through two builds of the library (A/B aid):  python tools/cmp_libs.py VARIANT [c3|c4|c5]   (lib/libdtsim.so against lib/libdtsim_VARIANT.so, one process each)."""
 import os, subprocess, sys
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,8 +6,9 @@ if len(sys.argv) > 3:                                    # child: render and dum
     sys.path.insert(0, os.path.join(root, "gym-duckietown_amd"))
     from dtsim.batched import BatchedSimulator
     cfg = sys.argv[2]
-    kw = dict(c3=dict(maps="small_loop", extra={}), c5=dict(maps=["loop_only_duckies", "small_loop_only_duckies"], extra=dict(map_cycle=True)))[cfg]
-    sim = BatchedSimulator(kw["maps"], 256, camera_width=640, camera_height=480, distortion=True, domain_rand=False, seed=5, max_steps=100000, **kw["extra"])
+    kw = dict(c3=dict(maps="small_loop", extra={}), c5=dict(maps=["loop_only_duckies", "small_loop_only_duckies"], extra=dict(map_cycle=True)),
+              c4=dict(maps="loop_pedestrians", extra={}, dr=True))[cfg]
+    sim = BatchedSimulator(kw["maps"], 256, camera_width=640, camera_height=480, distortion=True, domain_rand=kw.get("dr", False), seed=5, max_steps=100000, **kw["extra"])
     acts = np.random.default_rng(9).uniform(0.2, 0.9, (4, 256, 2)).astype(np.float32)
     sim.step(acts, n_steps=4); sim.render(); np.save(sys.argv[3], sim.frames_host()); sim.close()
     sys.exit(0)
