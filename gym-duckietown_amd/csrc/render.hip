@@ -2020,9 +2020,20 @@ __device__ inline void resolve_region(const RenderParams& R, const EnvCam* __res
 #ifndef DT_Q_WAVES
 #define DT_Q_WAVES 5                                 // wavefronts per SIMD the register allocation is held to (96 VGPRs)
 #endif
-#ifndef DT_Q_TILE_GROUP
-#define DT_Q_TILE_GROUP 10
+// Frame tiles per group of the launch order: an XCD takes the tiles of a group for one chunk of its slice, then for the next chunk, ..., then the next
+// group.  Round 6: HALF the frame per group (150 tiles at 640 x 480; 10 before) -- with 64 envs per workgroup the tiles of ONE chunk fill an XCD, and the
+// envs of a chunk look at one region of the map (k_env_sort): one L2 serves one region.  C3 - 4.6 %, C5 - 1.8 %; the whole frame as one group is + 5 ... 12 %
+// (profiles/r06_variants_ab.txt block P).  -DDT_Q_TILE_GROUP=n fixes the group size instead (A/B aid).
+#ifndef DT_Q_TILE_SPLIT
+#define DT_Q_TILE_SPLIT 2
 #endif
+__host__ __device__ inline int dt_q_tile_group(int n_tiles) {
+#ifdef DT_Q_TILE_GROUP
+  return DT_Q_TILE_GROUP;
+#else
+  return (n_tiles + DT_Q_TILE_SPLIT - 1) / DT_Q_TILE_SPLIT;
+#endif
+}
 #ifndef DT_Q_PRIO
 #define DT_Q_PRIO 3                                  // s_setprio level while a wavefront issues its quad loads (0: off)
 #endif
@@ -2041,14 +2052,15 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(OBJ ? DT_Q_W
   // eighth of the env chunks (all frame tiles of each): with the envs in k_env_sort order, one L2 serves the envs of one
   // region of the map for the whole launch.  The mapping only matters for speed.
   const int n_chunks = (R.N + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK, cpx = (n_chunks + 7) / 8;
-  // Within an XCD: groups of DT_Q_TILE_GROUP frame tiles, all chunks of the slice for one group before the next group,
+  // Within an XCD: groups of dt_q_tile_group() frame tiles, all chunks of the slice for one group before the next group,
   // so that a tile's PixTab slice (16 KB) is read from HBM once per XCD instead of once per chunk, while the workgroups
   // in flight still belong to few chunks.
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int per_group = DT_Q_TILE_GROUP * cpx;
+  const int q_tg = dt_q_tile_group(n_tiles);
+  const int per_group = q_tg * cpx;
   const int grp = bi / per_group, gi = bi % per_group;
-  const int g_tiles = min(DT_Q_TILE_GROUP, n_tiles - grp * DT_Q_TILE_GROUP);        // the last group may be short
-  const int tile = grp * DT_Q_TILE_GROUP + gi % g_tiles;
+  const int g_tiles = min(q_tg, n_tiles - grp * q_tg);        // the last group may be short
+  const int tile = grp * q_tg + gi % g_tiles;
   const int chunk = xcd * cpx + gi / g_tiles;
   if (gi >= g_tiles * cpx || chunk >= n_chunks) return;   // padding workgroups (whole workgroup)
   const int rwg = chunk * n_tiles + tile;            // logical workgroup index: queue regions, counts, work items
@@ -3019,8 +3031,9 @@ static void launch_raster_resolve(hipStream_t s, hipStream_t s_res, hipEvent_t e
   const size_t lds1 = lds + (size_t)RB * PPT * sizeof(uint32_t);          // + store transpose
   const size_t lds2 = lds + (size_t)(RB / 64) * ENVS_PER_BLOCK * sizeof(EnvCam);
   const dim3 grid((unsigned)(dt_raster_tiles(R.W, R.H) * n_chunks));
-  // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of DT_Q_TILE_GROUP (the last group padded)
-  const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + DT_Q_TILE_GROUP - 1) / DT_Q_TILE_GROUP) * DT_Q_TILE_GROUP * ((n_chunks + 7) / 8) * 8));
+  // XCD-affine map: 8 slices of ceil(n_chunks / 8) chunks, frame tiles in groups of dt_q_tile_group() (the last group padded)
+  const int q_tg = dt_q_tile_group((int)dt_raster_tiles(R.W, R.H));
+  const dim3 gridq((unsigned)(((dt_raster_tiles(R.W, R.H) + q_tg - 1) / q_tg) * q_tg * ((n_chunks + 7) / 8) * 8));
 #define LAUNCH_RASTER(DR_, OBJ_)                                                                              \
   hipLaunchKernelGGL((k_raster<DR_, OBJ_>), grid, dim3(RB), lds1, s, R, cams, fasts, frames_raster, R.texels,               \
                      reinterpret_cast<const float4*>(R.lut), R.maps, R.tile_recs, R.queue, R.qcount)
