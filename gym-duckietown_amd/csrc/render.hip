@@ -48,8 +48,8 @@
 //
 // Roofline: algorithmic bytes per env-step = W*H*3 (921 600 B at 640x480), written once (+ the ~1.3 % edge
 // pixels a second time); LUT / textures / tables are shared by all envs and stay in registers / LDS / L2.
-// Measured (profiles/): the pass is co-limited by vector issue and the texture path's cache-line rate -- 32.8 vector instructions per
-// pixel (round 1: 64.8; round 5: 36.9), 12 lines per record gather, vector ALUs 81 % and texture unit 74 % busy -- at 29 - 31 % of the HBM roofline; float32 geometry, byte-weight
+// Measured (profiles/): the pass is co-limited by vector issue and the texture path's cache-line rate -- 31.1 vector instructions per
+// pixel (round 1: 64.8; round 5: 36.9), 12 lines per record gather, vector ALUs 82 % and texture unit 73 % busy -- at 31.5 - 32.3 % of the HBM roofline; float32 geometry, byte-weight
 // filter at the precision GL's own GL_LINEAR has on the reference's renderer, uint8 output.
 // Parity: every pipeline is held to frames the unmodified reference rendered on Mesa llvmpipe (tests/test_gpu_gl_golden.py).
 #include "dtsim_dev.h"
